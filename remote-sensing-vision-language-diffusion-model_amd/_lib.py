@@ -1,0 +1,81 @@
+"""ctypes binding of librsvld_hip.so (C ABI declared in include/rsvld_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call returns an error
+code this module raises, so a silent CPU/eager path can never stand in for the kernels.
+"""
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "librsvld_hip.so")
+
+F16, BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+
+ERRORS = {-1: "RSVLD_EINVAL (bad shape / pointer / combination)",
+          -2: "RSVLD_EUNSUPPORTED", -3: "RSVLD_ELAUNCH (HIP launch failed)"}
+
+
+class RsvldError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("rowvec", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Cin2", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32),
+        ("pad_l", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("upsample", C.c_int32), ("dtype", C.c_int32), ("out_f32", C.c_int32), ("act", C.c_int32),
+        ("alpha", C.c_float), ("beta", C.c_float), ("rowvec_stride", C.c_int32),
+    ]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/rsvld_hip.h declares
+SIGNATURES = {
+    "rsvld_version": (C.c_char_p, []),
+    "rsvld_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
+    "rsvld_groupnorm_ws_bytes": (_i64, [_i, _i, _i, _i]),
+    "rsvld_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
+    "rsvld_groupnorm_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rsvld_groupnorm_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "rsvld_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
+    "rsvld_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                             _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _vp]),
+    "rsvld_linear_small_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsvld_sinusoidal_embedding": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "rsvld_nchw_f32_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsvld_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsvld_axpby": (_i, [_vp, _vp, _vp, _i64, _f, _f, _i, _vp]),
+    "rsvld_geglu": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "rsvld_ddpm_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RsvldError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RsvldError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C {os.path.join(_PKG_DIR, 'csrc')}`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RsvldError(f"{what} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,290 @@
+// attention.hip — flash-style attention for gfx950: out = softmax(scale * Q K^T) V with an
+// fp32 online softmax; the N x N score matrix never exists in HBM.
+//
+// D = 512 (single head: SR3 SelfAttention, VAE mid-block attention)
+//   workgroup = 4 waves, 64 query rows x 32-key tiles.  Head dim 512 is too wide for one
+//   wave's accumulators, so the head dimension is split: wave w owns d in [128w, 128w+128).
+//     S phase : each wave computes a PARTIAL S^T = K_w Q_w^T over its d-slice (16 MFMAs,
+//               Q fragments live in registers for the whole kernel), partials go to LDS;
+//     softmax : 4 threads per query row sum the 4 partials, online max / sum (wave shuffles),
+//               write P (16-bit) and the per-row rescale factor to LDS;
+//     PV phase: wave w accumulates O^T[d-slice][q] += V^T P^T (16 MFMAs); the query row sits on
+//               the lane, so the online-softmax rescale is one per-lane scalar.
+//   K is staged [kv][d] (XOR-swizzled 1-KiB rows), V is transposed through registers into
+//   V^T [d][kv] so both MFMA operands are ds_read_b128 along the contraction dim.
+//   Next tile's K/V global loads are issued before the S phase (register prefetch).
+#include "rsvld_common.h"
+
+namespace {
+
+struct AttnArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    int B, heads, Nq, Nk, D;
+    int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+    float scale_log2e;
+};
+
+constexpr int A5_KS = 0;
+constexpr int A5_VT = 32768;
+constexpr int A5_SP = 65536;
+constexpr int A5_SP_STRIDE = 36;  // floats per (wave,q) row: 32 + 4 pad -> conflict-free b128 writes
+constexpr int A5_PS = A5_SP + 4 * 64 * A5_SP_STRIDE * 4;
+constexpr int A5_AL = A5_PS + 64 * 64;
+constexpr int A5_SMEM = A5_AL + 2 * 64 * 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_d512_kernel(AttnArgs p) {
+    constexpr int D = 512;
+    typedef typename Mfma<T>::v8 v8;
+    typedef typename Mfma<T>::v4 v4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem + A5_KS;
+    char* VTs = smem + A5_VT;
+    float* Sp = (float*)(smem + A5_SP);
+    char* Ps = smem + A5_PS;
+    float* alpha_s = (float*)(smem + A5_AL);
+    float* l_s = alpha_s + 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const T* Qb = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
+    const T* Kb = (const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D;
+    const T* Vb = (const T*)p.v + (int64_t)b * p.v_bs + (int64_t)h * D;
+    T* Ob = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)h * D;
+
+    // Q fragments (MFMA B operand: col = query row on the lane, k = d)
+    v8 qf[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int row = q0 + qt * 32 + l31;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < p.Nq) v = *(const u32x4*)(Qb + (int64_t)row * p.q_ts + w * 128 + ks * 16 + lh * 8);
+            qf[qt][ks] = __builtin_bit_cast(v8, v);
+        }
+
+    f32x16 oacc[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][qt][r] = 0.f;
+
+    // softmax role: row sq, 8 keys starting at 8*part
+    const int sq = tid >> 2, part = tid & 3;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging roles
+    const int kvb = tid & 3, db = tid >> 2;
+    u32x4 rk[8], rv[8];
+    auto load_kv = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 6, ch = idx & 63;
+            const int kv = t * 32 + row;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (kv < p.Nk) v = *(const u32x4*)(Kb + (int64_t)kv * p.k_ts + ch * 8);
+            rk[i] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int kv = t * 32 + kvb * 8 + r;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (kv < p.Nk) v = *(const u32x4*)(Vb + (int64_t)kv * p.v_ts + db * 8);
+            rv[r] = v;
+        }
+    };
+    auto store_k = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 6, ch = idx & 63;
+            *(u32x4*)(Ks + row * 1024 + ((ch ^ (row & 15)) << 4)) = rk[i];
+        }
+    };
+    auto store_v = [&]() {
+        v8 vin[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) vin[r] = __builtin_bit_cast(v8, rv[r]);
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd) {
+            v8 o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = vin[r][dd];
+            const int d = db * 8 + dd;
+            *(v8*)(VTs + d * 64 + ((kvb ^ ((d >> 2) & 3)) << 4)) = o;
+        }
+    };
+
+    const int ntiles = (p.Nk + 31) / 32;
+    load_kv(0);
+    store_k();
+    store_v();
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        if (more) load_kv(t + 1);
+
+        // ---- S phase: partial S^T[kv][q] over this wave's d-slice
+        f32x16 sacc[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[qt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int ch = w * 16 + ks * 2 + lh;
+            const v8 kf = *(const v8*)(Ks + l31 * 1024 + ((ch ^ (l31 & 15)) << 4));
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) sacc[qt] = Mfma<T>::mma(kf, qf[qt][ks], sacc[qt]);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qq = qt * 32 + l31;
+                const int kvc = 8 * g + 4 * lh;
+                f32x4 v = {sacc[qt][4 * g], sacc[qt][4 * g + 1], sacc[qt][4 * g + 2], sacc[qt][4 * g + 3]};
+                *(f32x4*)(Sp + (w * 64 + qq) * A5_SP_STRIDE + kvc) = v;
+            }
+        __syncthreads();  // (A) partial scores visible; K tile free
+        if (more) store_k();
+
+        // ---- softmax over the 32 keys of this tile (4 threads per row)
+        {
+            float s[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const float* src = Sp + (ww * 64 + sq) * A5_SP_STRIDE + part * 8;
+                const f32x4 a = *(const f32x4*)src;
+                const f32x4 c = *(const f32x4*)(src + 4);
+                s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3];
+                s[4] += c[0]; s[5] += c[1]; s[6] += c[2]; s[7] += c[3];
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kv = t * 32 + part * 8 + e;
+                s[e] = kv < p.Nk ? s[e] * p.scale_log2e : -INFINITY;
+                mx = fmaxf(mx, s[e]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            const float m_new = fmaxf(m_run, mx);
+            const float a = exp2f(m_run - m_new);
+            float pr[8], rs = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pr[e] = exp2f(s[e] - m_new); rs += pr[e]; }
+            rs += __shfl_xor(rs, 1);
+            rs += __shfl_xor(rs, 2);
+            l_run = l_run * a + rs;
+            m_run = m_new;
+            *(u32x4*)(Ps + sq * 64 + ((part ^ ((sq >> 2) & 3)) << 4)) = pack8<T>(pr);
+            if (part == 0) alpha_s[sq] = a;
+        }
+        __syncthreads();  // (B) P and rescale factors visible
+
+        // ---- PV phase: O^T[d][q] = alpha*O^T + V^T P^T over this wave's d-slice
+        {
+            const float a0 = alpha_s[l31], a1 = alpha_s[32 + l31];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[dt][0][r] *= a0; oacc[dt][1][r] *= a1; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ch = 2 * ks + lh;
+                v8 pf[2];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const int qq = qt * 32 + l31;
+                    pf[qt] = *(const v8*)(Ps + qq * 64 + ((ch ^ ((qq >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int d = w * 128 + dt * 32 + l31;
+                    const v8 vf = *(const v8*)(VTs + d * 64 + ((ch ^ ((d >> 2) & 3)) << 4));
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mfma<T>::mma(vf, pf[qt], oacc[dt][qt]);
+                }
+            }
+        }
+        __syncthreads();  // (C) V^T / P free
+        if (more) store_v();
+    }
+
+    if (part == 0) l_s[sq] = l_run;
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int row = q0 + qt * 32 + l31;
+        if (row >= p.Nq) continue;
+        const float inv = 1.0f / l_s[qt * 32 + l31];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)(oacc[dt][qt][4 * g + e] * inv);
+                const int d = w * 128 + dt * 32 + 8 * g + 4 * lh;
+                *(v4*)(Ob + (int64_t)row * p.o_ts + d) = o;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
+                               int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
+                               int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride,
+                               int64_t o_batch_stride, int64_t o_tok_stride, float scale, int dtype, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return RSVLD_EINVAL;
+    if (dtype != RSVLD_F16 && dtype != RSVLD_BF16) return RSVLD_EINVAL;
+    // 16-byte vector access along d: strides must keep rows 8-element aligned
+    if ((q_tok_stride | k_tok_stride | v_tok_stride | o_tok_stride | q_batch_stride | k_batch_stride | v_batch_stride |
+         o_batch_stride) & 7)
+        return RSVLD_EINVAL;
+    if (heads > 65535 || B > 65535) return RSVLD_EINVAL;
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.out = out;
+    a.B = B; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.D = D;
+    a.q_bs = q_batch_stride; a.q_ts = q_tok_stride; a.k_bs = k_batch_stride; a.k_ts = k_tok_stride;
+    a.v_bs = v_batch_stride; a.v_ts = v_tok_stride; a.o_bs = o_batch_stride; a.o_ts = o_tok_stride;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 512) {
+        dim3 grid((unsigned)((Nq + 63) / 64), (unsigned)heads, (unsigned)B);
+        if (dtype == RSVLD_F16) {
+            static bool set = false;
+            if (!set) {
+                if (hipFuncSetAttribute((const void*)attn_d512_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        A5_SMEM) != hipSuccess)
+                    return RSVLD_ELAUNCH;
+                set = true;
+            }
+            hipLaunchKernelGGL(attn_d512_kernel<f16>, grid, dim3(256), A5_SMEM, s, a);
+        } else {
+            static bool set = false;
+            if (!set) {
+                if (hipFuncSetAttribute((const void*)attn_d512_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        A5_SMEM) != hipSuccess)
+                    return RSVLD_ELAUNCH;
+                set = true;
+            }
+            hipLaunchKernelGGL(attn_d512_kernel<bf16>, grid, dim3(256), A5_SMEM, s, a);
+        }
+        return rsvld_check_launch();
+    }
+    return RSVLD_EUNSUPPORTED;
+}

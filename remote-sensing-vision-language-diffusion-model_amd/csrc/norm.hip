@@ -1,0 +1,300 @@
+// norm.hip — GroupNorm (+SiLU, +ZeroSFT modulation) and LayerNorm over NHWC / token-major
+// 16-bit tensors.  HBM-bound: every pass moves 16 B per lane, statistics in fp32 with a
+// deterministic two-level reduction (per-block partials -> fp64 finalize), no atomics.
+#include "rsvld_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// pass 1: per (image, row-chunk) partial sums  part[b][chunk][g] = (sum, sumsq)
+// thread -> fixed 8-channel chunk, strided over rows; per-channel sums go through LDS so
+// that any group size (2 .. C/groups, not necessarily a multiple of 8) is handled.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
+                                                         float* __restrict__ part, int HW, int C1, int C2,
+                                                         int groups, int rows_per_chunk, int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sm = (float*)smem_raw;  // [rif][C][2]
+    const int C = C1 + C2, C8 = C >> 3, C1_8 = C1 >> 3;
+    const int TPR = C8 < 256 ? C8 : 256;  // threads per row
+    const int rif = 256 / TPR;            // rows in flight
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int row_lo = chunk * rows_per_chunk;
+    const int row_hi = min(HW, row_lo + rows_per_chunk);
+    const int tc = tid % TPR, rsub = tid / TPR;
+    if (rsub < rif) {
+        for (int cc = tc; cc < C8; cc += TPR) {
+            float s[8], ss[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+            const T* src;
+            int64_t cstride;
+            int coff;
+            if (cc < C1_8) { src = x1 + (int64_t)b * HW * C1; cstride = C1; coff = cc * 8; }
+            else { src = x2 + (int64_t)b * HW * C2; cstride = C2; coff = (cc - C1_8) * 8; }
+            for (int r = row_lo + rsub; r < row_hi; r += rif) {
+                const u32x4 v = *(const u32x4*)(src + (int64_t)r * cstride + coff);
+                float f[8];
+                unpack8<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+            }
+            float* dst = sm + ((int64_t)rsub * C + cc * 8) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dst[2 * e] = s[e]; dst[2 * e + 1] = ss[e]; }
+        }
+    }
+    __syncthreads();
+    const int gs = C / groups;
+    for (int g = tid; g < groups; g += 256) {
+        float s = 0.f, ss = 0.f;
+        for (int r = 0; r < rif; ++r) {
+            const float* src = sm + ((int64_t)r * C + g * gs) * 2;
+            for (int e = 0; e < gs; ++e) { s += src[2 * e]; ss += src[2 * e + 1]; }
+        }
+        float* o = part + (((int64_t)b * nchunks + chunk) * groups + g) * 2;
+        o[0] = s;
+        o[1] = ss;
+    }
+}
+
+// pass 2: stats[b][g] = (mean, biased var), fp64 merge of the partials (deterministic)
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int groups,
+                                   int nchunks, double inv_count, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / groups, g = i - b * groups;
+    double s = 0.0, ss = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+        const float* p = part + (((int64_t)b * nchunks + c) * groups + g) * 2;
+        s += (double)p[0];
+        ss += (double)p[1];
+    }
+    const double mean = s * inv_count;
+    double var = ss * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)var;
+}
+
+// pass 3: y = act((x-mean)*rstd*gamma+beta) [*(1+scale1p)+shift]
+// grid (blocks over HW*C8 chunks, B); per-channel a/b cached in LDS per block.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
+                                                       T* __restrict__ y, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const T* __restrict__ mod_scale, const T* __restrict__ mod_shift,
+                                                       int HW, int C1, int C2, int groups, float eps, int silu,
+                                                       int chunks_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sa = (float*)smem_raw;  // [C] scale
+    const int C = C1 + C2, C8 = C >> 3, C1_8 = C1 >> 3;
+    float* sb = sa + C;            // [C] shift
+    const int b = blockIdx.y;
+    const int gs = C / groups;
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const int g = ch / gs;
+        const float mean = stats[((int64_t)b * groups + g) * 2];
+        const float var = stats[((int64_t)b * groups + g) * 2 + 1];
+        const float rstd = 1.0f / sqrtf(var + eps);
+        const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
+        const float a = rstd * ga;
+        sa[ch] = a;
+        sb[ch] = be - mean * a;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)HW * C8;
+    const int64_t lo = (int64_t)blockIdx.x * chunks_per_block;
+    const int64_t hi = min(total, lo + chunks_per_block);
+    for (int64_t idx = lo + threadIdx.x; idx < hi; idx += 256) {
+        const int64_t r = idx / C8;
+        const int cc = (int)(idx - r * C8);
+        u32x4 v;
+        if (cc < C1_8) v = *(const u32x4*)(x1 + ((int64_t)b * HW + r) * C1 + cc * 8);
+        else v = *(const u32x4*)(x2 + ((int64_t)b * HW + r) * C2 + (cc - C1_8) * 8);
+        float f[8];
+        unpack8<T>(v, f);
+        const int c0 = cc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = f[e] * sa[c0 + e] + sb[c0 + e];
+            if (silu) t = silu_f(t);
+            f[e] = t;
+        }
+        const int64_t o = ((int64_t)b * HW + r) * C + c0;
+        if (mod_scale != nullptr) {
+            float ms[8], mh[8];
+            unpack8<T>(*(const u32x4*)(mod_scale + o), ms);
+            unpack8<T>(*(const u32x4*)(mod_shift + o), mh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] * (1.f + ms[e]) + mh[e];
+        }
+        *(u32x4*)(y + o) = pack8<T>(f);
+    }
+}
+
+// LayerNorm: one wave per row, row kept in registers (C <= 4096), exact two-pass variance.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int64_t rows, int C, float eps) {
+    constexpr int MAXC = 8;  // chunks of 8 per lane -> C <= 64*8*8 = 4096
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C8 = C >> 3;
+    float f[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int cc = lane + 64 * j;
+        if (cc < C8) {
+            unpack8<T>(*(const u32x4*)(x + row * C + cc * 8), f[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[j][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int cc = lane + 64 * j;
+        if (cc < C8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int cc = lane + 64 * j;
+        if (cc < C8) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = cc * 8 + e;
+                o[e] = (f[j][e] - mean) * rstd * (gamma ? gamma[ch] : 1.f) + (beta ? beta[ch] : 0.f);
+            }
+            *(u32x4*)(y + row * C + cc * 8) = pack8<T>(o);
+        }
+    }
+}
+
+struct GnPlan {
+    int nchunks, rows_per_chunk;
+};
+GnPlan gn_plan(int B, int HW) {
+    int max_chunks = 2048 / (B > 0 ? B : 1);
+    if (max_chunks < 1) max_chunks = 1;
+    if (max_chunks > 256) max_chunks = 256;
+    int rpc = (HW + max_chunks - 1) / max_chunks;
+    if (rpc < 32) rpc = 32;
+    GnPlan p;
+    p.rows_per_chunk = rpc;
+    p.nchunks = (HW + rpc - 1) / rpc;
+    return p;
+}
+
+bool gn_shape_ok(int B, int HW, int C1, int C2, int groups) {
+    if (B <= 0 || HW <= 0 || C1 <= 0 || C1 % 8 || C2 < 0 || C2 % 8 || groups <= 0) return false;
+    const int C = C1 + C2;
+    if (C % groups) return false;
+    if (C > 8192 || groups > 256) return false;
+    return true;
+}
+
+template <typename T>
+int gn_stats_impl(const void* x, const void* x2, float* stats, int B, int HW, int C1, int C2, int groups, void* ws,
+                  hipStream_t s) {
+    const GnPlan pl = gn_plan(B, HW);
+    const int C = C1 + C2, C8 = C / 8;
+    const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
+    const size_t smem = (size_t)rif * C * 2 * sizeof(float);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(pl.nchunks, B), dim3(256), smem, s, (const T*)x, (const T*)x2, part,
+                       HW, C1, C2, groups, pl.rows_per_chunk, pl.nchunks);
+    const int total = B * groups;
+    const double inv_count = 1.0 / ((double)HW * (double)(C / groups));
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, stats, groups, pl.nchunks,
+                       inv_count, total);
+    return rsvld_check_launch();
+}
+
+template <typename T>
+int gn_apply_impl(const void* x, const void* x2, void* y, const float* stats, const float* gamma, const float* beta,
+                  const void* mscale, const void* mshift, int B, int HW, int C1, int C2, int groups, float eps,
+                  int silu, hipStream_t s) {
+    const int C = C1 + C2;
+    const int64_t total = (int64_t)HW * (C / 8);
+    int cpb = 2048;  // 16-B chunks per block (32 KiB of input)
+    // keep the LDS prologue (2*C floats) small relative to the block's work
+    if (C > 1024) cpb = 4096;
+    const int64_t nblk = cdiv64(total, cpb);
+    const size_t smem = (size_t)C * 2 * sizeof(float);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)nblk, B), dim3(256), smem, s, (const T*)x, (const T*)x2,
+                       (T*)y, stats, gamma, beta, (const T*)mscale, (const T*)mshift, HW, C1, C2, groups, eps, silu,
+                       cpb);
+    return rsvld_check_launch();
+}
+
+}  // namespace
+
+extern "C" int64_t rsvld_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
+    (void)C;
+    if (B <= 0 || HW <= 0 || groups <= 0) return 0;
+    const GnPlan pl = gn_plan(B, HW);
+    // partials + final stats
+    return ((int64_t)B * pl.nchunks * groups * 2 + (int64_t)B * groups * 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int rsvld_groupnorm_stats(const void* x, const void* x2, float* mean_var, int B, int HW, int C1, int C2,
+                                     int groups, int dtype, void* ws, void* stream) {
+    if (!x || !mean_var || !ws || !gn_shape_ok(B, HW, C1, C2, groups) || ((C2 > 0) != (x2 != nullptr))) return RSVLD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RSVLD_F16) return gn_stats_impl<f16>(x, x2, mean_var, B, HW, C1, C2, groups, ws, s);
+    if (dtype == RSVLD_BF16) return gn_stats_impl<bf16>(x, x2, mean_var, B, HW, C1, C2, groups, ws, s);
+    return RSVLD_EINVAL;
+}
+
+extern "C" int rsvld_groupnorm_apply(const void* x, const void* x2, void* y, const float* mean_var,
+                                     const float* gamma, const float* beta, const void* mod_scale1p,
+                                     const void* mod_shift, int B, int HW, int C1, int C2, int groups, float eps,
+                                     int silu, int dtype, void* stream) {
+    if (!x || !y || !mean_var || !gn_shape_ok(B, HW, C1, C2, groups) || ((C2 > 0) != (x2 != nullptr))) return RSVLD_EINVAL;
+    if ((mod_scale1p != nullptr) != (mod_shift != nullptr)) return RSVLD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RSVLD_F16)
+        return gn_apply_impl<f16>(x, x2, y, mean_var, gamma, beta, mod_scale1p, mod_shift, B, HW, C1, C2, groups, eps, silu, s);
+    if (dtype == RSVLD_BF16)
+        return gn_apply_impl<bf16>(x, x2, y, mean_var, gamma, beta, mod_scale1p, mod_shift, B, HW, C1, C2, groups, eps, silu, s);
+    return RSVLD_EINVAL;
+}
+
+extern "C" int rsvld_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta,
+                                    const void* mod_scale1p, const void* mod_shift, int B, int HW, int C1, int C2,
+                                    int groups, float eps, int silu, int dtype, void* ws, void* stream) {
+    if (!ws) return RSVLD_EINVAL;
+    if (!gn_shape_ok(B, HW, C1, C2, groups)) return RSVLD_EINVAL;
+    const GnPlan pl = gn_plan(B, HW);
+    float* stats = (float*)ws + (int64_t)B * pl.nchunks * groups * 2;
+    int rc = rsvld_groupnorm_stats(x, x2, stats, B, HW, C1, C2, groups, dtype, ws, stream);
+    if (rc != RSVLD_OK) return rc;
+    return rsvld_groupnorm_apply(x, x2, y, stats, gamma, beta, mod_scale1p, mod_shift, B, HW, C1, C2, groups, eps, silu,
+                                 dtype, stream);
+}
+
+extern "C" int rsvld_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C,
+                               float eps, int dtype, void* stream) {
+    if (!x || !y || rows <= 0 || C <= 0 || C % 8 || C > 4096) return RSVLD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nblk = (unsigned)cdiv64(rows, 4);
+    if (dtype == RSVLD_F16)
+        hipLaunchKernelGGL(layernorm_kernel<f16>, dim3(nblk), dim3(256), 0, s, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
+    else if (dtype == RSVLD_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<bf16>, dim3(nblk), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, rows, C, eps);
+    else
+        return RSVLD_EINVAL;
+    return rsvld_check_launch();
+}

@@ -1,0 +1,73 @@
+// rsvld_common.h — shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rsvld_hip.h"
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define RSVLD_WAVE 64
+
+// Per-dtype traits: 8-wide operand vector and the 32x32x16 MFMA.
+// Operand maps (cdna_hip_programming.md §3): lane l holds A[row l&31][k = 8*(l>>5)+j] and
+// B[k = 8*(l>>5)+j][col l&31]; D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+template <typename T> struct Mfma;
+template <> struct Mfma<f16> {
+    typedef f16x8 v8;
+    typedef f16x4 v4;
+    static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<bf16> {
+    typedef bf16x8 v8;
+    typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// unpack / pack 8 x 16-bit <-> 8 x fp32 through a 16-byte register quad
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4& r, float (&f)[8]) {
+    typename Mfma<T>::v8 v = __builtin_bit_cast(typename Mfma<T>::v8, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    typename Mfma<T>::v8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (T)f[e];
+    return __builtin_bit_cast(u32x4, v);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+static inline int rsvld_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? RSVLD_OK : RSVLD_ELAUNCH;
+}
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

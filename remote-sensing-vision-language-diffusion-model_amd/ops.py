@@ -1,0 +1,289 @@
+"""Tensor-level wrappers over the C ABI (include/rsvld_hip.h).
+
+torch is used here only for device memory (allocation through its caching allocator) and for the
+current HIP stream; every computation is a kernel of librsvld_hip.so.  Activations are NHWC
+16-bit tensors ``[B, H, W, C]`` with ``C % 8 == 0``; tokens ``[B, N, C]`` are the same thing with
+``H = 1``.  Every function raises if the tensor is not on a GPU: there is no CPU path.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float16: L.F16, torch.bfloat16: L.BF16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.RsvldError("rsvld_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise L.RsvldError(f"16-bit activation expected, got {t.dtype}")
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------- weights
+class PackedConv:
+    """K-major 16-bit weights of a Conv2d / Linear: ``w[Cout_p, KH*KW*Cin_p]``, bias fp32."""
+
+    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu")
+
+    def __init__(self, w, bias, cin, cout, cin_p, cout_p, kh, kw, geglu=False):
+        self.w, self.bias = w, bias
+        self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
+        self.kh, self.kw, self.geglu = kh, kw, geglu
+
+
+def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
+    """fp32 ``[Cout, Cin, KH, KW]`` (or Linear ``[Cout, Cin]``) -> PackedConv on ``device``.
+
+    ``cin_split=(C1, C2)``: the layer consumes the concatenation of two NHWC tensors whose channel
+    counts are padded separately to multiples of 8.  ``geglu``: rows are re-ordered so that value j
+    and gate j (rows j and j + Cout/2 of the reference weight, sgm/modules/attention.py:84-96)
+    become adjacent output channels 2j, 2j+1.
+    """
+    w = weight.detach().to("cpu", torch.float32)
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, kh, kw = w.shape
+    b = None if bias is None else bias.detach().to("cpu", torch.float32)
+    if geglu:
+        half = cout // 2
+        idx = torch.stack([torch.arange(half), torch.arange(half) + half], 1).reshape(-1)
+        w = w[idx]
+        b = None if b is None else b[idx]
+    parts = [cin] if cin_split is None else list(cin_split)
+    assert sum(parts) == cin
+    w = w.permute(0, 2, 3, 1)  # [Cout, KH, KW, Cin]
+    chunks, off = [], 0
+    for c in parts:
+        blk = w[..., off:off + c]
+        if pad8(c) != c:
+            blk = torch.nn.functional.pad(blk, (0, pad8(c) - c))
+        chunks.append(blk)
+        off += c
+    w = torch.cat(chunks, dim=-1)
+    cin_p = w.shape[-1]
+    cout_p = pad8(cout) if not geglu else (cout + 15) // 16 * 16
+    if cout_p != cout:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_p - cout))
+        if b is not None:
+            b = torch.nn.functional.pad(b, (0, cout_p - cout))
+    w = w.reshape(cout_p, kh * kw * cin_p).contiguous().to(device=device, dtype=dtype)
+    b = None if b is None else b.contiguous().to(device)
+    return PackedConv(w, b, cin, cout, cin_p, cout_p, kh, kw, geglu)
+
+
+# ----------------------------------------------------------------------------- conv / linear
+def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, residual=None,
+           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0):
+    """NHWC convolution through rsvld_conv2d_nhwc.  ``pad`` = int or (top, left, bottom, right)."""
+    _need_gpu(x, x2, pc.w, rowvec, residual)
+    B, H, W, Cin = x.shape
+    Cin2 = 0 if x2 is None else x2.shape[-1]
+    if Cin + Cin2 != pc.cin_p:
+        raise L.RsvldError(f"conv2d: input channels {Cin}+{Cin2} != packed {pc.cin_p}")
+    if pad is None:
+        pad = pc.kh // 2
+    if isinstance(pad, int):
+        pt = pl = pb = pr = pad
+    else:
+        pt, pl, pb, pr = pad
+    Hin, Win = (2 * H, 2 * W) if upsample else (H, W)
+    Ho = (Hin + pt + pb - pc.kh) // stride + 1
+    Wo = (Win + pl + pr - pc.kw) // stride + 1
+    geglu = act == L.ACT_GEGLU
+    c_out = pc.cout_p // 2 if geglu else pc.cout_p
+    out = torch.empty((B, Ho, Wo, c_out), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise L.RsvldError("conv2d: inputs must be contiguous NHWC")
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()):
+        raise L.RsvldError("conv2d: residual must match the output shape")
+    rv_stride = 0
+    if rowvec is not None:
+        if tuple(rowvec.shape) != (B, pc.cout_p) or rowvec.dtype != torch.float32 or rowvec.stride(1) != 1:
+            raise L.RsvldError("conv2d: rowvec must be fp32 [B, Cout] with unit inner stride")
+        rv_stride = rowvec.stride(0) if B > 1 else pc.cout_p
+    d = L.ConvDesc(
+        x=x.data_ptr(), x2=None if x2 is None else x2.data_ptr(), w=pc.w.data_ptr(),
+        bias=None if pc.bias is None else pc.bias.data_ptr(),
+        rowvec=None if rowvec is None else rowvec.data_ptr(),
+        residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
+        B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride,
+        pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=_dt(x), out_f32=int(out_f32),
+        act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride)
+    L.check(L.load().rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc")
+    return out
+
+
+def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0):
+    """``[..., Cin] -> [..., Cout]`` on token-major tensors (a 1x1 conv over rows)."""
+    shp = x.shape
+    rows = x.numel() // shp[-1]
+    res = None if residual is None else residual.reshape(1, 1, rows, residual.shape[-1])
+    y = conv2d(x.reshape(1, 1, rows, shp[-1]), pc, pad=0, residual=res, act=act, alpha=alpha, beta=beta)
+    return y.reshape(*shp[:-1], y.shape[-1])
+
+
+# ----------------------------------------------------------------------------- norms
+def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None):
+    """GroupNorm(+SiLU) over NHWC ``x`` (or the channel concat [x | x2])."""
+    _need_gpu(x, x2, gamma, beta)
+    B, H, W, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    lib = L.load()
+    ws = torch.empty(lib.rsvld_groupnorm_ws_bytes(B, H * W, C1 + C2, groups), device=x.device, dtype=torch.uint8)
+    y = torch.empty((B, H, W, C1 + C2), device=x.device, dtype=x.dtype)
+    L.check(lib.rsvld_groupnorm_nhwc(_ptr(x), _ptr(x2), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mod_scale1p),
+                                     _ptr(mod_shift), B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _ptr(ws),
+                                     _stream()), "rsvld_groupnorm_nhwc")
+    return y
+
+
+def group_norm_stats(x, groups, *, x2=None):
+    """-> fp32 ``[B, groups, 2]`` (mean, biased variance)."""
+    _need_gpu(x, x2)
+    B, H, W, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    lib = L.load()
+    ws = torch.empty(lib.rsvld_groupnorm_ws_bytes(B, H * W, C1 + C2, groups), device=x.device, dtype=torch.uint8)
+    st = torch.empty((B, groups, 2), device=x.device, dtype=torch.float32)
+    L.check(lib.rsvld_groupnorm_stats(_ptr(x), _ptr(x2), _ptr(st), B, H * W, C1, C2, groups, _dt(x), _ptr(ws),
+                                      _stream()), "rsvld_groupnorm_stats")
+    return st
+
+
+def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False):
+    _need_gpu(x, x2, stats, gamma, beta)
+    B, H, W, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    y = torch.empty((B, H, W, C1 + C2), device=x.device, dtype=x.dtype)
+    L.check(L.load().rsvld_groupnorm_apply(_ptr(x), _ptr(x2), _ptr(y), _ptr(stats), _ptr(gamma), _ptr(beta), None,
+                                           None, B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _stream()),
+            "rsvld_groupnorm_apply")
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    _need_gpu(x, gamma, beta)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    L.check(L.load().rsvld_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, _dt(x), _stream()),
+            "rsvld_layernorm")
+    return y
+
+
+# ----------------------------------------------------------------------------- attention
+def attention(q, k, v, heads, scale=None):
+    """q ``[B, Nq, heads*D]``, k/v ``[B, Nk, heads*D]`` (views with a token stride are fine, e.g.
+    slices of a fused qkv tensor) -> ``[B, Nq, heads*D]`` contiguous."""
+    _need_gpu(q, k, v)
+    B, Nq, HD = q.shape
+    Nk = k.shape[1]
+    D = HD // heads
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    for t in (q, k, v):
+        if t.stride(2) != 1:
+            raise L.RsvldError("attention: last dim must be contiguous")
+    out = torch.empty((B, Nq, HD), device=q.device, dtype=q.dtype)
+    L.check(L.load().rsvld_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
+                                     q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                     out.stride(0), out.stride(1), scale, _dt(q), _stream()), "rsvld_attention")
+    return out
+
+
+# ----------------------------------------------------------------------------- small fp32 layers
+def linear_small(x, w, b, act_in=0, act_out=0):
+    """fp32 ``[rows, in] -> [rows, out]`` with torch nn.Linear weight layout."""
+    _need_gpu(x, w, b)
+    rows, in_f = x.shape
+    out_f = w.shape[0]
+    y = torch.empty((rows, out_f), device=x.device, dtype=torch.float32)
+    L.check(L.load().rsvld_linear_small_f32(_ptr(x), _ptr(w), _ptr(b), _ptr(y), rows, in_f, out_f, act_in, act_out,
+                                            _stream()), "rsvld_linear_small_f32")
+    return y
+
+
+def sinusoidal(t, dim, kind):
+    _need_gpu(t)
+    t = t.reshape(-1).contiguous().float()
+    out = torch.empty((t.numel(), dim), device=t.device, dtype=torch.float32)
+    L.check(L.load().rsvld_sinusoidal_embedding(_ptr(t), _ptr(out), t.numel(), dim, kind, _stream()),
+            "rsvld_sinusoidal_embedding")
+    return out
+
+
+# ----------------------------------------------------------------------------- layout / elementwise
+def nchw_to_nhwc(src, dtype, c_dst=None, c_off=0, out=None):
+    """fp32 NCHW -> 16-bit NHWC with channels padded to ``c_dst`` (default: next multiple of 8)."""
+    _need_gpu(src)
+    B, Cc, H, W = src.shape
+    src = src.contiguous().float()
+    if out is None:
+        c_dst = pad8(Cc) if c_dst is None else c_dst
+        out = torch.empty((B, H, W, c_dst), device=src.device, dtype=dtype)
+        zero = 1
+    else:
+        c_dst, zero = out.shape[-1], 0
+    L.check(L.load().rsvld_nchw_f32_to_nhwc(_ptr(src), _ptr(out), B, Cc, H, W, c_dst, c_off, zero, _DT[out.dtype],
+                                            _stream()), "rsvld_nchw_f32_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(src, channels=None, c_off=0):
+    """NHWC (16-bit or fp32) -> fp32 NCHW, keeping channels [c_off, c_off+channels)."""
+    _need_gpu(src)
+    B, H, W, Cs = src.shape
+    Cc = Cs - c_off if channels is None else channels
+    out = torch.empty((B, Cc, H, W), device=src.device, dtype=torch.float32)
+    f32 = src.dtype == torch.float32
+    L.check(L.load().rsvld_nhwc_to_nchw_f32(_ptr(src), _ptr(out), B, Cc, H, W, Cs, c_off, int(f32),
+                                            0 if f32 else _dt(src), _stream()), "rsvld_nhwc_to_nchw_f32")
+    return out
+
+
+def axpby(a, b, sa=1.0, sb=1.0):
+    _need_gpu(a, b)
+    out = torch.empty_like(a)
+    L.check(L.load().rsvld_axpby(_ptr(a), _ptr(b), _ptr(out), a.numel(), sa, sb, _dt(a), _stream()), "rsvld_axpby")
+    return out
+
+
+def geglu(x):
+    _need_gpu(x)
+    Cc = x.shape[-1] // 2
+    rows = x.numel() // x.shape[-1]
+    out = torch.empty((*x.shape[:-1], Cc), device=x.device, dtype=x.dtype)
+    L.check(L.load().rsvld_geglu(_ptr(x), _ptr(out), rows, Cc, _dt(x), _stream()), "rsvld_geglu")
+    return out
+
+
+def ddpm_step(x, eps_nhwc, noise, c_recip, c_recipm1, coef1, coef2, sigma, clip=True):
+    """SR3 ancestral step on fp32 NCHW ``x`` with the UNet's fp32 NHWC eps (diffusion.py:142-175)."""
+    _need_gpu(x, eps_nhwc, noise)
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    L.check(L.load().rsvld_ddpm_step(_ptr(x), _ptr(eps_nhwc), _ptr(noise), _ptr(out), B, Cc, H, W,
+                                     eps_nhwc.shape[-1], c_recip, c_recipm1, coef1, coef2, sigma, int(clip),
+                                     _stream()), "rsvld_ddpm_step")
+    return out

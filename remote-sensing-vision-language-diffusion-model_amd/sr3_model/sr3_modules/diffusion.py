@@ -1,0 +1,180 @@
+"""Stage-1 ancestral DDPM sampler (SR3) driving the HIP UNet.
+
+Drop-in for ``models/sr3_model/sr3_modules/diffusion.py`` (GaussianDiffusion :63-201): same
+buffers, same ``set_new_noise_schedule`` / ``p_sample_loop`` / ``super_resolution`` contract, same
+order of random draws (one ``randn(shape)`` for x_T, then one ``randn_like`` per step with t > 0).
+
+MI355X-specific structure:
+  * the conditioning image is packed ONCE into channels 0..2 of a 16-bit NHWC buffer; each step
+    only rewrites channels 3..5 with x_t (no torch.cat of [cond, x], diffusion.py:157-158);
+  * the per-step scalars (noise level, posterior coefficients, sigma) are host floats computed at
+    schedule time -- the reference re-uploads a FloatTensor every step (:154-155);
+  * x0 prediction, clamp, posterior mean and the noise injection are one fused kernel
+    (rsvld_ddpm_step) reading the UNet's fp32 NHWC epsilon directly.
+
+``noise_source``: "device" draws with the device generator (what the reference does on a GPU);
+"cpu" draws with the default CPU generator in the reference's order and uploads, which makes a
+run bit-comparable with the reference's CPU path for a fixed ``torch.manual_seed``.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+from ... import ops
+from ..._lib import RsvldError
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """float64 beta tables, formula-for-formula diffusion.py:21-51."""
+    lin = partial(np.linspace, num=n_timestep, dtype=np.float64)
+    if schedule == "linear":
+        return lin(linear_start, linear_end)
+    if schedule == "quad":
+        return lin(linear_start ** 0.5, linear_end ** 0.5) ** 2
+    if schedule in ("warmup10", "warmup50"):
+        frac = 0.1 if schedule == "warmup10" else 0.5
+        betas = linear_end * np.ones(n_timestep, dtype=np.float64)
+        n_warm = int(n_timestep * frac)
+        betas[:n_warm] = np.linspace(linear_start, linear_end, n_warm, dtype=np.float64)
+        return betas
+    if schedule == "const":
+        return linear_end * np.ones(n_timestep, dtype=np.float64)
+    if schedule == "jsd":
+        return 1.0 / np.linspace(n_timestep, 1, n_timestep, dtype=np.float64)
+    if schedule == "cosine":
+        steps = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+        alphas = torch.cos(steps / (1 + cosine_s) * np.pi / 2).pow(2)
+        alphas = alphas / alphas[0]
+        return (1 - alphas[1:] / alphas[:-1]).clamp(max=0.999).numpy()
+    raise NotImplementedError(schedule)
+
+
+def schedule_tables(schedule_opt):
+    """All derived tables as float64 numpy arrays (diffusion.py:93-140)."""
+    betas = make_beta_schedule(schedule_opt["schedule"], schedule_opt["n_timestep"],
+                               schedule_opt["linear_start"], schedule_opt["linear_end"])
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+    return {
+        "betas": betas,
+        "alphas_cumprod": ac,
+        "alphas_cumprod_prev": ac_prev,
+        "sqrt_alphas_cumprod": np.sqrt(ac),
+        "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - ac),
+        "log_one_minus_alphas_cumprod": np.log(1.0 - ac),
+        "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / ac),
+        "sqrt_recipm1_alphas_cumprod": np.sqrt(1.0 / ac - 1),
+        "posterior_variance": post_var,
+        "posterior_log_variance_clipped": np.log(np.maximum(post_var, 1e-20)),
+        "posterior_mean_coef1": betas * np.sqrt(ac_prev) / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac),
+        "sqrt_alphas_cumprod_prev": np.sqrt(np.append(1.0, ac)),  # stays numpy in the reference (:106)
+    }
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, denoise_fn, image_size, channels=3, loss_type="l1", conditional=True, schedule_opt=None):
+        super().__init__()
+        self.channels, self.image_size = channels, image_size
+        self.denoise_fn, self.loss_type, self.conditional = denoise_fn, loss_type, conditional
+        self.noise_source = "device"
+        self._host = None
+
+    def set_loss(self, device):  # training only in the reference (:84-91); kept as a no-op hook
+        self.loss_func = None
+
+    def set_new_noise_schedule(self, schedule_opt, device):
+        tabs = schedule_tables(schedule_opt)
+        self.sqrt_alphas_cumprod_prev = tabs.pop("sqrt_alphas_cumprod_prev")
+        self.num_timesteps = int(tabs["betas"].shape[0])
+        for name, arr in tabs.items():
+            self.register_buffer(name, torch.tensor(arr, dtype=torch.float32, device=device))
+        # host-side fp32 copies of what the step kernel needs; sigma = exp(0.5*logvar) in fp32 (:175)
+        f32 = {k: v.astype(np.float32) for k, v in tabs.items()}
+        self._host = {
+            "recip": f32["sqrt_recip_alphas_cumprod"], "recipm1": f32["sqrt_recipm1_alphas_cumprod"],
+            "coef1": f32["posterior_mean_coef1"], "coef2": f32["posterior_mean_coef2"],
+            "sigma": np.exp(np.float32(0.5) * f32["posterior_log_variance_clipped"]).astype(np.float32),
+            "level": self.sqrt_alphas_cumprod_prev.astype(np.float32),  # FloatTensor([...]) cast (:154)
+        }
+
+    # ---- noise -------------------------------------------------------------------------
+    def _randn(self, shape, device):
+        if self.noise_source == "cpu":
+            return torch.randn(shape).to(device)
+        if self.noise_source == "device":
+            return torch.randn(shape, device=device)
+        raise ValueError(f"noise_source must be 'cpu' or 'device', got {self.noise_source!r}")
+
+    # ---- sampling ----------------------------------------------------------------------
+    @torch.no_grad()
+    def p_sample(self, x, t, clip_denoised=True, condition_x=None, _xin=None, _levels=None):
+        """One ancestral step (diffusion.py:152-175) on fp32 NCHW ``x``."""
+        h = self._host
+        B = x.shape[0]
+        unet = self.denoise_fn
+        if _xin is None:
+            _xin = self._pack_condition(condition_x, x)
+        off = 0 if condition_x is None else condition_x.shape[1]
+        ops.nchw_to_nhwc(x, unet.compute_dtype, c_off=off, out=_xin)
+        if _levels is None:
+            level = torch.full((B, 1), float(h["level"][t + 1]), device=x.device, dtype=torch.float32)
+        else:
+            level = _levels[t + 1]
+        eps = unet.forward_nhwc(_xin, level)
+        noise = self._randn(x.shape, x.device) if t > 0 else None
+        return ops.ddpm_step(x, eps, noise, float(h["recip"][t]), float(h["recipm1"][t]), float(h["coef1"][t]),
+                             float(h["coef2"][t]), float(h["sigma"][t]) if t > 0 else 0.0, clip=clip_denoised)
+
+    def _pack_condition(self, cond, x):
+        unet = self.denoise_fn
+        c_in = (0 if cond is None else cond.shape[1]) + x.shape[1]
+        B, _, H, W = x.shape
+        xin = torch.zeros((B, H, W, ops.pad8(c_in)), device=x.device, dtype=unet.compute_dtype)
+        if cond is not None:
+            ops.nchw_to_nhwc(cond, unet.compute_dtype, c_off=0, out=xin)
+        return xin
+
+    @torch.no_grad()
+    def p_sample_loop(self, x_in, continous=False):
+        if self._host is None:
+            raise RsvldError("call set_new_noise_schedule() first")
+        device = self.betas.device
+        if device.type != "cuda":
+            raise RsvldError("GaussianDiffusion samples on the GPU only (no CPU fallback)")
+        T = self.num_timesteps
+        sample_inter = 1 | (T // 10)
+        if not self.conditional:
+            shape, cond = tuple(x_in), None
+            img = self._randn(shape, device)
+            ret_img = img
+        else:
+            cond = x_in.to(device=device, dtype=torch.float32).contiguous()
+            shape = cond.shape
+            img = self._randn(shape, device)
+            ret_img = cond
+        B = shape[0]
+        xin = self._pack_condition(cond, img)
+        # one [T+1, B, 1] device table of noise levels instead of a host->device copy per step
+        levels = torch.tensor(self._host["level"], device=device).view(T + 1, 1, 1).expand(T + 1, B, 1).contiguous()
+        for i in reversed(range(T)):
+            img = self.p_sample(img, i, condition_x=cond, _xin=xin, _levels=levels)
+            if i % sample_inter == 0:
+                ret_img = torch.cat([ret_img, img], dim=0)
+        return ret_img if continous else ret_img[-1]
+
+    @torch.no_grad()
+    def sample(self, batch_size=1, continous=False):
+        s = self.image_size
+        return self.p_sample_loop((batch_size, self.channels, s, s), continous)
+
+    @torch.no_grad()
+    def super_resolution(self, x_in, continous=False):
+        return self.p_sample_loop(x_in, continous)
+
+    def forward(self, x, *args, **kwargs):
+        raise NotImplementedError("training (p_losses, diffusion.py:223-250) is outside the inference hot path")

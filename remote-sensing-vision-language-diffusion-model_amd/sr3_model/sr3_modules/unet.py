@@ -1,0 +1,282 @@
+"""Stage-1 (SR3) pixel-space UNet on the MI355X kernel library.
+
+Drop-in for the reference ``models/sr3_model/sr3_modules/unet.py`` (UNet :162-261): same
+constructor arguments, same parameter names (so ``I1000000_E800_gen.pth`` loads unchanged), same
+``forward(x, time)`` contract.  What differs is everything underneath: activations are 16-bit
+NHWC tensors that never leave HBM in NCHW form, and every layer is a kernel of librsvld_hip.so:
+
+  Block            GN(32)+Swish (norm.hip) -> Conv3x3 implicit GEMM on MFMA (conv_igemm.hip)
+  FeatureWiseAffine all 26 noise-level projections in ONE stacked launch, consumed as the
+                   per-image row vector of block1's conv epilogue
+  ResnetBlock      residual / 1x1 res_conv add fused in block2's conv epilogue; the skip
+                   concatenation (unet.py:257) is never materialised (two-source GN + conv)
+  SelfAttention    fused qkv 1x1 GEMM -> flash attention, d = 512 (attention.hip) -> out 1x1 GEMM
+                   with the residual in its epilogue; no [B,1,h,w,h,w] score tensor (:133-141)
+  Upsample         nearest x2 folded into the conv's gather;  Downsample: stride-2 gather
+
+The nn.Conv2d / nn.GroupNorm / nn.Linear children only HOLD parameters under the reference's
+names; their ``forward`` is never called.
+"""
+import math
+
+import torch
+from torch import nn
+
+from ... import ops
+from ..._lib import RsvldError
+
+
+class PositionalEncoding(nn.Module):  # parameter-free; index 0 of noise_level_mlp (unet.py:19-32)
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+
+class Swish(nn.Module):
+    pass
+
+
+class FeatureWiseAffine(nn.Module):
+    """unet.py:35-51 — only the additive form is used by the shipped config."""
+
+    def __init__(self, in_channels, out_channels, use_affine_level=False):
+        super().__init__()
+        if use_affine_level:
+            raise NotImplementedError("use_affine_level=True is not used by configs/sr_sr3.json")
+        self.use_affine_level = use_affine_level
+        self.noise_func = nn.Sequential(nn.Linear(in_channels, out_channels))
+
+
+class Upsample(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=2, mode="nearest")
+        self.conv = nn.Conv2d(dim, dim, 3, padding=1)
+
+
+class Downsample(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = nn.Conv2d(dim, dim, 3, 2, 1)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, dim_out, groups=32, dropout=0):
+        super().__init__()
+        self.block = nn.Sequential(
+            nn.GroupNorm(groups, dim), Swish(),
+            nn.Dropout(dropout) if dropout != 0 else nn.Identity(),
+            nn.Conv2d(dim, dim_out, 3, padding=1))
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, dim, dim_out, noise_level_emb_dim=None, dropout=0, use_affine_level=False, norm_groups=32):
+        super().__init__()
+        self.noise_func = FeatureWiseAffine(noise_level_emb_dim, dim_out, use_affine_level)
+        self.block1 = Block(dim, dim_out, groups=norm_groups)
+        self.block2 = Block(dim_out, dim_out, groups=norm_groups, dropout=dropout)
+        self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, in_channel, n_head=1, norm_groups=32):
+        super().__init__()
+        self.n_head = n_head
+        self.norm = nn.GroupNorm(norm_groups, in_channel)
+        self.qkv = nn.Conv2d(in_channel, in_channel * 3, 1, bias=False)
+        self.out = nn.Conv2d(in_channel, in_channel, 1)
+
+
+class ResnetBlocWithAttn(nn.Module):
+    def __init__(self, dim, dim_out, *, noise_level_emb_dim=None, norm_groups=32, dropout=0, with_attn=False):
+        super().__init__()
+        self.with_attn = with_attn
+        self.res_block = ResnetBlock(dim, dim_out, noise_level_emb_dim, norm_groups=norm_groups, dropout=dropout)
+        if with_attn:
+            self.attn = SelfAttention(dim_out, norm_groups=norm_groups)
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=32,
+                 channel_mults=(1, 2, 4, 8, 8), attn_res=(8), res_blocks=3, dropout=0,
+                 with_noise_level_emb=True, image_size=128):
+        super().__init__()
+        if not with_noise_level_emb:
+            raise NotImplementedError("the SR3 sampler always conditions on the noise level")
+        if isinstance(attn_res, int):
+            attn_res = (attn_res,)
+        self.in_channel, self.out_channel = in_channel, out_channel if out_channel is not None else in_channel
+        emb = inner_channel
+        self.noise_level_mlp = nn.Sequential(
+            PositionalEncoding(inner_channel), nn.Linear(inner_channel, inner_channel * 4), Swish(),
+            nn.Linear(inner_channel * 4, inner_channel))
+
+        # encoder: attention sites depend on the CONSTRUCTION-time resolution only (unet.py:198,221)
+        widths = [inner_channel * m for m in channel_mults]
+        res, cur = image_size, inner_channel
+        skips = [cur]
+        downs = [nn.Conv2d(in_channel, inner_channel, kernel_size=3, padding=1)]
+        for level, width in enumerate(widths):
+            attn_here = res in attn_res
+            for _ in range(res_blocks):
+                downs.append(ResnetBlocWithAttn(cur, width, noise_level_emb_dim=emb, norm_groups=norm_groups,
+                                                dropout=dropout, with_attn=attn_here))
+                cur = width
+                skips.append(cur)
+            if level != len(widths) - 1:
+                downs.append(Downsample(cur))
+                skips.append(cur)
+                res //= 2
+        self.downs = nn.ModuleList(downs)
+        self.mid = nn.ModuleList([
+            ResnetBlocWithAttn(cur, cur, noise_level_emb_dim=emb, norm_groups=norm_groups, dropout=dropout, with_attn=True),
+            ResnetBlocWithAttn(cur, cur, noise_level_emb_dim=emb, norm_groups=norm_groups, dropout=dropout, with_attn=False)])
+        ups = []
+        for level in reversed(range(len(widths))):
+            width, attn_here = widths[level], res in attn_res
+            for _ in range(res_blocks + 1):
+                ups.append(ResnetBlocWithAttn(cur + skips.pop(), width, noise_level_emb_dim=emb, norm_groups=norm_groups,
+                                              dropout=dropout, with_attn=attn_here))
+                cur = width
+            if level != 0:
+                ups.append(Upsample(cur))
+                res *= 2
+        self.ups = nn.ModuleList(ups)
+        self.final_conv = Block(cur, self.out_channel, groups=norm_groups)
+
+        self.compute_dtype = torch.float16   # storage / MFMA operand type of the activations
+        self._pk = None                      # packed weights, built lazily on the parameters' device
+
+    # ------------------------------------------------------------------ weight packing
+    def invalidate_packed(self):
+        self._pk = None
+
+    def load_state_dict(self, *a, **k):
+        self._pk = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):  # .to(device) / .half() etc. move the fp32 masters
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    def _res_blocks(self):
+        for seq in (self.downs, self.mid, self.ups):
+            for layer in seq:
+                if isinstance(layer, ResnetBlocWithAttn):
+                    yield layer
+
+    def _pack(self):
+        dev = self.noise_level_mlp[1].weight.device
+        if dev.type != "cuda":
+            raise RsvldError("SR3 UNet: parameters must be on the GPU (there is no CPU execution path)")
+        dt = self.compute_dtype
+        pk = {}
+
+        def conv(m, **kw):
+            pk[id(m)] = ops.pack_conv(m.weight, m.bias, dt, dev, **kw)
+
+        conv(self.downs[0])
+        # stacked noise-level projections: one [sum(C), emb] matrix, offsets per block
+        ws, bs, off = [], [], 0
+        for rb in self._res_blocks():
+            lin = rb.res_block.noise_func.noise_func[0]
+            pk[("nf", id(rb))] = (off, lin.out_features)
+            ws.append(lin.weight.detach().float())
+            bs.append(lin.bias.detach().float())
+            off += lin.out_features
+        pk["nf_w"] = torch.cat(ws, 0).contiguous().to(dev)
+        pk["nf_b"] = torch.cat(bs, 0).contiguous().to(dev)
+        for seq in (self.downs, self.mid, self.ups):
+            for layer in seq:
+                if isinstance(layer, (Downsample, Upsample)):
+                    conv(layer.conv)
+                elif isinstance(layer, ResnetBlocWithAttn):
+                    rb = layer.res_block
+                    c_in = rb.block1.block[0].num_channels
+                    conv(rb.block1.block[3])
+                    conv(rb.block2.block[3])
+                    if isinstance(rb.res_conv, nn.Conv2d):
+                        pk[("res", id(rb))] = c_in  # split decided at run time (skip concat or not)
+                    if layer.with_attn:
+                        if layer.attn.n_head != 1:
+                            raise NotImplementedError("SR3 SelfAttention is built with n_head=1 (unet.py:151)")
+                        conv(layer.attn.qkv)
+                        conv(layer.attn.out)
+        conv(self.final_conv.block[3])
+        self._pk = pk
+        return pk
+
+    def _res_conv_packed(self, rb, split):
+        key = ("resw", id(rb), split)
+        pk = self._pk
+        if key not in pk:
+            m = rb.res_conv
+            pk[key] = ops.pack_conv(m.weight, m.bias, self.compute_dtype, m.weight.device, cin_split=split)
+        return pk[key]
+
+    # ------------------------------------------------------------------ forward pieces
+    def _block(self, blk, x, x2=None, **conv_kw):
+        gn = blk.block[0]
+        h = ops.group_norm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, x2=x2, silu=True)
+        return ops.conv2d(h, self._pk[id(blk.block[3])], **conv_kw)
+
+    def _resblock(self, layer, x, x2, nf_all):
+        rb = layer.res_block
+        off, width = self._pk[("nf", id(layer))]
+        rowvec = nf_all[:, off:off + width]
+        h = self._block(rb.block1, x, x2, rowvec=rowvec)
+        if isinstance(rb.res_conv, nn.Conv2d):
+            split = None if x2 is None else (x.shape[-1], x2.shape[-1])
+            res = ops.conv2d(x, self._res_conv_packed(rb, split), x2=x2, pad=0)
+        else:
+            res = x
+        h = self._block(rb.block2, h, residual=res)
+        if layer.with_attn:
+            h = self._attention(layer.attn, h)
+        return h
+
+    def _attention(self, at, x):
+        B, H, W, Cc = x.shape
+        n = ops.group_norm(x, at.norm.weight, at.norm.bias, at.norm.num_groups, at.norm.eps)
+        qkv = ops.conv2d(n, self._pk[id(at.qkv)], pad=0).reshape(B, H * W, 3 * Cc)
+        o = ops.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads=1,
+                          scale=1.0 / math.sqrt(Cc))  # scale uses the full channel count (unet.py:135)
+        return ops.conv2d(o.reshape(B, H, W, Cc), self._pk[id(at.out)], pad=0, residual=x)
+
+    def forward_nhwc(self, x, noise_level):
+        """x: 16-bit NHWC ``[B,H,W,pad8(in_channel)]``; noise_level fp32 ``[B,1]`` -> fp32 NHWC eps
+        ``[B,H,W,pad8(out_channel)]`` (channels beyond out_channel are zero)."""
+        if self._pk is None:
+            self._pack()
+        pk = self._pk
+        mlp = self.noise_level_mlp
+        pe = ops.sinusoidal(noise_level, mlp[0].dim, 0)
+        t = ops.linear_small(pe, mlp[1].weight, mlp[1].bias, 0, 1)   # Linear + Swish
+        t = ops.linear_small(t, mlp[3].weight, mlp[3].bias)
+        nf_all = ops.linear_small(t, pk["nf_w"], pk["nf_b"])         # every FeatureWiseAffine at once
+
+        feats = []
+        for layer in self.downs:
+            if isinstance(layer, ResnetBlocWithAttn):
+                x = self._resblock(layer, x, None, nf_all)
+            elif isinstance(layer, Downsample):
+                x = ops.conv2d(x, pk[id(layer.conv)], stride=2, pad=1)
+            else:
+                x = ops.conv2d(x, pk[id(layer)], pad=1)
+            feats.append(x)
+        for layer in self.mid:
+            x = self._resblock(layer, x, None, nf_all)
+        for layer in self.ups:
+            if isinstance(layer, ResnetBlocWithAttn):
+                x = self._resblock(layer, x, feats.pop(), nf_all)
+            else:
+                x = ops.conv2d(x, pk[id(layer.conv)], pad=1, upsample=True)
+        return self._block(self.final_conv, x, out_f32=True)
+
+    def forward(self, x, time):
+        """Reference contract (unet.py:236-261): fp32 NCHW ``[B,in,H,W]``, ``time [B,1]`` -> fp32 NCHW."""
+        if not x.is_cuda:
+            raise RsvldError("SR3 UNet runs on the GPU only")
+        xin = ops.nchw_to_nhwc(x, self.compute_dtype)
+        eps = self.forward_nhwc(xin, time.float())
+        return ops.nhwc_to_nchw(eps, channels=self.out_channel)

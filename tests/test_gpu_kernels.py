@@ -1,0 +1,270 @@
+"""GPU parity of every kernel behind the C ABI against a plain torch fp32 CPU reference of the
+same op (inputs pre-rounded to the 16-bit storage type, so the tolerance covers fp32-accumulate
+MFMA arithmetic + one output rounding)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _tol(dtype):
+    return (4e-3, 4e-3) if dtype == torch.float16 else (3e-2, 3e-2)
+
+
+def _close(got, want, dtype, scale=None):
+    rt, at = _tol(dtype)
+    want = want.float()
+    got = got.float().cpu()
+    s = float(want.abs().max()) if scale is None else scale
+    err = float((got - want).abs().max())
+    assert err <= at * max(s, 1e-6) + 1e-6, f"max|d|={err:.3e} scale={s:.3e}"
+    return err
+
+
+def _nhwc(x, dtype, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+
+
+def _rt(x, dtype):  # round-trip through the storage type
+    return x.to(dtype).float()
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, stride, pad, upsample
+    (2, 64, 64, 24, 20, 3, 1, 1, False),
+    (1, 8, 64, 16, 16, 3, 1, 1, False),      # first conv: 6 channels padded to 8
+    (2, 64, 128, 17, 13, 3, 2, 1, False),    # stride 2, ragged M
+    (1, 128, 256, 9, 11, 1, 1, 0, False),    # 1x1
+    (1, 64, 8, 32, 32, 3, 1, 1, False),      # tiny Cout (final conv 64 -> 3 padded)
+    (1, 256, 256, 6, 5, 3, 1, 1, True),      # fused nearest x2
+    (1, 320, 640, 8, 8, 3, 1, 1, False),     # K = 2880 (not a multiple of 64 per tap)
+    (1, 72, 40, 10, 10, 3, 1, 1, False),     # Cin, Cout multiples of 8 only
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(cuda, dtype, case):
+    from rsvld_amd import ops
+    B, Cin, Cout, H, W, k, stride, pad, up = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = _rt(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = _rt(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1
+    pc = ops.pack_conv(w, b, dtype, cuda)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    want = F.conv2d(xin, w, b, stride=stride, padding=pad)
+    got = ops.conv2d(_nhwc(x, dtype, cuda), pc, stride=stride, pad=pad, upsample=up)
+    assert got.shape == (B, want.shape[2], want.shape[3], Cout)
+    _close(got.permute(0, 3, 1, 2), want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_epilogue_rowvec_residual_concat(cuda, dtype):
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, C1, C2, Cout, H, W = 3, 64, 32, 128, 12, 10
+    x1 = _rt(torch.randn(B, C1, H, W, generator=g), dtype)
+    x2 = _rt(torch.randn(B, C2, H, W, generator=g), dtype)
+    w = _rt(torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1
+    rv_full = torch.randn(B, 2 * Cout, generator=g)        # strided row vector (slice of a wider table)
+    res = _rt(torch.randn(B, Cout, H, W, generator=g), dtype)
+    pc = ops.pack_conv(w, b, dtype, cuda, cin_split=(C1, C2))
+    rv_dev = rv_full.to(cuda)
+    got = ops.conv2d(_nhwc(x1, dtype, cuda), pc, x2=_nhwc(x2, dtype, cuda), rowvec=rv_dev[:, Cout:],
+                     residual=_nhwc(res, dtype, cuda), alpha=0.5, beta=2.0)
+    want = 0.5 * (F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1) + rv_full[:, Cout:, None, None]) + 2.0 * res
+    _close(got.permute(0, 3, 1, 2), want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_asymmetric_pad_and_f32_out(cuda, dtype):
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = _rt(torch.randn(1, 64, 16, 16, generator=g), dtype)
+    w = _rt(torch.randn(64, 64, 3, 3, generator=g) / 24.0, dtype)
+    pc = ops.pack_conv(w, None, dtype, cuda)
+    # VAE downsample: pad (0,1,0,1) then stride-2 conv (model.py:81-85)
+    want = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=2)
+    got = ops.conv2d(_nhwc(x, dtype, cuda), pc, stride=2, pad=(0, 0, 1, 1))
+    _close(got.permute(0, 3, 1, 2), want, dtype)
+    w3 = _rt(torch.randn(3, 64, 3, 3, generator=g) / 24.0, dtype)
+    b3 = torch.randn(3, generator=g)
+    pc3 = ops.pack_conv(w3, b3, dtype, cuda)
+    got = ops.conv2d(_nhwc(x, dtype, cuda), pc3, pad=1, out_f32=True)
+    assert got.dtype == torch.float32 and got.shape[-1] == 8
+    _close(got[..., :3].permute(0, 3, 1, 2), F.conv2d(x, w3, b3, padding=1), dtype)
+    assert float(got[..., 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_and_geglu(cuda, dtype):
+    from rsvld_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(7)
+    rows, Cin, Cout = 200, 320, 640
+    x = _rt(torch.randn(2, rows // 2, Cin, generator=g), dtype)
+    w = _rt(torch.randn(Cout, Cin, generator=g) / math.sqrt(Cin), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1
+    res = _rt(torch.randn(2, rows // 2, Cout, generator=g), dtype)
+    got = ops.linear(x.to(cuda, dtype), ops.pack_conv(w, b, dtype, cuda), residual=res.to(cuda, dtype))
+    _close(got, F.linear(x, w, b) + res, dtype)
+    # GEGLU fused in the epilogue (attention.py:84-96)
+    got = ops.linear(x.to(cuda, dtype), ops.pack_conv(w, b, dtype, cuda, geglu=True), act=L.ACT_GEGLU)
+    y = F.linear(x, w, b)
+    val, gate = y.chunk(2, dim=-1)
+    _close(got, val * F.gelu(gate), dtype)
+    # stand-alone geglu kernel
+    got = ops.geglu(_rt(y, dtype).to(cuda, dtype))
+    v2, g2 = _rt(y, dtype).chunk(2, dim=-1)
+    _close(got, v2 * F.gelu(g2), dtype)
+
+
+GN_CASES = [(2, 64, 0, 16, 12, 32, True), (1, 320, 0, 9, 7, 32, False), (3, 512, 256, 6, 6, 32, True),
+            (1, 2560, 0, 4, 4, 32, True), (2, 128, 0, 40, 40, 32, True), (1, 960, 0, 5, 5, 32, True)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", GN_CASES)
+def test_group_norm(cuda, dtype, case):
+    from rsvld_amd import ops
+    B, C1, C2, H, W, G, silu = case
+    g = torch.Generator().manual_seed(C1 + C2)
+    x1 = _rt(torch.randn(B, C1, H, W, generator=g) * 2 + 0.5, dtype)
+    x2 = _rt(torch.randn(B, C2, H, W, generator=g), dtype) if C2 else None
+    gamma = 1 + 0.1 * torch.randn(C1 + C2, generator=g)
+    beta = 0.1 * torch.randn(C1 + C2, generator=g)
+    xc = x1 if x2 is None else torch.cat([x1, x2], 1)
+    want = F.group_norm(xc, G, gamma, beta, eps=1e-5)
+    if silu:
+        want = F.silu(want)
+    got = ops.group_norm(_nhwc(x1, dtype, cuda), gamma.to(cuda), beta.to(cuda), G, 1e-5,
+                         x2=None if x2 is None else _nhwc(x2, dtype, cuda), silu=silu)
+    _close(got.permute(0, 3, 1, 2), want, dtype)
+    st = ops.group_norm_stats(_nhwc(x1, dtype, cuda), G, x2=None if x2 is None else _nhwc(x2, dtype, cuda)).cpu()
+    xg = xc.view(B, G, -1)
+    assert torch.allclose(st[..., 0], xg.mean(-1), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(st[..., 1], xg.var(-1, unbiased=False), atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_group_norm_zerosft_modulation(cuda, dtype):
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, Cc, H, W = 2, 320, 6, 6
+    x = _rt(torch.randn(B, Cc, H, W, generator=g), dtype)
+    sc = _rt(torch.randn(B, Cc, H, W, generator=g) * 0.3, dtype)
+    sh = _rt(torch.randn(B, Cc, H, W, generator=g) * 0.3, dtype)
+    want = F.group_norm(x, 32, None, None, eps=1e-5) * (1 + sc) + sh
+    got = ops.group_norm(_nhwc(x, dtype, cuda), None, None, 32, 1e-5, mod_scale1p=_nhwc(sc, dtype, cuda),
+                         mod_shift=_nhwc(sh, dtype, cuda))
+    _close(got.permute(0, 3, 1, 2), want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cc", [640, 1280, 320])
+def test_layer_norm(cuda, dtype, Cc):
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(Cc)
+    x = _rt(torch.randn(3, 37, Cc, generator=g) * 1.5 + 0.3, dtype)
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g), 0.1 * torch.randn(Cc, generator=g)
+    got = ops.layer_norm(x.to(cuda, dtype), gamma.to(cuda), beta.to(cuda), 1e-5)
+    _close(got, F.layer_norm(x, (Cc,), gamma, beta, 1e-5), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 64, 64), (2, 144, 144), (1, 1, 1), (1, 100, 333), (2, 1024, 1024)])
+def test_attention_d512(cuda, dtype, shape):
+    from rsvld_amd import ops
+    B, Nq, Nk = shape
+    D = 512
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    qkv = _rt(torch.randn(B, max(Nq, Nk), 3 * D, generator=g), dtype)
+    q, k, v = qkv[:, :Nq, :D], qkv[:, :Nk, D:2 * D], qkv[:, :Nk, 2 * D:]
+    scale = 1.0 / math.sqrt(D)
+    want = torch.softmax(q @ k.transpose(1, 2) * scale, -1) @ v
+    dq = qkv.to(cuda, dtype)
+    got = ops.attention(dq[:, :Nq, :D], dq[:, :Nk, D:2 * D], dq[:, :Nk, 2 * D:], heads=1, scale=scale)
+    _close(got, want, dtype)
+
+
+def test_attention_online_softmax_rescale_path(cuda):
+    """Force the running max to jump at a late key tile (cdna_hip_programming.md rule 26)."""
+    from rsvld_amd import ops
+    dtype, D, N = torch.float16, 512, 256
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(1, N, D, generator=g) * 0.5
+    k = torch.randn(1, N, D, generator=g) * 0.5
+    v = torch.randn(1, N, D, generator=g)
+    k[0, 200] = q[0, 17] * 3.0      # one key spikes against one query, in tile 6
+    k[0, 70] = q[0, 40] * 2.0
+    q, k, v = _rt(q, dtype), _rt(k, dtype), _rt(v, dtype)
+    scale = 1.0 / math.sqrt(D)
+    want = torch.softmax(q @ k.transpose(1, 2) * scale, -1) @ v
+    got = ops.attention(q.to(cuda, dtype), k.to(cuda, dtype), v.to(cuda, dtype), heads=1, scale=scale)
+    _close(got, want, dtype)
+
+
+def test_small_layers_and_embeddings(cuda):
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 320, generator=g)
+    w, b = torch.randn(1280, 320, generator=g) / 18, torch.randn(1280, generator=g)
+    got = ops.linear_small(x.to(cuda), w.to(cuda), b.to(cuda), 1, 1).cpu()
+    assert torch.allclose(got, F.silu(F.linear(F.silu(x), w, b)), atol=1e-4, rtol=1e-4)
+    lv = torch.tensor([0.1, 0.7, 0.999])
+    import oracle.sr3_oracle as O
+    got = ops.sinusoidal(lv.to(cuda), 64, 0).cpu()
+    assert torch.allclose(got, O.positional_encoding(lv, 64), atol=2e-6)
+    t = torch.tensor([0.0, 19.0, 999.0])
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None] * freqs[None]
+    want = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    got = ops.sinusoidal(t.to(cuda), 320, 1).cpu()
+    assert torch.allclose(got, want, atol=2e-4)
+
+
+def test_layout_and_ddpm_step(cuda):
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 10, 12, generator=g)
+    c = torch.randn(2, 3, 10, 12, generator=g)
+    buf = ops.nchw_to_nhwc(c.to(cuda), torch.float16)
+    assert buf.shape == (2, 10, 12, 8) and float(buf[..., 3:].abs().max()) == 0.0
+    buf = torch.zeros((2, 10, 12, 8), device=cuda, dtype=torch.float16)
+    ops.nchw_to_nhwc(c.to(cuda), torch.float16, c_off=0, out=buf)
+    ops.nchw_to_nhwc(x.to(cuda), torch.float16, c_off=3, out=buf)
+    want = torch.cat([c, x, torch.zeros(2, 2, 10, 12)], 1).permute(0, 2, 3, 1).half()
+    assert torch.equal(buf.cpu(), want)
+    back = ops.nhwc_to_nchw(buf, channels=3, c_off=3).cpu()
+    assert torch.equal(back, x.half().float())
+    eps = torch.randn(2, 10, 12, 8, generator=g)
+    nz = torch.randn(2, 3, 10, 12, generator=g)
+    a, bq, c1, c2, s = 1.3, 0.8, 0.4, 0.6, 0.05
+    x0 = (a * x - bq * eps[..., :3].permute(0, 3, 1, 2)).clamp(-1, 1)
+    want = c1 * x0 + c2 * x + s * nz
+    got = ops.ddpm_step(x.to(cuda), eps.to(cuda), nz.to(cuda), a, bq, c1, c2, s).cpu()
+    assert torch.allclose(got, want, atol=1e-6)
+    got = ops.ddpm_step(x.to(cuda), eps.to(cuda), None, a, bq, c1, c2, 0.0).cpu()
+    assert torch.allclose(got, c1 * x0 + c2 * x, atol=1e-6)
+    a16, b16 = torch.randn(64, generator=g).half(), torch.randn(64, generator=g).half()
+    got = ops.axpby(a16.to(cuda), b16.to(cuda), 0.5, 2.0).cpu()
+    assert torch.allclose(got.float(), (0.5 * a16.float() + 2 * b16.float()), atol=2e-3)
+
+
+def test_errors_are_loud(cuda):
+    from rsvld_amd import ops, _lib as L
+    with pytest.raises(L.RsvldError):
+        ops.group_norm(torch.zeros(1, 4, 4, 64, dtype=torch.float16), None, None, 32, 1e-5)  # CPU tensor
+    x = torch.zeros(1, 4, 4, 64, dtype=torch.float16, device=cuda)
+    with pytest.raises(L.RsvldError):
+        ops.group_norm(x, None, None, 48, 1e-5)  # 64 % 48 != 0 -> RSVLD_EINVAL
+    q = torch.zeros(1, 8, 96, dtype=torch.float16, device=cuda)
+    with pytest.raises(L.RsvldError):
+        ops.attention(q, q, q, heads=1)  # D = 96 unsupported
