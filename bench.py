@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the Stage-1 sampler over one batch: BASELINE.json configs[1]
+(Stage-1 only, 128 -> 512 x4 SR, batch 4 per GPU, 50 ancestral DDPM steps, synthetic inputs and
+seeded random-init weights of the shipped architecture).  value = images / second over the whole
+job (all ranks), inputs resident in HBM when the timed region starts.  Weak scaling: every rank
+processes its own 4 images; the only collective is the all-gather of finished uint8 images.
+
+Besides the contract fields the JSON line carries
+  roofline     : the dominant kernel (implicit-GEMM conv, MFMA-bound): algorithmic FLOPs of its
+                 launches / their summed HIP-event durations, from one extra instrumented pass;
+  cpu_baseline : the CPU oracle (oracle/sr3_oracle.py, a port) timed on this host's cores on a
+                 bounded sample and extrapolated linearly in step count.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+METRIC = "512px x8 SR images/sec @50 steps"
+PEAK_TFLOPS_F16 = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+UNET_TF_PER_IMAGE_STEP = {256: 0.262, 512: 1.126, 1024: 5.77, 2048: 43.3, 4096: 496.3}
+
+
+def build_model(dev, T):
+    from oracle import sr3_oracle as O
+    from rsvld_amd.sr3_model.sr3_modules.diffusion import GaussianDiffusion
+    from rsvld_amd.sr3_model.sr3_modules.unet import UNet
+    c = O.SR3_CFG
+    torch.manual_seed(0)
+    unet = UNet(in_channel=c["in_channel"], out_channel=c["out_channel"], inner_channel=c["inner_channel"],
+                norm_groups=c["norm_groups"], channel_mults=c["channel_mults"], attn_res=list(c["attn_res"]),
+                res_blocks=c["res_blocks"], dropout=0.2, image_size=c["image_size"])
+    net = GaussianDiffusion(unet, image_size=c["image_size"], channels=3, conditional=True)
+    net.to(dev).eval()
+    net.set_new_noise_schedule(dict(schedule="linear", n_timestep=T, linear_start=1e-6, linear_end=1e-2), dev)
+    return net
+
+
+def synthetic_batch(batch, lr_side, scale, rank):
+    """LR images -> the Stage-1 input contract (data/dataset.py:16-21,30-42): bicubic x scale, [-1,1]."""
+    from oracle import seeded
+    lr = torch.cat([seeded.synthetic_image((1, 3, lr_side, lr_side), seed=1234 + rank * batch + i, smooth=4)
+                    for i in range(batch)], 0)
+    return torch.nn.functional.interpolate(lr, scale_factor=scale, mode="bicubic", align_corners=False).clamp(-1, 1)
+
+
+def cpu_baseline(side, T, steps_sampled=2):
+    """Time the CPU oracle on `steps_sampled` ancestral steps of ONE image at the real size."""
+    from oracle import seeded, sr3_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(avail, 32))   # beyond ~32 threads the fp32 conv/GEMM oracle stops scaling (NUMA, sync)
+    torch.set_num_threads(ncores)
+    c = O.SR3_CFG
+    names = []
+    torch.manual_seed(0)
+    from rsvld_amd.sr3_model.sr3_modules.unet import UNet
+    unet = UNet(in_channel=c["in_channel"], out_channel=c["out_channel"], inner_channel=c["inner_channel"],
+                norm_groups=c["norm_groups"], channel_mults=c["channel_mults"], attn_res=list(c["attn_res"]),
+                res_blocks=c["res_blocks"], dropout=0.2, image_size=c["image_size"])
+    sd = {"denoise_fn." + k: v.detach() for k, v in unet.state_dict().items()}
+    sch = O.schedule(dict(schedule="linear", n_timestep=T, linear_start=1e-6, linear_end=1e-2))
+    cond = seeded.synthetic_image((1, 3, side, side), seed=1, smooth=4)
+    x = torch.randn(1, 3, side, side)
+    with torch.no_grad():
+        O.p_sample(sd, c, sch, x, T - 1, cond, torch.randn_like(x))  # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        for i in range(steps_sampled):
+            x = O.p_sample(sd, c, sch, x, T - 1 - i, cond, torch.randn_like(x))
+        dt = (time.perf_counter() - t0) / steps_sampled
+    return {"value": 1.0 / (dt * T), "unit": "img/s", "cores": ncores, "kind": "port",
+            "sample": f"{steps_sampled} ancestral steps of 1 image at {side}x{side} on the fp32 CPU oracle "
+                      f"({dt:.2f} s/step, {ncores} threads of {avail} schedulable cores), extrapolated linearly to {T} steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
+    ap.add_argument("--lr-side", type=int, default=128)
+    ap.add_argument("--scale", type=int, default=4)
+    ap.add_argument("--ddpm-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    args = ap.parse_args()
+
+    from rsvld_amd import ops, parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    side = args.lr_side * args.scale
+    T = args.ddpm_steps
+
+    net = build_model(dev, T)
+    net.use_graph = not args.no_graph
+    cond = synthetic_batch(args.batch, args.lr_side, args.scale, rank).to(dev)
+
+    def one_pass():
+        # continous=False returns ret_img[-1], i.e. ONE image (diffusion.py:198-201): take the last
+        # B rows of the 11-frame stack instead, as infer.py does for its single image (infer.py:133-135)
+        sr = net.super_resolution(cond, continous=True)[-args.batch:]
+        u8 = parallel.to_uint8(sr)
+        return parallel.gather_images(u8, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    n_img = args.batch * world * args.steps
+    value = n_img / dt
+
+    # ---- roofline of the dominant kernel: one extra, instrumented pass (not part of `value`)
+    roof = None
+    if rank == 0:
+        prof = ops.LaunchProfiler()
+        ops.set_profiler(prof)
+        saved = net.use_graph
+        net.use_graph = False
+        one_pass()
+        torch.cuda.synchronize()
+        net.use_graph = saved
+        ops.set_profiler(None)
+        summ = prof.summary()
+        dom = max(summ.values(), key=lambda r: r["ms"])
+        tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK_TFLOPS_F16,
+                "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": None,
+                "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 2),
+                "kernel_time_share": round(dom["ms"] / sum(r["ms"] for r in summ.values()), 3),
+                "by_kernel": {k: {"ms": round(v["ms"], 3), "n": v["n"],
+                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
+                              for k, v in summ.items()}}
+
+    if rank == 0:
+        step_tf = UNET_TF_PER_IMAGE_STEP.get(side)
+        line = {
+            "metric": METRIC, "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: Stage-1 (SR3) only, {args.lr_side}->{side} x{args.scale} SR, "
+                                   f"batch {args.batch}/GPU, {T} ancestral DDPM steps, seeded random-init weights",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "hipgraph": bool(net.use_graph),
+                       "algorithmic_tflops_whole_step": None if step_tf is None else round(
+                           step_tf * T * args.batch * world * args.steps / dt, 2)},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(side, T)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -243,6 +243,205 @@ __global__ __launch_bounds__(256) void attn_d512_kernel(AttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// D = 64 (multi-head: sgm CrossAttention / MemoryEfficientCrossAttention, ZeroCrossAttn)
+//   workgroup = 4 waves, each wave owns QT x 32 query rows of one head; 64-key tiles of K and
+//   V^T are double-buffered in LDS and shared by the 4 waves (one barrier per tile).
+//   S^T = K Q^T is computed "swapped" (keys on the accumulator registers, the query row on the
+//   lane), so the online softmax is register-local: a row's 64 scores sit in the registers of
+//   lanes l and l^32 (one shuffle for max; the row sums are merged once at the end).
+//   P never touches LDS: accumulator registers 8s..8s+7 are converted to 16-bit and used
+//   directly as the B operand of k-step s of O^T += V^T P^T (cdna_hip_programming.md §3 "An
+//   accumulator tile as the next MFMA's operand"); their k order is permuted
+//   (k = 16s + 8(j>>2) + 4h + (j&3)), so V^T is STORED in LDS with that permutation and the A
+//   operand stays one ds_read_b128.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int a6_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int QT>
+__global__ __launch_bounds__(256) void attn_d64_kernel(AttnArgs p) {
+    constexpr int D = 64;
+    typedef typename Mfma<T>::v8 v8;
+    typedef typename Mfma<T>::v4 v4;
+    __shared__ __attribute__((aligned(16))) char smem[4 * 8192];  // K[2] | VT[2], 8 KiB each
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + w) * (QT * 32), h = blockIdx.y, b = blockIdx.z;
+    const T* Qb = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
+    const T* Kb = (const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D;
+    const T* Vb = (const T*)p.v + (int64_t)b * p.v_bs + (int64_t)h * D;
+    T* Ob = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)h * D;
+
+    v8 qf[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = q0 + qt * 32 + l31;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < p.Nq) v = *(const u32x4*)(Qb + (int64_t)row * p.q_ts + ks * 16 + lh * 8);
+            qf[qt][ks] = __builtin_bit_cast(v8, v);
+        }
+    f32x16 oacc[QT][2];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qt][dt][r] = 0.f;
+    }
+
+    // staging roles.  K: two 16-B chunks per thread.  V: a 4(kv) x 4(d) micro-block per thread,
+    // transposed in registers and written as four 8-B pieces of V^T.
+    const int kc = tid & 7, kr = tid >> 3;        // chunk kc of rows kr, kr+32
+    const int dq = tid & 15, kvq = tid >> 4;      // d = 4dq.., kv = 4kvq..
+    u32x4 rk[2];
+    u32x2 rv[4];
+    auto load_kv = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kv = t * 64 + kr + 32 * i;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (kv < p.Nk) v = *(const u32x4*)(Kb + (int64_t)kv * p.k_ts + kc * 8);
+            rk[i] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kv = t * 64 + kvq * 4 + r;
+            u32x2 v = {0u, 0u};
+            if (kv < p.Nk) v = *(const u32x2*)(Vb + (int64_t)kv * p.v_ts + dq * 4);
+            rv[r] = v;
+        }
+    };
+    auto store_kv = [&](int buf) {
+        char* Ks = smem + buf * 8192;
+        char* VTs = smem + 16384 + buf * 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *(u32x4*)(Ks + a6_off(kr + 32 * i, kc)) = rk[i];
+        v4 vin[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vin[r] = __builtin_bit_cast(v4, rv[r]);
+        // kv = 4*kvq + r  ->  16-group g, within it 8a + 4hh + r  ->  stored position 8hh + 4a + r
+        const int g = kvq >> 2, a = (kvq >> 1) & 1, hh = kvq & 1;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            v4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = vin[r][dd];
+            const int d = dq * 4 + dd;
+            *(v4*)(VTs + a6_off(d, 2 * g + hh) + a * 8) = o;
+        }
+    };
+
+    const int ntiles = (p.Nk + 63) / 64;
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        if (more) load_kv(t + 1);
+        const char* Ks = smem + (t & 1) * 8192;
+        const char* VTs = smem + 16384 + (t & 1) * 8192;
+
+        // ---- S^T[kv][q] for both 32-key halves
+        f32x16 sacc[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[qt][kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const v8 kf = *(const v8*)(Ks + a6_off(kt * 32 + l31, 2 * ks + lh));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) sacc[qt][kt] = Mfma<T>::mma(kf, qf[qt][ks], sacc[qt][kt]);
+            }
+
+        // ---- online softmax, register-local per query row (lane) + its partner lane^32
+        v8 pf[QT][4];
+        const bool tail = (t + 1) * 64 > p.Nk;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sv = sacc[qt][kt][r] * p.scale_log2e;
+                    if (tail) {
+                        const int kv = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (kv >= p.Nk) sv = -INFINITY;
+                    }
+                    sacc[qt][kt][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = exp2f(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = exp2f(sacc[qt][kt][r] - m_new);
+                    sacc[qt][kt][r] = pv;
+                    rs += pv;
+                }
+            l_run[qt] = l_run[qt] * alpha + rs;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[qt][dt][r] *= alpha;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                v8 f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (T)sacc[qt][s4 >> 1][8 * (s4 & 1) + j];
+                pf[qt][s4] = f;
+            }
+        }
+
+        // ---- O^T[d][q] += V^T P^T
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const v8 vf = *(const v8*)(VTs + a6_off(dt * 32 + l31, 2 * s4 + lh));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = Mfma<T>::mma(vf, pf[qt][s4], oacc[qt][dt]);
+            }
+
+        if (more) store_kv((t + 1) & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int row = q0 + qt * 32 + l31;
+        const float l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+        if (row >= p.Nq) continue;
+        const float inv = 1.0f / l_tot;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)(oacc[qt][dt][4 * g + e] * inv);
+                *(v4*)(Ob + (int64_t)row * p.o_ts + dt * 32 + 8 * g + 4 * lh) = o;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
@@ -283,6 +482,20 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
                 set = true;
             }
             hipLaunchKernelGGL(attn_d512_kernel<bf16>, grid, dim3(256), A5_SMEM, s, a);
+        }
+        return rsvld_check_launch();
+    }
+    if (D == 64) {
+        // 2 query tiles per wave (256 rows per workgroup) once the grid still fills the chip
+        const bool big = (int64_t)((Nq + 255) / 256) * heads * B >= 512;
+        const int rows = big ? 256 : 128;
+        dim3 grid((unsigned)((Nq + rows - 1) / rows), (unsigned)heads, (unsigned)B);
+        if (dtype == RSVLD_F16) {
+            if (big) hipLaunchKernelGGL((attn_d64_kernel<f16, 2>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_d64_kernel<f16, 1>), grid, dim3(256), 0, s, a);
+        } else {
+            if (big) hipLaunchKernelGGL((attn_d64_kernel<bf16, 2>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_d64_kernel<bf16, 1>), grid, dim3(256), 0, s, a);
         }
         return rsvld_check_launch();
     }

@@ -34,7 +34,20 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
             int coff;
             if (cc < C1_8) { src = x1 + (int64_t)b * HW * C1; cstride = C1; coff = cc * 8; }
             else { src = x2 + (int64_t)b * HW * C2; cstride = C2; coff = (cc - C1_8) * 8; }
-            for (int r = row_lo + rsub; r < row_hi; r += rif) {
+            int r = row_lo + rsub;
+            for (; r + 3 * rif < row_hi; r += 4 * rif) {  // 4 independent 16-B loads in flight
+                u32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(src + (int64_t)(r + u * rif) * cstride + coff);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    unpack8<T>(v[u], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+                }
+            }
+            for (; r < row_hi; r += rif) {
                 const u32x4 v = *(const u32x4*)(src + (int64_t)r * cstride + coff);
                 float f[8];
                 unpack8<T>(v, f);
@@ -60,78 +73,102 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
-// pass 2: stats[b][g] = (mean, biased var), fp64 merge of the partials (deterministic)
-__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int groups,
-                                   int nchunks, double inv_count, int total) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// pass 2: stats[b][g] = (mean, biased var); one wave per (image, group), lanes stride over the
+// chunk partials, fp64 merge in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                          int groups, int nchunks, double inv_count, int total) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= total) return;
     const int b = i / groups, g = i - b * groups;
     double s = 0.0, ss = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = lane; c < nchunks; c += 64) {
         const float* p = part + (((int64_t)b * nchunks + c) * groups + g) * 2;
         s += (double)p[0];
         ss += (double)p[1];
     }
-    const double mean = s * inv_count;
-    double var = ss * inv_count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[2 * i] = (float)mean;
-    stats[2 * i + 1] = (float)var;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        ss += __shfl_xor(ss, o);
+    }
+    if (lane == 0) {
+        const double mean = s * inv_count;
+        double var = ss * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)var;
+    }
 }
 
 // pass 3: y = act((x-mean)*rstd*gamma+beta) [*(1+scale1p)+shift]
-// grid (blocks over HW*C8 chunks, B); per-channel a/b cached in LDS per block.
+// grid (row-chunks, B).  Same thread <-> channel-chunk mapping as pass 1: a thread keeps ONE
+// 8-channel chunk, so its 8 (scale, shift) pairs live in registers and the row loop is pure
+// 16-byte streaming with 4 loads in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, const T* __restrict__ x2,
                                                        T* __restrict__ y, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const T* __restrict__ mod_scale, const T* __restrict__ mod_shift,
                                                        int HW, int C1, int C2, int groups, float eps, int silu,
-                                                       int chunks_per_block) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sa = (float*)smem_raw;  // [C] scale
+                                                       int rows_per_block) {
     const int C = C1 + C2, C8 = C >> 3, C1_8 = C1 >> 3;
-    float* sb = sa + C;            // [C] shift
+    const int TPR = C8 < 256 ? C8 : 256;
+    const int rif = 256 / TPR;
+    const int tid = threadIdx.x;
+    const int tc = tid % TPR, rsub = tid / TPR;
+    if (rsub >= rif) return;
     const int b = blockIdx.y;
     const int gs = C / groups;
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
-        const int g = ch / gs;
-        const float mean = stats[((int64_t)b * groups + g) * 2];
-        const float var = stats[((int64_t)b * groups + g) * 2 + 1];
-        const float rstd = 1.0f / sqrtf(var + eps);
-        const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
-        const float a = rstd * ga;
-        sa[ch] = a;
-        sb[ch] = be - mean * a;
-    }
-    __syncthreads();
-    const int64_t total = (int64_t)HW * C8;
-    const int64_t lo = (int64_t)blockIdx.x * chunks_per_block;
-    const int64_t hi = min(total, lo + chunks_per_block);
-    for (int64_t idx = lo + threadIdx.x; idx < hi; idx += 256) {
-        const int64_t r = idx / C8;
-        const int cc = (int)(idx - r * C8);
-        u32x4 v;
-        if (cc < C1_8) v = *(const u32x4*)(x1 + ((int64_t)b * HW + r) * C1 + cc * 8);
-        else v = *(const u32x4*)(x2 + ((int64_t)b * HW + r) * C2 + (cc - C1_8) * 8);
-        float f[8];
-        unpack8<T>(v, f);
-        const int c0 = cc * 8;
+    const int row_lo = blockIdx.x * rows_per_block;
+    const int row_hi = min(HW, row_lo + rows_per_block);
+    for (int cc = tc; cc < C8; cc += TPR) {
+        float sa[8], sb[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float t = f[e] * sa[c0 + e] + sb[c0 + e];
-            if (silu) t = silu_f(t);
-            f[e] = t;
+            const int ch = cc * 8 + e;
+            const int g = ch / gs;
+            const float mean = stats[((int64_t)b * groups + g) * 2];
+            const float var = stats[((int64_t)b * groups + g) * 2 + 1];
+            const float a = (gamma ? gamma[ch] : 1.f) / sqrtf(var + eps);
+            sa[e] = a;
+            sb[e] = (beta ? beta[ch] : 0.f) - mean * a;
         }
-        const int64_t o = ((int64_t)b * HW + r) * C + c0;
-        if (mod_scale != nullptr) {
-            float ms[8], mh[8];
-            unpack8<T>(*(const u32x4*)(mod_scale + o), ms);
-            unpack8<T>(*(const u32x4*)(mod_shift + o), mh);
+        const T* src;
+        int64_t cstride;
+        int coff;
+        if (cc < C1_8) { src = x1 + (int64_t)b * HW * C1; cstride = C1; coff = cc * 8; }
+        else { src = x2 + (int64_t)b * HW * C2; cstride = C2; coff = (cc - C1_8) * 8; }
+        T* dst = y + (int64_t)b * HW * C + cc * 8;
+        auto emit = [&](int r, const u32x4& v) {
+            float f[8];
+            unpack8<T>(v, f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = f[e] * (1.f + ms[e]) + mh[e];
+            for (int e = 0; e < 8; ++e) {
+                float t = f[e] * sa[e] + sb[e];
+                if (silu) t = silu_f(t);
+                f[e] = t;
+            }
+            const int64_t o = (int64_t)r * C;
+            if (mod_scale != nullptr) {
+                const int64_t mo = ((int64_t)b * HW + r) * C + cc * 8;
+                float ms[8], mh[8];
+                unpack8<T>(*(const u32x4*)(mod_scale + mo), ms);
+                unpack8<T>(*(const u32x4*)(mod_shift + mo), mh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * (1.f + ms[e]) + mh[e];
+            }
+            *(u32x4*)(dst + o) = pack8<T>(f);
+        };
+        int r = row_lo + rsub;
+        for (; r + 3 * rif < row_hi; r += 4 * rif) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(src + (int64_t)(r + u * rif) * cstride + coff);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emit(r + u * rif, v[u]);
         }
-        *(u32x4*)(y + o) = pack8<T>(f);
+        for (; r < row_hi; r += rif) emit(r, *(const u32x4*)(src + (int64_t)r * cstride + coff));
     }
 }
 
@@ -188,9 +225,9 @@ struct GnPlan {
 GnPlan gn_plan(int B, int HW) {
     int max_chunks = 2048 / (B > 0 ? B : 1);
     if (max_chunks < 1) max_chunks = 1;
-    if (max_chunks > 256) max_chunks = 256;
+    if (max_chunks > 512) max_chunks = 512;
     int rpc = (HW + max_chunks - 1) / max_chunks;
-    if (rpc < 32) rpc = 32;
+    if (rpc < 64) rpc = 64;
     GnPlan p;
     p.rows_per_chunk = rpc;
     p.nchunks = (HW + rpc - 1) / rpc;
@@ -217,7 +254,7 @@ int gn_stats_impl(const void* x, const void* x2, float* stats, int B, int HW, in
                        HW, C1, C2, groups, pl.rows_per_chunk, pl.nchunks);
     const int total = B * groups;
     const double inv_count = 1.0 / ((double)HW * (double)(C / groups));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, stats, groups, pl.nchunks,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s, part, stats, groups, pl.nchunks,
                        inv_count, total);
     return rsvld_check_launch();
 }
@@ -226,16 +263,17 @@ template <typename T>
 int gn_apply_impl(const void* x, const void* x2, void* y, const float* stats, const float* gamma, const float* beta,
                   const void* mscale, const void* mshift, int B, int HW, int C1, int C2, int groups, float eps,
                   int silu, hipStream_t s) {
-    const int C = C1 + C2;
-    const int64_t total = (int64_t)HW * (C / 8);
-    int cpb = 2048;  // 16-B chunks per block (32 KiB of input)
-    // keep the LDS prologue (2*C floats) small relative to the block's work
-    if (C > 1024) cpb = 4096;
-    const int64_t nblk = cdiv64(total, cpb);
-    const size_t smem = (size_t)C * 2 * sizeof(float);
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)nblk, B), dim3(256), smem, s, (const T*)x, (const T*)x2,
+    const int C = C1 + C2, C8 = C / 8;
+    const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
+    // ~2048 blocks over the chip, at least 4*rif rows per block so the unrolled loop is used
+    int max_blocks = 2048 / (B > 0 ? B : 1);
+    if (max_blocks < 1) max_blocks = 1;
+    int rpb = (HW + max_blocks - 1) / max_blocks;
+    if (rpb < 4 * rif) rpb = 4 * rif;
+    const int nblk = (HW + rpb - 1) / rpb;
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)nblk, B), dim3(256), 0, s, (const T*)x, (const T*)x2,
                        (T*)y, stats, gamma, beta, (const T*)mscale, (const T*)mshift, HW, C1, C2, groups, eps, silu,
-                       cpb);
+                       rpb);
     return rsvld_check_launch();
 }
 

@@ -40,6 +40,48 @@ def pad8(c):
     return (c + 7) // 8 * 8
 
 
+# ----------------------------------------------------------------------------- launch profiling
+class LaunchProfiler:
+    """Brackets every C-ABI launch with HIP events on the launch stream (torch's current stream is
+    the stream the kernels are enqueued on) and accumulates time / algorithmic FLOPs per kernel."""
+
+    def __init__(self):
+        self.records = []
+
+    def run(self, name, flops, nbytes, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.records.append((name, flops, nbytes, e0, e1))
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            r = agg.setdefault(name, {"name": name, "ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+            r["ms"] += e0.elapsed_time(e1)
+            r["n"] += 1
+            r["flops"] += flops
+            r["bytes"] += nbytes
+        return agg
+
+
+_PROFILER = None
+
+
+def set_profiler(p):
+    global _PROFILER
+    _PROFILER = p
+
+
+def _launch(name, flops, nbytes, fn):
+    if _PROFILER is None:
+        return fn()
+    return _PROFILER.run(name, flops, nbytes, fn)
+
+
 # ----------------------------------------------------------------------------- weights
 class PackedConv:
     """K-major 16-bit weights of a Conv2d / Linear: ``w[Cout_p, KH*KW*Cin_p]``, bias fp32."""
@@ -130,7 +172,13 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride,
         pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=_dt(x), out_f32=int(out_f32),
         act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride)
-    L.check(L.load().rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc")
+    variant = "conv_igemm_256x32" if pc.cout_p <= 32 else ("conv_igemm_256x64" if pc.cout_p <= 64 else "conv_igemm_128x128")
+    esz = x.element_size()
+    flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
+    nbytes = (x.numel() + (0 if x2 is None else x2.numel()) + pc.w.numel()) * esz + out.numel() * out.element_size() \
+        + (0 if residual is None else residual.numel() * esz)
+    lib = L.load()
+    _launch(variant, flops, nbytes, lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
     return out
 
 
@@ -152,9 +200,11 @@ def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=
     lib = L.load()
     ws = torch.empty(lib.rsvld_groupnorm_ws_bytes(B, H * W, C1 + C2, groups), device=x.device, dtype=torch.uint8)
     y = torch.empty((B, H, W, C1 + C2), device=x.device, dtype=x.dtype)
-    L.check(lib.rsvld_groupnorm_nhwc(_ptr(x), _ptr(x2), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mod_scale1p),
-                                     _ptr(mod_shift), B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _ptr(ws),
-                                     _stream()), "rsvld_groupnorm_nhwc")
+    nbytes = 3 * y.numel() * y.element_size()  # stats read + apply read + write
+    _launch("groupnorm(3 kernels)", 0.0, nbytes, lambda: L.check(
+        lib.rsvld_groupnorm_nhwc(_ptr(x), _ptr(x2), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mod_scale1p),
+                                 _ptr(mod_shift), B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _ptr(ws),
+                                 _stream()), "rsvld_groupnorm_nhwc"))
     return y
 
 
@@ -206,9 +256,13 @@ def attention(q, k, v, heads, scale=None):
         if t.stride(2) != 1:
             raise L.RsvldError("attention: last dim must be contiguous")
     out = torch.empty((B, Nq, HD), device=q.device, dtype=q.dtype)
-    L.check(L.load().rsvld_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
-                                     q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                     out.stride(0), out.stride(1), scale, _dt(q), _stream()), "rsvld_attention")
+    lib = L.load()
+    flops = 4.0 * B * heads * Nq * Nk * D
+    nbytes = (q.shape[0] * Nq * HD * 2 + 2 * B * Nk * HD) * q.element_size()
+    _launch(f"attention_d{D}", flops, nbytes, lambda: L.check(
+        lib.rsvld_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
+                            q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                            out.stride(0), out.stride(1), scale, _dt(q), _stream()), "rsvld_attention"))
     return out
 
 

@@ -1,0 +1,58 @@
+"""Data-parallel sharding of independent images: one process per GPU, RCCL over xGMI.
+
+The reference processes one image at a time (infer_dir.py:198-200; just_sampling is only called
+with N=1) and has no collective on the hot path.  Images are independent units, so the only
+exchange is ONE all-gather of the finished uint8 images per batch.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """(rank, world, local_rank).  Initialises torch.distributed from RANK/WORLD_SIZE/MASTER_* when
+    world > 1 (backend 'nccl' = RCCL on ROCm, 'gloo' on CPU)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_images, rank, world):
+    """Image i is processed by rank i % world (round-robin keeps per-rank load within one image)."""
+    return list(range(rank, n_images, world))
+
+
+def to_uint8(x):
+    """[-1,1] fp32 NCHW -> uint8, the quantisation the reference applies at the Stage-1 hand-off
+    (utils/tensor2img.py:4-21): clamp, (x+1)/2*255, round."""
+    return ((x.clamp(-1, 1) + 1) * 0.5 * 255.0).round().to(torch.uint8)
+
+
+def gather_images(local_u8, world):
+    """All-gather equally-shaped uint8 image batches; returns [world*B, C, H, W] ordered by rank."""
+    if world == 1:
+        return local_u8
+    out = torch.empty((world,) + tuple(local_u8.shape), dtype=local_u8.dtype, device=local_u8.device)
+    dist.all_gather_into_tensor(out, local_u8.contiguous())
+    return out.flatten(0, 1)
+
+
+def unshard(gathered, n_images, world):
+    """Invert shard_indices: gathered is rank-major ([rank0's images..., rank1's ...]) -> image order."""
+    per = gathered.shape[0] // world
+    order = []
+    for r in range(world):
+        order += shard_indices(n_images, r, world)[:per]
+    inv = torch.empty(len(order), dtype=torch.long)
+    inv[torch.tensor(order)] = torch.arange(len(order))
+    return gathered[inv.to(gathered.device)]
