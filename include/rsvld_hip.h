@@ -81,7 +81,8 @@ int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
  * rsvld_groupnorm_ws_bytes(B, HW, C, groups) bytes.
  *   y = act( (x - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c] )
  * With x2 != NULL statistics and output cover the concatenation [x | x2] along C.
- * If scale1p/shift (both [B,HW,C] 16-bit) are given: y = y*(1+scale1p) + shift  (ZeroSFT).
+ * If scale1p/shift (16-bit, rows of `mod_stride` elements, 0 = C; both may point into one stacked
+ * [B,HW,2C] conv output) are given: y = y*(1+scale1p) + shift  (ZeroSFT, SR_modules.py:100-106).
  *
  * Replaces: nn.GroupNorm + Swish/SiLU at sr3_modules/unet.py:81-92,114-125;
  *   GroupNorm32 (sgm/modules/diffusionmodules/util.py:273-276) in openaimodel.py:207-350;
@@ -91,7 +92,7 @@ int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
 int64_t rsvld_groupnorm_ws_bytes(int B, int HW, int C, int groups);
 int rsvld_groupnorm_nhwc(const void* x, const void* x2, void* y,
                          const float* gamma, const float* beta,
-                         const void* mod_scale1p, const void* mod_shift,
+                         const void* mod_scale1p, const void* mod_shift, int mod_stride,
                          int B, int HW, int C1, int C2, int groups, float eps,
                          int silu, int dtype, void* ws, void* stream);
 /* statistics only: writes mean_var[B*groups*2] fp32 = (mean, biased variance) per (image, group);
@@ -102,7 +103,7 @@ int rsvld_groupnorm_stats(const void* x, const void* x2, float* mean_var,
 /* apply with caller-provided statistics (mean_var[B*groups*2]) */
 int rsvld_groupnorm_apply(const void* x, const void* x2, void* y, const float* mean_var,
                           const float* gamma, const float* beta,
-                          const void* mod_scale1p, const void* mod_shift,
+                          const void* mod_scale1p, const void* mod_shift, int mod_stride,
                           int B, int HW, int C1, int C2, int groups, float eps,
                           int silu, int dtype, void* stream);
 
@@ -150,10 +151,11 @@ int rsvld_sinusoidal_embedding(const float* t, float* out, int rows, int dim, in
 /* ---------------------------------------------------------------------------------------
  * Layout / element-wise kernels (HBM-bound).
  * ------------------------------------------------------------------------------------- */
-/* fp32 NCHW [B,C,H,W] -> 16-bit NHWC [B,H,W,Cdst] at channel offset c_off (pad lanes untouched
- * unless zero_pad=1, which zeroes channels outside [c_off, c_off+C)). */
+/* fp32 NCHW [B,C,H,W] * scale -> 16-bit NHWC [B,H,W,Cdst] at channel offset c_off (pad lanes untouched
+ * unless zero_pad=1, which zeroes channels outside [c_off, c_off+C)).  `scale` carries the denoiser's
+ * input scaling c_in (denoiser.py:72-76). */
 int rsvld_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W,
-                           int Cdst, int c_off, int zero_pad, int dtype, void* stream);
+                           int Cdst, int c_off, int zero_pad, float scale, int dtype, void* stream);
 /* 16-bit (or fp32 when src_f32) NHWC [B,H,W,Csrc] channels [c_off,c_off+C) -> fp32 NCHW */
 int rsvld_nhwc_to_nchw_f32(const void* src, float* dst, int B, int C, int H, int W,
                            int Csrc, int c_off, int src_f32, int dtype, void* stream);
@@ -171,6 +173,49 @@ int rsvld_ddpm_step(const float* x, const float* eps_nhwc, const float* noise, f
                     int B, int C, int H, int W, int eps_c,
                     float c_recip, float c_recipm1, float coef1, float coef2, float sigma,
                     int clip, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Stage-2 sampler (RestoreEDMSampler + DiscreteDenoiserWithControl + LinearCFG), fp32 NCHW state.
+ * ------------------------------------------------------------------------------------- */
+/* out (fp32 NCHW) = net_out_nhwc (fp32 NHWC [B,H,W,c_pad]) * c_out + input (fp32 NCHW) * c_skip.
+ * Replaces denoiser.py:77-78. */
+int rsvld_denoiser_out(const float* net_out_nhwc, const float* input, float* out,
+                       int B, int C, int H, int W, int c_pad, float c_out, float c_skip, void* stream);
+/* out = a + w*(b-a): CFG combine x_u + s*(x_c - x_u) (guiders.py:58-63, sampling_utils.py:7-9) */
+int rsvld_lerp_f32(const float* a, const float* b, float* out, int64_t n, float w, void* stream);
+/* out = x + s*y (x == NULL: out = s*y): churn noise x + eps*s_noise*sqrt(sigma_hat^2 - sigma^2)
+ * (sampling.py:600-606) and the initial x *= sqrt(1 + sigma_0^2) (:49) */
+int rsvld_axpy_f32(const float* x, const float* y, float* out, int64_t n, float s, void* stream);
+/* dn = denoised - (denoised - x_center)*restore_w (x_center may be NULL); x_out = x_hat +
+ * (x_hat - dn)/sigma_hat * dt.   Replaces sampling.py:614-620. */
+int rsvld_euler_step(const float* x_hat, const float* denoised, const float* x_center, float* x_out,
+                     int64_t n, float restore_w, float sigma_hat, float dt, void* stream);
+/* First-block-cache similarity (models/modules/DFBCache.py:98-112): out[row] = (sum|a-b|, sum|a|) per
+ * row of two 16-bit [rows, n_per_row] tensors; fp32 partials, fp64 merge, deterministic. */
+int64_t rsvld_absdiff_ws_bytes(int rows, int64_t n_per_row);
+int rsvld_absdiff_sums(const void* a, const void* b, float* out, int rows, int64_t n_per_row,
+                       int dtype, void* ws, void* stream);
+
+/* DiagonalGaussianDistribution (sgm/modules/distributions/distributions.py:24-41,71-72) on NHWC moments
+ * [B,H,W,m_c] (mean | logvar): z = (mean + exp(0.5*clamp(logvar,-30,20))*noise)*scale, or mode()*scale
+ * when noise == NULL; z is fp32 NCHW [B,C,H,W]. */
+int rsvld_gaussian_sample(const void* moments_nhwc, const float* noise, float* z,
+                          int B, int C, int H, int W, int m_c, float scale, int src_f32,
+                          int dtype, void* stream);
+
+/* Colour fix (utils/colorfix.py).  wavelet_blur: 3x3 [1,2,1]x[1,2,1]/16 depthwise blur, dilation =
+ * radius, replicate padding, on `planes` fp32 H x W planes; if high_accum != NULL it also accumulates
+ * high_accum += img - low (one level of wavelet_decomposition, :94-106). */
+int rsvld_wavelet_blur(const float* img, float* low, float* high_accum, int planes, int H, int W,
+                       int radius, void* stream);
+int rsvld_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* adaptive_instance_normalization (:59-71); ws_stats holds 4*planes floats */
+int rsvld_adain(const float* content, const float* style, float* out, float* ws_stats,
+                int planes, int64_t HW, void* stream);
+
+/* channel concatenation of two 16-bit NHWC tensors [rows,C1] | [rows,C2] -> [rows,C1+C2] */
+int rsvld_concat_c(const void* a, const void* b, void* out, int64_t rows, int C1, int C2,
+                   int dtype, void* stream);
 
 #ifdef __cplusplus
 }

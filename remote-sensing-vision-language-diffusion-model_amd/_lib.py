@@ -40,19 +40,30 @@ SIGNATURES = {
     "rsvld_version": (C.c_char_p, []),
     "rsvld_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
     "rsvld_groupnorm_ws_bytes": (_i64, [_i, _i, _i, _i]),
-    "rsvld_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
+    "rsvld_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "rsvld_groupnorm_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "rsvld_groupnorm_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "rsvld_groupnorm_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "rsvld_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
     "rsvld_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
                              _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _vp]),
     "rsvld_linear_small_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsvld_sinusoidal_embedding": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "rsvld_nchw_f32_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsvld_nchw_f32_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "rsvld_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsvld_axpby": (_i, [_vp, _vp, _vp, _i64, _f, _f, _i, _vp]),
     "rsvld_geglu": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "rsvld_ddpm_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _vp]),
+    "rsvld_denoiser_out": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    "rsvld_lerp_f32": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
+    "rsvld_axpy_f32": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
+    "rsvld_euler_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _vp]),
+    "rsvld_absdiff_ws_bytes": (_i64, [_i, _i64]),
+    "rsvld_absdiff_sums": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
+    "rsvld_gaussian_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "rsvld_wavelet_blur": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsvld_add_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "rsvld_adain": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "rsvld_concat_c": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -6,7 +6,7 @@ namespace {
 // fp32 NCHW -> 16-bit NHWC (channel window [c_off, c_off+C) of a Cdst-wide row); one thread per pixel
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int64_t HW, int Cdst,
-                                    int c_off, int zero_pad, int64_t total_pix) {
+                                    int c_off, int zero_pad, float scale, int64_t total_pix) {
     const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= total_pix) return;
     const int64_t b = pix / HW, r = pix - b * HW;
@@ -14,10 +14,10 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict
     if (zero_pad) {
         for (int c = 0; c < Cdst; ++c) {
             const int cs = c - c_off;
-            d[c] = (cs >= 0 && cs < C) ? (T)src[(b * C + cs) * HW + r] : (T)0.f;
+            d[c] = (cs >= 0 && cs < C) ? (T)(src[(b * C + cs) * HW + r] * scale) : (T)0.f;
         }
     } else {
-        for (int c = 0; c < C; ++c) d[c_off + c] = (T)src[(b * C + c) * HW + r];
+        for (int c = 0; c < C; ++c) d[c_off + c] = (T)(src[(b * C + c) * HW + r] * scale);
     }
 }
 
@@ -126,15 +126,15 @@ __global__ void sinusoidal_kernel(const float* __restrict__ t, float* __restrict
 extern "C" const char* rsvld_version(void) { return "rsvld-hip 0.1 (gfx950)"; }
 
 extern "C" int rsvld_nchw_f32_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cdst, int c_off,
-                                      int zero_pad, int dtype, void* stream) {
+                                      int zero_pad, float scale, int dtype, void* stream) {
     if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || c_off < 0 || c_off + C > Cdst) return RSVLD_EINVAL;
     const int64_t HW = (int64_t)H * W, total = HW * B;
     const unsigned nblk = (unsigned)cdiv64(total, 256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RSVLD_F16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, dim3(nblk), dim3(256), 0, s, src, (f16*)dst, C, HW, Cdst, c_off, zero_pad, total);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16>, dim3(nblk), dim3(256), 0, s, src, (f16*)dst, C, HW, Cdst, c_off, zero_pad, scale, total);
     else if (dtype == RSVLD_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(nblk), dim3(256), 0, s, src, (bf16*)dst, C, HW, Cdst, c_off, zero_pad, total);
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(nblk), dim3(256), 0, s, src, (bf16*)dst, C, HW, Cdst, c_off, zero_pad, scale, total);
     else
         return RSVLD_EINVAL;
     return rsvld_check_launch();

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const T* __restrict__ mod_scale, const T* __restrict__ mod_shift,
                                                        int HW, int C1, int C2, int groups, float eps, int silu,
-                                                       int rows_per_block) {
+                                                       int rows_per_block, int mod_stride) {
     const int C = C1 + C2, C8 = C >> 3, C1_8 = C1 >> 3;
     const int TPR = C8 < 256 ? C8 : 256;
     const int rif = 256 / TPR;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
             }
             const int64_t o = (int64_t)r * C;
             if (mod_scale != nullptr) {
-                const int64_t mo = ((int64_t)b * HW + r) * C + cc * 8;
+                const int64_t mo = ((int64_t)b * HW + r) * mod_stride + cc * 8;
                 float ms[8], mh[8];
                 unpack8<T>(*(const u32x4*)(mod_scale + mo), ms);
                 unpack8<T>(*(const u32x4*)(mod_shift + mo), mh);
@@ -261,8 +261,8 @@ int gn_stats_impl(const void* x, const void* x2, float* stats, int B, int HW, in
 
 template <typename T>
 int gn_apply_impl(const void* x, const void* x2, void* y, const float* stats, const float* gamma, const float* beta,
-                  const void* mscale, const void* mshift, int B, int HW, int C1, int C2, int groups, float eps,
-                  int silu, hipStream_t s) {
+                  const void* mscale, const void* mshift, int mod_stride, int B, int HW, int C1, int C2, int groups,
+                  float eps, int silu, hipStream_t s) {
     const int C = C1 + C2, C8 = C / 8;
     const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
     // ~2048 blocks over the chip, at least 4*rif rows per block so the unrolled loop is used
@@ -273,7 +273,7 @@ int gn_apply_impl(const void* x, const void* x2, void* y, const float* stats, co
     const int nblk = (HW + rpb - 1) / rpb;
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)nblk, B), dim3(256), 0, s, (const T*)x, (const T*)x2,
                        (T*)y, stats, gamma, beta, (const T*)mscale, (const T*)mshift, HW, C1, C2, groups, eps, silu,
-                       rpb);
+                       rpb, mod_stride > 0 ? mod_stride : C);
     return rsvld_check_launch();
 }
 
@@ -298,29 +298,29 @@ extern "C" int rsvld_groupnorm_stats(const void* x, const void* x2, float* mean_
 
 extern "C" int rsvld_groupnorm_apply(const void* x, const void* x2, void* y, const float* mean_var,
                                      const float* gamma, const float* beta, const void* mod_scale1p,
-                                     const void* mod_shift, int B, int HW, int C1, int C2, int groups, float eps,
-                                     int silu, int dtype, void* stream) {
+                                     const void* mod_shift, int mod_stride, int B, int HW, int C1, int C2, int groups,
+                                     float eps, int silu, int dtype, void* stream) {
     if (!x || !y || !mean_var || !gn_shape_ok(B, HW, C1, C2, groups) || ((C2 > 0) != (x2 != nullptr))) return RSVLD_EINVAL;
-    if ((mod_scale1p != nullptr) != (mod_shift != nullptr)) return RSVLD_EINVAL;
+    if ((mod_scale1p != nullptr) != (mod_shift != nullptr) || mod_stride < 0 || (mod_stride & 7)) return RSVLD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == RSVLD_F16)
-        return gn_apply_impl<f16>(x, x2, y, mean_var, gamma, beta, mod_scale1p, mod_shift, B, HW, C1, C2, groups, eps, silu, s);
+        return gn_apply_impl<f16>(x, x2, y, mean_var, gamma, beta, mod_scale1p, mod_shift, mod_stride, B, HW, C1, C2, groups, eps, silu, s);
     if (dtype == RSVLD_BF16)
-        return gn_apply_impl<bf16>(x, x2, y, mean_var, gamma, beta, mod_scale1p, mod_shift, B, HW, C1, C2, groups, eps, silu, s);
+        return gn_apply_impl<bf16>(x, x2, y, mean_var, gamma, beta, mod_scale1p, mod_shift, mod_stride, B, HW, C1, C2, groups, eps, silu, s);
     return RSVLD_EINVAL;
 }
 
 extern "C" int rsvld_groupnorm_nhwc(const void* x, const void* x2, void* y, const float* gamma, const float* beta,
-                                    const void* mod_scale1p, const void* mod_shift, int B, int HW, int C1, int C2,
-                                    int groups, float eps, int silu, int dtype, void* ws, void* stream) {
+                                    const void* mod_scale1p, const void* mod_shift, int mod_stride, int B, int HW, int C1,
+                                    int C2, int groups, float eps, int silu, int dtype, void* ws, void* stream) {
     if (!ws) return RSVLD_EINVAL;
     if (!gn_shape_ok(B, HW, C1, C2, groups)) return RSVLD_EINVAL;
     const GnPlan pl = gn_plan(B, HW);
     float* stats = (float*)ws + (int64_t)B * pl.nchunks * groups * 2;
     int rc = rsvld_groupnorm_stats(x, x2, stats, B, HW, C1, C2, groups, dtype, ws, stream);
     if (rc != RSVLD_OK) return rc;
-    return rsvld_groupnorm_apply(x, x2, y, stats, gamma, beta, mod_scale1p, mod_shift, B, HW, C1, C2, groups, eps, silu,
-                                 dtype, stream);
+    return rsvld_groupnorm_apply(x, x2, y, stats, gamma, beta, mod_scale1p, mod_shift, mod_stride, B, HW, C1, C2, groups,
+                                 eps, silu, dtype, stream);
 }
 
 extern "C" int rsvld_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C,

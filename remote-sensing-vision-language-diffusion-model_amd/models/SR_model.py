@@ -1,0 +1,158 @@
+"""Stage-2 driver: ``SR_backbone`` (reference: models/SR_model.py:17-298).
+
+Same constructor (yaml ``model.params``), same public methods — ``just_sampling``,
+``encode_first_stage``, ``encode_first_stage_with_denoise``, ``decode_first_stage``,
+``batchify_denoise``, ``init_tile_vae``, ``prepare_condition`` — and the same order of random draws
+in ``just_sampling``: posterior sample of ``z_stage1`` (CPU generator, distributions.py:37-41), then
+``randn_like(_z)`` (device generator, :265), then one draw per sampler step.  ``noise_source="cpu"``
+draws the device-side noises with the CPU generator instead, which makes a run comparable with the
+reference's CPU path for a fixed ``torch.manual_seed``.
+"""
+import copy
+
+import torch
+
+from ..sgm.models.diffusion import DiffusionEngine
+from ..sgm.util import AttrDict, instantiate_from_config
+from ..utils.colorfix import adaptive_instance_normalization, wavelet_reconstruction
+from .modules.DFBCache import MyCacheContext, cache_context
+
+
+class SR_backbone(DiffusionEngine):
+    def __init__(self, control_stage_config, ae_dtype="fp32", diffusion_dtype="fp32", p_p="", n_p="", *args, **kwargs):
+        kwargs = {k: (AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v) for k, v in kwargs.items()}
+        super().__init__(*args, **kwargs)
+        control_model = instantiate_from_config(control_stage_config)
+        self.model.load_control_model(control_model)
+        self.first_stage_model.denoise_encoder = copy.deepcopy(self.first_stage_model.encoder)
+        self.sampler_config = kwargs["sampler_config"]
+
+        assert (ae_dtype in ["fp32", "fp16", "bf16"]) and (diffusion_dtype in ["fp32", "fp16", "bf16"])
+        if ae_dtype == "fp16":
+            raise RuntimeError("fp16 cause NaN in AE")
+        self.ae_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[ae_dtype]
+        self.model.dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[diffusion_dtype]
+        self.first_stage_model.set_compute_dtype(self.ae_dtype)
+        self.p_p, self.n_p = p_p, n_p
+        self.noise_source = "device"
+        self.upscale, self.min_size = 1, 256
+
+    # ---- first stage ------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_first_stage(self, x):
+        """image fp32 NCHW -> sampled latent * scale_factor, fp32 NCHW (:57-62)."""
+        from ..sgm.modules.distributions.distributions import DiagonalGaussianDistribution
+        fs = self.first_stage_model
+        post = DiagonalGaussianDistribution(fs.moments(x), channels=fs.embed_dim)
+        B, H, W, _ = post.parameters.shape
+        # the reference draws this one with the CPU generator whatever the device (distributions.py:37-41)
+        return post.sample(self.scale_factor, noise=self._posterior_noise((B, fs.embed_dim, H, W)))
+
+    @torch.no_grad()
+    def encode_first_stage_with_denoise(self, x, use_sample=True, is_stage1=False):
+        """denoise_encoder -> quant_conv -> posterior sample()/mode() * scale_factor (:64-78)."""
+        fs = self.first_stage_model
+        if is_stage1:
+            raise NotImplementedError("denoise_encoder_s1 does not exist in the reference model either (:69)")
+        from ..sgm.modules.distributions.distributions import DiagonalGaussianDistribution
+        post = DiagonalGaussianDistribution(fs.moments(x, encoder=fs.denoise_encoder), channels=fs.embed_dim)
+        return post.sample(self.scale_factor) if use_sample else post.mode(self.scale_factor)
+
+    @torch.no_grad()
+    def decode_first_stage(self, z):
+        from .. import ops
+        return self.first_stage_model.decode(ops.axpy_f32(None, z.float().contiguous(), 1.0 / self.scale_factor)).float()
+
+    @torch.no_grad()
+    def batchify_denoise(self, x, is_stage1=False):
+        return self.decode_first_stage(self.encode_first_stage_with_denoise(x, use_sample=False, is_stage1=is_stage1))
+
+    def init_tile_vae(self, encoder_tile_size=512, decoder_tile_size=64):
+        from ..utils.tilevae import VAEHook
+        fs = self.first_stage_model
+        for net, size, dec in ((fs.denoise_encoder, encoder_tile_size, False), (fs.encoder, encoder_tile_size, False),
+                               (fs.decoder, decoder_tile_size, True)):
+            net.original_forward = net.forward
+            net.forward = VAEHook(net, size, is_decoder=dec, fast_decoder=False, fast_encoder=False, color_fix=False,
+                                  to_gpu=True)
+
+    # ---- conditioning -----------------------------------------------------------------------
+    def prepare_condition(self, _z, p, p_p, n_p, N):
+        batch = {
+            "original_size_as_tuple": torch.tensor([1024, 1024]).repeat(N, 1).to(_z.device),
+            "crop_coords_top_left": torch.tensor([0, 0]).repeat(N, 1).to(_z.device),
+            "target_size_as_tuple": torch.tensor([1024, 1024]).repeat(N, 1).to(_z.device),
+            "aesthetic_score": torch.tensor([9.0]).repeat(N, 1).to(_z.device),
+            "control": _z,
+        }
+        batch_uc = copy.copy(batch)
+        batch_uc["txt"] = [n_p for _ in p]
+        if isinstance(p[0], list):
+            raise NotImplementedError("per-tile prompts (:145-156) belong to the tiled sampler, not selected by the yaml")
+        batch["txt"] = [" ".join([_p, p_p]) for _p in p]
+        return self.conditioner.get_unconditional_conditioning(batch, batch_uc)
+
+    def _posterior_noise(self, shape):
+        return torch.randn(shape)
+
+    def _randn_like(self, t):
+        if self.noise_source == "cpu":
+            return torch.randn(t.shape).to(t.device)
+        return torch.randn_like(t)
+
+    # ---- the sampling loop (:200-298) ---------------------------------------------------------
+    @torch.no_grad()
+    def just_sampling(self, x, p, p_p="default", n_p="default", img_threshold=0.1, dec_img=1.0, num_steps=100,
+                      restoration_scale=4.0, s_churn=0, s_noise=1.003, cfg_scale=4.0, seed=-1, num_samples=1,
+                      control_scale=1, color_fix_type="None", use_linear_CFG=False, use_linear_control_scale=False,
+                      cfg_scale_start=1.0, control_scale_start=0.0, **kwargs):
+        assert len(x) == len(p)
+        assert color_fix_type in ["Wavelet", "AdaIn", "None"]
+        N = len(x)
+        if num_samples > 1:
+            assert N == 1
+            N = num_samples
+            x = x.repeat(N, 1, 1, 1)
+            p = p * N
+        if N > 1 and img_threshold > 0:
+            raise NotImplementedError("the feature cache decides per image; batch > 1 runs with img_threshold <= 0 "
+                                      "(the reference itself only ever samples one image, infer.py:172,199)")
+        p_p = self.p_p if p_p == "default" else p_p
+        n_p = self.n_p if n_p == "default" else n_p
+
+        sp = self.sampler_config.params
+        sp.num_steps = num_steps
+        sp.guider_config.params.scale_min = cfg_scale
+        sp.guider_config.params.scale = cfg_scale_start if use_linear_CFG else cfg_scale
+        sp.restore_cfg, sp.s_churn, sp.s_noise = restoration_scale, s_churn, s_noise
+        self.sampler = instantiate_from_config(self.sampler_config)
+
+        x = x.float().contiguous()
+        _z = self.encode_first_stage_with_denoise(x, use_sample=False)
+        x_stage1 = self.decode_first_stage(_z)
+        z_stage1 = self.encode_first_stage(x_stage1)
+        c_img, uc_img = self.prepare_condition(_z, p, p_p, n_p, N)
+
+        def denoiser(inp, sigma, c, *a, **kw):
+            return self.denoiser(self.model, inp, sigma, c, *a, **kw)
+
+        noised_z = self._randn_like(_z)
+        sampler = self.sampler
+        sampler.noise_fn = self._randn_like   # per-step churn draws follow the same generator choice
+        z, s_in, sigmas, num_sigmas, c_img, uc_img = sampler.init_loop(noised_z, c_img, uc=uc_img, num_steps=num_steps)
+        x_center_cur = z_stage1
+        with cache_context(MyCacheContext()):
+            for i in range(num_sigmas - 1):
+                z, img_threshold = sampler.step(z, i, s_in, sigmas, denoiser, c_img, uc_img, x_center=x_center_cur,
+                                                control_scale=control_scale,
+                                                use_linear_control_scale=use_linear_control_scale,
+                                                control_scale_start=control_scale_start, threshold=img_threshold)
+                x_center_cur = z
+                img_threshold = img_threshold * dec_img
+
+        samples = self.decode_first_stage(z)
+        if color_fix_type == "Wavelet":
+            samples = wavelet_reconstruction(samples, x_stage1)
+        elif color_fix_type == "AdaIn":
+            samples = adaptive_instance_normalization(samples, x_stage1)
+        return samples

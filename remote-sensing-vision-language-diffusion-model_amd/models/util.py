@@ -1,0 +1,77 @@
+"""Model factory + image <-> tensor helpers (reference: models/util.py:73-108,132-166)."""
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from ..sgm.util import AttrDict, instantiate_from_config
+
+
+def get_state_dict(d):
+    return d.get("state_dict", d)
+
+
+def load_state_dict(ckpt_path, location="cpu"):
+    _, ext = os.path.splitext(ckpt_path)
+    if ext.lower() == ".safetensors":
+        import safetensors.torch
+        sd = safetensors.torch.load_file(ckpt_path, device=location)
+    else:
+        sd = get_state_dict(torch.load(ckpt_path, map_location=torch.device(location)))
+    return get_state_dict(sd)
+
+
+def load_config(path):
+    with open(path, "r", encoding="utf-8") as f:
+        return AttrDict(yaml.safe_load(f))
+
+
+def create_SR_model(config_path, load_default_setting=False):
+    """yaml -> SR_backbone, then the two checkpoints (SDXL base, SR adapter) with strict=False, exactly
+    the order of models/util.py:93-108.  Missing checkpoint files are skipped (random init)."""
+    config = load_config(config_path)
+    model = instantiate_from_config(config.model).cpu()
+    for key in ("SR_CKPT", "SR_CKPT_Q"):
+        path = config.get(key)
+        if path is not None and os.path.exists(path):
+            model.load_state_dict(load_state_dict(path), strict=False)
+    if load_default_setting:
+        return model, config.default_setting
+    return model
+
+
+def PIL2Tensor(img, upscale=1, min_size=1024, fix_resize=None):
+    """PIL.Image -> Tensor[C,H,W] RGB in [-1,1]; sides rounded to multiples of 64 (util.py:132-156)."""
+    from PIL import Image
+    w, h = img.size
+    w *= upscale
+    h *= upscale
+    w0, h0 = round(w), round(h)
+    if min(w, h) < min_size:
+        s = min_size / min(w, h)
+        w *= s
+        h *= s
+    if fix_resize is not None:
+        s = fix_resize / min(w, h)
+        w *= s
+        h *= s
+        w0, h0 = round(w), round(h)
+    w = int(np.round(w / 64.0)) * 64
+    h = int(np.round(h / 64.0)) * 64
+    x = img.resize((w, h), Image.BICUBIC)
+    x = np.array(x).round().clip(0, 255).astype(np.uint8)
+    x = x / 255 * 2 - 1
+    return torch.tensor(x, dtype=torch.float32).permute(2, 0, 1), h0, w0
+
+
+def Tensor2PIL(x, h0, w0):
+    """Tensor[C,H,W] RGB in [-1,1] -> PIL.Image of size (w0, h0) (util.py:159-166)."""
+    from PIL import Image
+    x = torch.nn.functional.interpolate(x.unsqueeze(0).float().cpu(), size=(h0, w0), mode="bicubic")
+    x = (x.squeeze(0).permute(1, 2, 0) * 127.5 + 127.5).numpy().clip(0, 255).astype(np.uint8)
+    return Image.fromarray(x)
+
+
+def convert_dtype(dtype_str):
+    return {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[dtype_str]

@@ -193,7 +193,13 @@ def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0):
 
 # ----------------------------------------------------------------------------- norms
 def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None):
-    """GroupNorm(+SiLU) over NHWC ``x`` (or the channel concat [x | x2])."""
+    """GroupNorm(+SiLU) over NHWC ``x`` (or the channel concat [x | x2]).  ``mod_scale1p`` / ``mod_shift``
+    (ZeroSFT) may be channel slices of one stacked tensor: only their row stride must agree."""
+    mod_stride = 0
+    if mod_scale1p is not None:
+        mod_stride = mod_scale1p.stride(-2)
+        if mod_shift.stride(-2) != mod_stride or mod_scale1p.stride(-1) != 1 or mod_shift.stride(-1) != 1:
+            raise L.RsvldError("group_norm: modulation tensors must share a row stride and be channel-contiguous")
     _need_gpu(x, x2, gamma, beta)
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
@@ -203,8 +209,8 @@ def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=
     nbytes = 3 * y.numel() * y.element_size()  # stats read + apply read + write
     _launch("groupnorm(3 kernels)", 0.0, nbytes, lambda: L.check(
         lib.rsvld_groupnorm_nhwc(_ptr(x), _ptr(x2), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mod_scale1p),
-                                 _ptr(mod_shift), B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _ptr(ws),
-                                 _stream()), "rsvld_groupnorm_nhwc"))
+                                 _ptr(mod_shift), mod_stride, B, H * W, C1, C2, groups, eps, int(silu), _dt(x),
+                                 _ptr(ws), _stream()), "rsvld_groupnorm_nhwc"))
     return y
 
 
@@ -227,7 +233,7 @@ def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False)
     C2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((B, H, W, C1 + C2), device=x.device, dtype=x.dtype)
     L.check(L.load().rsvld_groupnorm_apply(_ptr(x), _ptr(x2), _ptr(y), _ptr(stats), _ptr(gamma), _ptr(beta), None,
-                                           None, B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _stream()),
+                                           None, 0, B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _stream()),
             "rsvld_groupnorm_apply")
     return y
 
@@ -288,8 +294,8 @@ def sinusoidal(t, dim, kind):
 
 
 # ----------------------------------------------------------------------------- layout / elementwise
-def nchw_to_nhwc(src, dtype, c_dst=None, c_off=0, out=None):
-    """fp32 NCHW -> 16-bit NHWC with channels padded to ``c_dst`` (default: next multiple of 8)."""
+def nchw_to_nhwc(src, dtype, c_dst=None, c_off=0, out=None, scale=1.0):
+    """fp32 NCHW (* scale) -> 16-bit NHWC with channels padded to ``c_dst`` (default: next multiple of 8)."""
     _need_gpu(src)
     B, Cc, H, W = src.shape
     src = src.contiguous().float()
@@ -299,7 +305,7 @@ def nchw_to_nhwc(src, dtype, c_dst=None, c_off=0, out=None):
         zero = 1
     else:
         c_dst, zero = out.shape[-1], 0
-    L.check(L.load().rsvld_nchw_f32_to_nhwc(_ptr(src), _ptr(out), B, Cc, H, W, c_dst, c_off, zero, _DT[out.dtype],
+    L.check(L.load().rsvld_nchw_f32_to_nhwc(_ptr(src), _ptr(out), B, Cc, H, W, c_dst, c_off, zero, scale, _DT[out.dtype],
                                             _stream()), "rsvld_nchw_f32_to_nhwc")
     return out
 
@@ -340,4 +346,101 @@ def ddpm_step(x, eps_nhwc, noise, c_recip, c_recipm1, coef1, coef2, sigma, clip=
     L.check(L.load().rsvld_ddpm_step(_ptr(x), _ptr(eps_nhwc), _ptr(noise), _ptr(out), B, Cc, H, W,
                                      eps_nhwc.shape[-1], c_recip, c_recipm1, coef1, coef2, sigma, int(clip),
                                      _stream()), "rsvld_ddpm_step")
+    return out
+
+
+# ----------------------------------------------------------------------------- Stage-2 sampler / cache / VAE posterior
+def denoiser_out(net_out_nhwc, inp, c_out, c_skip):
+    """fp32 NHWC network output -> fp32 NCHW ``net*c_out + input*c_skip`` (denoiser.py:77-78)."""
+    _need_gpu(net_out_nhwc, inp)
+    B, Cc, H, W = inp.shape
+    if net_out_nhwc.dtype != torch.float32 or tuple(net_out_nhwc.shape[:3]) != (B, H, W):
+        raise L.RsvldError("denoiser_out: network output must be fp32 NHWC matching the input")
+    out = torch.empty_like(inp)
+    L.check(L.load().rsvld_denoiser_out(_ptr(net_out_nhwc), _ptr(inp), _ptr(out), B, Cc, H, W, net_out_nhwc.shape[-1],
+                                        c_out, c_skip, _stream()), "rsvld_denoiser_out")
+    return out
+
+
+def lerp_f32(a, b, w):
+    _need_gpu(a, b)
+    if not (a.is_contiguous() and b.is_contiguous()):
+        raise L.RsvldError("lerp_f32: contiguous fp32 tensors expected")
+    out = torch.empty_like(a)
+    L.check(L.load().rsvld_lerp_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), w, _stream()), "rsvld_lerp_f32")
+    return out
+
+
+def axpy_f32(x, y, s):
+    """x + s*y on fp32 tensors; ``x=None`` gives s*y."""
+    _need_gpu(x, y)
+    out = torch.empty_like(y)
+    L.check(L.load().rsvld_axpy_f32(_ptr(x), _ptr(y), _ptr(out), y.numel(), s, _stream()), "rsvld_axpy_f32")
+    return out
+
+
+def euler_step(x_hat, denoised, x_center, restore_w, sigma_hat, dt):
+    _need_gpu(x_hat, denoised, x_center)
+    out = torch.empty_like(x_hat)
+    L.check(L.load().rsvld_euler_step(_ptr(x_hat), _ptr(denoised), _ptr(x_center), _ptr(out), x_hat.numel(),
+                                      restore_w, sigma_hat, dt, _stream()), "rsvld_euler_step")
+    return out
+
+
+def absdiff_sums(a, b):
+    """Per batch row: fp32 ``[rows, 2]`` = (sum|a-b|, sum|a|)  (DFBCache.py:98-112)."""
+    _need_gpu(a, b)
+    rows = a.shape[0]
+    n = a.numel() // rows
+    lib = L.load()
+    ws = torch.empty(lib.rsvld_absdiff_ws_bytes(rows, n), device=a.device, dtype=torch.uint8)
+    out = torch.empty((rows, 2), device=a.device, dtype=torch.float32)
+    L.check(lib.rsvld_absdiff_sums(_ptr(a), _ptr(b), _ptr(out), rows, n, _dt(a), _ptr(ws), _stream()),
+            "rsvld_absdiff_sums")
+    return out
+
+
+def gaussian_sample(moments, channels, noise, scale):
+    """NHWC moments (16-bit or fp32) -> fp32 NCHW z; ``noise=None`` gives mode()."""
+    _need_gpu(moments, noise)
+    B, H, W, mc = moments.shape
+    z = torch.empty((B, channels, H, W), device=moments.device, dtype=torch.float32)
+    f32 = moments.dtype == torch.float32
+    L.check(L.load().rsvld_gaussian_sample(_ptr(moments), _ptr(noise), _ptr(z), B, channels, H, W, mc, scale, int(f32),
+                                           0 if f32 else _dt(moments), _stream()), "rsvld_gaussian_sample")
+    return z
+
+
+def wavelet_blur(img, radius, high_accum=None):
+    _need_gpu(img, high_accum)
+    B, Cc, H, W = img.shape
+    low = torch.empty_like(img)
+    L.check(L.load().rsvld_wavelet_blur(_ptr(img), _ptr(low), _ptr(high_accum), B * Cc, H, W, radius, _stream()),
+            "rsvld_wavelet_blur")
+    return low
+
+
+def add_f32(a, b):
+    _need_gpu(a, b)
+    out = torch.empty_like(a)
+    L.check(L.load().rsvld_add_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "rsvld_add_f32")
+    return out
+
+
+def adain(content, style):
+    _need_gpu(content, style)
+    B, Cc, H, W = content.shape
+    out = torch.empty_like(content)
+    ws = torch.empty(4 * B * Cc, device=content.device, dtype=torch.float32)
+    L.check(L.load().rsvld_adain(_ptr(content), _ptr(style), _ptr(out), _ptr(ws), B * Cc, H * W, _stream()),
+            "rsvld_adain")
+    return out
+
+
+def concat_c(a, b):
+    _need_gpu(a, b)
+    rows = a.numel() // a.shape[-1]
+    out = torch.empty((*a.shape[:-1], a.shape[-1] + b.shape[-1]), device=a.device, dtype=a.dtype)
+    L.check(L.load().rsvld_concat_c(_ptr(a), _ptr(b), _ptr(out), rows, a.shape[-1], b.shape[-1], _dt(a), _stream()),
+            "rsvld_concat_c")
     return out

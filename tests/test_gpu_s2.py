@@ -1,0 +1,206 @@
+"""Stage-2 parity on the GPU: the HIP path against (i) golden vectors produced by the reference itself and
+(ii) the CPU oracle.  Compute types: UNet/ControlNet fp16 storage + fp32 accumulate (the reference's
+autocast-fp16 policy), VAE bf16 (reference: ae_dtype bf16); goldens/oracle are fp32.  Tolerances are
+stated per test, relative to each tensor's range."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import s2_common as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(cuda):
+    from oracle import seeded
+    from rsvld_amd.sgm.util import instantiate_from_config
+    m = instantiate_from_config({"target": "rsvld_amd.models.SR_model.SR_backbone", "params": S.product_params()})
+    seeded.seed_module(m, S.WEIGHT_SEED)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m.to(cuda).eval(), sd
+
+
+def _cmp(got_nchw, want, rel, name):
+    want = torch.as_tensor(want).float()
+    got = got_nchw.float().cpu()
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    print(f"{name}: max|d| = {err:.3e} (range {scale:.2f})")
+    assert err <= rel * scale + 1e-5, f"{name}: {err:.3e} > {rel} x {scale:.3e}"
+    return err
+
+
+def _h(t, cuda, dt=torch.float16):
+    from rsvld_amd import ops
+    return ops.nchw_to_nhwc(t.to(cuda), dt)
+
+
+def _n(t, channels=None):
+    from rsvld_amd import ops
+    return ops.nhwc_to_nchw(t.contiguous(), channels=channels)
+
+
+def test_ops_vs_reference_golden(model, cuda, golden_dir):
+    """ResBlock / SpatialTransformer / Down / Up / ZeroSFT (3 variants) / ZeroCrossAttn (2) / embedding.
+    Tolerance 6e-3 x range (fp16 operands through 2-20 layers)."""
+    from rsvld_amd import ops
+    m, _ = model
+    unet = m.model.diffusion_model
+    unet.compute_dtype = torch.float16
+    z = np.load(os.path.join(golden_dir, "s2_networks.npz"))
+    emb, ctx = S.rnd((2, 1280), 50, 0.5).to(cuda), S.rnd((2, 77, 64), 51).to(cuda, torch.float16)
+    rows = unet.emb_rows(emb)
+    x320, x640, x1280 = S.rnd((2, 320, 8, 8), 52), S.rnd((2, 640, 4, 4), 53), S.rnd((2, 1280, 4, 4), 54)
+    pm = unet.project_modules
+    R = 6e-3
+    _cmp(_n(unet.input_blocks[1][0].run(unet, _h(x320, cuda), rows)), z["op.res_320"], R, "res_320")
+    _cmp(_n(unet.input_blocks[4][0].run(unet, _h(S.rnd((2, 320, 4, 4), 55), cuda), rows)), z["op.res_320_640"], R, "res_320_640")
+    _cmp(_n(unet.input_blocks[4][1].run(unet, _h(x640, cuda), ctx)), z["op.st_640"], R, "st_640")
+    _cmp(_n(unet.input_blocks[7][1].run(unet, _h(x1280, cuda), ctx)), z["op.st_1280"], R, "st_1280")
+    _cmp(_n(unet.input_blocks[3][0].run(unet, _h(x320, cuda))), z["op.down_320"], R, "down_320")
+    _cmp(_n(unet.output_blocks[2][2].run(unet, _h(x1280, cuda))), z["op.up_1280"], R, "up_1280")
+    _cmp(_n(pm[11].run(unet, _h(x1280, cuda), _h(S.rnd((2, 1280, 4, 4), 56), cuda))), z["op.sft_mid"], R, "sft_mid")
+    _cmp(_n(pm[10].run(unet, _h(x1280, cuda), _h(S.rnd((2, 1280, 4, 4), 57), cuda), _h(S.rnd((2, 1280, 4, 4), 58), cuda))),
+         z["op.sft_cat"], R, "sft_cat")
+    _cmp(_n(pm[0].run(unet, _h(x320, cuda), _h(S.rnd((2, 320, 8, 8), 59), cuda), _h(S.rnd((2, 320, 8, 8), 60), cuda), 0.7)),
+         z["op.sft_cat_cs"], R, "sft_cat_cs")
+    _cmp(_n(pm[7].run(unet, _h(x640, cuda), _h(x1280, cuda))), z["op.zca_7"], R, "zca_7")
+    _cmp(_n(pm[3].run(unet, _h(x320, cuda), _h(S.rnd((2, 640, 8, 8), 61), cuda), 0.9)), z["op.zca_3"], R, "zca_3")
+    t, y = torch.tensor([999.0, 19.0]).to(cuda), S.rnd((2, 32), 62).to(cuda)
+    got = unet.embed(t, y).cpu()
+    assert float((got - torch.tensor(z["op.emb"])).abs().max()) < 2e-3   # sin/cos of t*f up to 999 rad in fp32
+
+
+def test_networks_vs_reference_golden(model, cuda, golden_dir):
+    """Whole ControlNet + UNet forward (CFG pair, L = 16), and the cache split: none == stage1 o stage2."""
+    m, _ = model
+    z = np.load(os.path.join(golden_dir, "s2_networks.npz"))
+    t, y, ctx = torch.tensor([999.0, 19.0]).to(cuda), S.rnd((2, 32), 62).to(cuda), S.rnd((2, 77, 64), 51).to(cuda)
+    xt, xc = S.rnd((2, 4, 16, 16), 70).to(cuda), S.rnd((2, 4, 16, 16), 71, 0.5).to(cuda)
+    c = {"crossattn": ctx, "vector": y, "control": xc}
+    w = m.model
+    part = w(xt, t, c, 1.0, "input_stage1", None)
+    _cmp(_n(part["control"][9]), z["control.9"], 1e-2, "control[9]")
+    _cmp(_n(part["h"]), z["unet.h"], 1e-2, "unet stage-1 h (cache key)")
+    two = w(xt, t, c, 1.0, "input_stage2", part)
+    full = w(xt, t, c, 1.0, "none", None)
+    assert torch.equal(full, two), "none != stage1 o stage2 (must be bit-identical, SURVEY.md App. B)"
+    _cmp(_n(full, 4), z["unet.out"], 1.5e-2, "unet eps")
+    _cmp(_n(w(xt, t, c, 0.8, "none", None), 4), z["unet.out_cs08"], 1.5e-2, "unet eps, control_scale 0.8")
+
+
+def test_denoiser_and_guider_vs_oracle(model, cuda):
+    from oracle import s2_oracle as O
+    m, sd = model
+    table = O.legacy_ddpm_sigmas(1000, append_zero=False, flip=True)
+    x = S.rnd((1, 4, 16, 16), 90) * 5.0
+    zc = S.rnd((1, 4, 16, 16), 91, 0.5)
+    cd, ucd = S.cond_dicts()
+    c = {**cd, "control": zc}
+    uc = {**ucd, "control": zc}
+    sigma = torch.tensor([7.3])
+    want = O.linear_cfg(O.denoiser(sd, table, *O.cfg_inputs(x, sigma, c, uc), 1.0), sigma, 4.0, 7.5)
+    from rsvld_amd.sgm.modules.diffusionmodules.guiders import LinearCFG
+    g = LinearCFG(scale=4.0, scale_min=7.5)
+    dev = lambda d: {k: v.to(cuda) for k, v in d.items()}
+    inp = g.prepare_inputs(x.to(cuda), sigma, dev(c), dev(uc))
+    got = g(m.denoiser(m.model, *inp, control_scale=1.0, fbcache_mode="none", partial_info=None), sigma)
+    _cmp(got, want, 1.5e-2, "guided x0 prediction at sigma 7.3")
+
+
+def test_vae_and_colorfix_vs_reference_golden(model, cuda, golden_dir):
+    """VAE in bf16 (8-bit mantissa) vs fp32 goldens: 4e-2 x range; posterior/colour-fix kernels are fp32: 1e-5."""
+    from oracle import seeded
+    from rsvld_amd import ops
+    from rsvld_amd.utils import colorfix
+    m, _ = model
+    z = np.load(os.path.join(golden_dir, "s2_vae_colorfix.npz"))
+    img = seeded.synthetic_image((1, 3, 64, 64), seed=80, smooth=3).to(cuda)
+    fs = m.first_stage_model
+    _cmp(_n(fs.moments(img)), z["moments"], 4e-2, "VAE moments (bf16)")
+    _cmp(m.decode_first_stage(S.rnd((1, 4, 8, 8), 81).to(cuda)), z["decoded"], 4e-2, "VAE decode (bf16)")
+    _cmp(m.encode_first_stage_with_denoise(img, use_sample=False), z["z_denoise"], 4e-2, "denoise-encoder mode")
+    fs.set_compute_dtype(torch.float16)
+    _cmp(_n(fs.moments(img)), z["moments"], 6e-3, "VAE moments (fp16)")
+    _cmp(m.decode_first_stage(S.rnd((1, 4, 8, 8), 81).to(cuda)), z["decoded"], 6e-3, "VAE decode (fp16)")
+    fs.set_compute_dtype(torch.bfloat16)
+    a, b = S.rnd((2, 3, 48, 40), 82).to(cuda), (S.rnd((2, 3, 48, 40), 83, 0.5) + 0.2).to(cuda)
+    _cmp(colorfix.wavelet_reconstruction(a, b), z["wavelet"], 1e-6, "wavelet_reconstruction")
+    _cmp(colorfix.adaptive_instance_normalization(a, b), z["adain"], 1e-5, "AdaIN")
+    # posterior sample with an injected draw
+    mom = torch.tensor(z["moments"]).permute(0, 2, 3, 1).contiguous().to(cuda)
+    noise = S.rnd((1, 4, 8, 8), 84)
+    want = (torch.tensor(z["moments"])[:, :4] + torch.exp(0.5 * torch.tensor(z["moments"])[:, 4:].clamp(-30, 20)) * noise) * 0.13025
+    _cmp(ops.gaussian_sample(mom, 4, noise.to(cuda), 0.13025), want, 1e-6, "posterior sample")
+
+
+@pytest.mark.parametrize("tag", ["nocache", "cache"])
+def test_just_sampling_vs_reference_golden(model, cuda, golden_dir, tag):
+    """The whole Stage-2 pipeline with the reference's RNG order (CPU generator), 6 steps.  The cache trace
+    (hit/miss per step and the diff that replaces the threshold) must reproduce the reference's decisions."""
+    from oracle import seeded
+    import rsvld_amd.sgm.modules.diffusionmodules.sampling as RS
+    m, _ = model
+    z = np.load(os.path.join(golden_dir, "s2_pipeline.npz"))
+    img = seeded.synthetic_image((1, 3, 64, 64), seed=80, smooth=3).to(cuda)
+    opt = S.PIPE_OPT
+    trace, orig = [], RS.get_can_use_cache_multi
+
+    def spy(first, threshold, parallelized=False):
+        use, d = orig(first, threshold=threshold, parallelized=parallelized)
+        trace.append((float(threshold), float(d), bool(use)))
+        return use, d
+
+    RS.get_can_use_cache_multi = spy
+    try:
+        m.noise_source = "cpu"
+        m.first_stage_model.set_compute_dtype(torch.float16 if os.environ.get("RSVLD_VAE_FP16") else torch.bfloat16)
+        torch.manual_seed(7)
+        thr = opt["img_threshold"] if tag == "cache" else 0.0
+        out = m.just_sampling(img, [""], p_p="", n_p="", img_threshold=thr, dec_img=opt["dec_img"], num_steps=opt["num_steps"],
+                              restoration_scale=opt["restoration_scale"], s_churn=opt["s_churn"], s_noise=opt["s_noise"],
+                              cfg_scale=opt["cfg_scale"], control_scale=opt["control_scale"], color_fix_type=opt["color_fix_type"],
+                              use_linear_CFG=opt["use_linear_CFG"], cfg_scale_start=opt["cfg_scale_start"])
+    finally:
+        RS.get_can_use_cache_multi = orig
+        m.noise_source = "device"
+    want = torch.tensor(z[f"{tag}.final"])
+    d = (out.cpu() - want).abs()
+    print(f"just_sampling[{tag}]: max|d| = {float(d.max()):.3e}, mean|d| = {float(d.mean()):.3e} (range {float(want.abs().max()):.2f})")
+    print("   cache trace:", [(round(a, 4), round(b, 4), h) for a, b, h in trace])
+    wt = z[f"{tag}.trace"]
+    assert len(trace) == len(wt)
+    for (a, b, h), w in zip(trace, wt):
+        assert bool(w[2]) == h, "cache decision flipped vs the reference"
+        assert abs(b - w[1]) < 2e-2 * max(1.0, w[1])
+    assert float(d.mean()) < 2e-2 and float(d.max()) < 0.25
+
+
+def test_batched_sampling_is_per_image(model, cuda):
+    """Images are independent units: a batch of 2 gives the same images as two batches of 1
+    when each image sees the same noise."""
+    from oracle import seeded
+    m, _ = model
+    imgs = torch.cat([seeded.synthetic_image((1, 3, 64, 64), seed=s, smooth=3) for s in (80, 81)]).to(cuda)
+    kw = dict(p_p="", n_p="", img_threshold=0.0, num_steps=3, restoration_scale=-1, s_churn=0, cfg_scale=5.0,
+              color_fix_type="None")
+    n_post, n_xt = S.rnd((2, 4, 8, 8), 95), S.rnd((2, 4, 8, 8), 96)
+
+    def run(x, sl):
+        m._posterior_noise = lambda shape: n_post[sl]
+        m._randn_like = lambda t: n_xt[sl].to(t.device)
+        try:
+            return m.just_sampling(x, [""] * x.shape[0], **kw)
+        finally:
+            del m._posterior_noise, m._randn_like
+
+    both = run(imgs, slice(0, 2))
+    one = torch.cat([run(imgs[i:i + 1], slice(i, i + 1)) for i in range(2)])
+    d = float((both - one).abs().max())
+    print("batch-of-2 vs 2 x batch-of-1: max|d| =", d)
+    assert d < 2e-2

@@ -1,0 +1,123 @@
+"""CPU: the Stage-2 oracle (oracle/s2_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/gen_s2_golden.py), plus host-side logic of the product (schedules, sigma quantisation,
+CFG schedule, parameter-name contract, yaml plugin registry)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import s2_common as S
+from oracle import s2_oracle as O
+from oracle import seeded
+
+
+@pytest.fixture(scope="module")
+def model():
+    from rsvld_amd.sgm.util import instantiate_from_config
+    m = instantiate_from_config({"target": "rsvld_amd.models.SR_model.SR_backbone", "params": S.product_params()})
+    seeded.seed_module(m, S.WEIGHT_SEED)
+    return m.eval(), {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def _d(a, b):
+    return float((torch.as_tensor(a).float() - torch.as_tensor(b).float()).abs().max())
+
+
+def test_parameter_contract_and_plugin_registry(model, golden_dir):
+    m, sd = model
+    want = json.load(open(os.path.join(golden_dir, "s2_param_names.json")))
+    assert [[k, list(v.shape)] for k, v in sd.items()] == want   # names, shapes AND order of the reference
+    from rsvld_amd.models.modules.SR_modules import GLVControl, LightGLVUNet
+    from rsvld_amd.sgm.modules.diffusionmodules.denoiser import DiscreteDenoiserWithControl
+    from rsvld_amd.sgm.modules.diffusionmodules.wrappers import ControlWrapper
+    assert isinstance(m.model, ControlWrapper) and isinstance(m.model.diffusion_model, LightGLVUNet)
+    assert isinstance(m.model.control_model, GLVControl) and isinstance(m.denoiser, DiscreteDenoiserWithControl)
+    assert m.model.dtype == torch.float16 and m.ae_dtype == torch.bfloat16
+
+
+def test_schedules_oracle_and_product(model, golden_dir):
+    m, _ = model
+    z = np.load(os.path.join(golden_dir, "s2_schedules.npz"))
+    from rsvld_amd.sgm.modules.diffusionmodules.discretizer import LegacyDDPMDiscretization
+    from rsvld_amd.sgm.modules.diffusionmodules.guiders import LinearCFG
+    disc = LegacyDDPMDiscretization()
+    for n in (6, 50):
+        assert np.array_equal(O.legacy_ddpm_sigmas(n).numpy(), z[f"sigmas{n}"])
+        assert np.array_equal(disc(n, device="cpu").numpy(), z[f"sigmas{n}"])
+    assert np.array_equal(m.denoiser.sigmas.numpy(), z["table"])
+    assert np.array_equal(m.denoiser.sigma_to_idx(torch.tensor(z["probe"])).numpy(), z["probe_idx"])
+    assert np.array_equal(O.quantize_sigma(torch.tensor(z["probe"]), torch.tensor(z["table"]))[1].numpy(), z["probe_idx"])
+    got = LinearCFG(scale=4.0, scale_min=7.5).scale_schedule(torch.tensor(z["sigmas50"])).numpy()
+    assert np.array_equal(got, z["cfg_scale"])
+
+
+def test_oracle_ops(model, golden_dir):
+    _, sd = model
+    z = np.load(os.path.join(golden_dir, "s2_networks.npz"))
+    P = "model.diffusion_model."
+    emb, ctx = S.rnd((2, 1280), 50, 0.5), S.rnd((2, 77, 64), 51)
+    x320, x640, x1280 = S.rnd((2, 320, 8, 8), 52), S.rnd((2, 640, 4, 4), 53), S.rnd((2, 1280, 4, 4), 54)
+    got = {
+        "res_320": O.resblock(sd, P + "input_blocks.1.0", x320, emb),
+        "res_320_640": O.resblock(sd, P + "input_blocks.4.0", S.rnd((2, 320, 4, 4), 55), emb),
+        "st_640": O.spatial_transformer(sd, P + "input_blocks.4.1", x640, ctx),
+        "st_1280": O.spatial_transformer(sd, P + "input_blocks.7.1", x1280, ctx),
+        "sft_mid": O.zero_sft(sd, P + "project_modules.11", x1280, S.rnd((2, 1280, 4, 4), 56)),
+        "sft_cat": O.zero_sft(sd, P + "project_modules.10", x1280, S.rnd((2, 1280, 4, 4), 57), S.rnd((2, 1280, 4, 4), 58)),
+        "sft_cat_cs": O.zero_sft(sd, P + "project_modules.0", x320, S.rnd((2, 320, 8, 8), 59), S.rnd((2, 320, 8, 8), 60), 0.7),
+        "zca_7": O.zero_cross_attn(sd, P + "project_modules.7", x640, x1280),
+        "zca_3": O.zero_cross_attn(sd, P + "project_modules.3", x320, S.rnd((2, 640, 8, 8), 61), 0.9),
+    }
+    for k, v in got.items():
+        assert _d(v, z["op." + k]) < 5e-5, k
+    t, y = torch.tensor([999.0, 19.0]), S.rnd((2, 32), 62)
+    assert _d(O.embed(sd, P, t, y), z["op.emb"]) < 1e-5
+
+
+def test_oracle_networks(model, golden_dir):
+    _, sd = model
+    z = np.load(os.path.join(golden_dir, "s2_networks.npz"))
+    t, y, ctx = torch.tensor([999.0, 19.0]), S.rnd((2, 32), 62), S.rnd((2, 77, 64), 51)
+    xt, xc = S.rnd((2, 4, 16, 16), 70), S.rnd((2, 4, 16, 16), 71, 0.5)
+    control = O.glv_control(sd, xc, t, xt, ctx, y)
+    assert _d(control[9], z["control.9"]) < 2e-4
+    part = O.light_unet_stage1(sd, xt, t, ctx, y)
+    assert _d(part["h"], z["unet.h"]) < 2e-4
+    assert _d(O.light_unet_stage2(sd, part, ctx, control, 1.0), z["unet.out"]) < 5e-5
+    assert _d(O.light_unet(sd, xt, t, ctx, y, control, 0.8), z["unet.out_cs08"]) < 5e-5
+
+
+def test_oracle_vae_colorfix(model, golden_dir):
+    _, sd = model
+    z = np.load(os.path.join(golden_dir, "s2_vae_colorfix.npz"))
+    img = seeded.synthetic_image((1, 3, 64, 64), seed=80, smooth=3)
+    assert _d(O.conv(sd, "first_stage_model.quant_conv", O.vae_encoder(sd, img)), z["moments"]) < 5e-5
+    assert _d(O.decode(sd, S.rnd((1, 4, 8, 8), 81)), z["decoded"]) < 5e-5
+    assert _d(O.encode_with_denoise(sd, img), z["z_denoise"]) < 1e-5
+    torch.manual_seed(5)
+    assert _d(O.encode_sample(sd, img, torch.randn(1, 4, 8, 8)), z["z_sample_seed5"]) < 1e-5
+    a, b = S.rnd((2, 3, 48, 40), 82), S.rnd((2, 3, 48, 40), 83, 0.5) + 0.2
+    assert _d(O.wavelet_reconstruction(a, b), z["wavelet"]) < 1e-6
+    assert _d(O.adain(a, b), z["adain"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["cache", "nocache"])
+def test_oracle_pipeline(model, golden_dir, tag):
+    """just_sampling end to end (VAE x4, conditioner, 6 sampler steps, cache decisions, wavelet fix)."""
+    _, sd = model
+    z = np.load(os.path.join(golden_dir, "s2_pipeline.npz"))
+    img = seeded.synthetic_image((1, 3, 64, 64), seed=80, smooth=3)
+    c, uc = S.cond_dicts()
+    trace = []
+    torch.manual_seed(7)
+    thr = S.PIPE_OPT["img_threshold"] if tag == "cache" else 0.0
+    out = O.just_sampling(sd, img, c, uc, dict(S.PIPE_OPT, img_threshold=thr), trace=trace)
+    assert _d(out, z[f"{tag}.final"]) < 1e-4
+    want = z[f"{tag}.trace"]
+    assert len(trace) == len(want)
+    for (a, b, h), w in zip(trace, want):
+        assert bool(w[2]) == h and abs(a - w[0]) < 1e-4 and abs(b - w[1]) < 1e-3
