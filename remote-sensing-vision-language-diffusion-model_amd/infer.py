@@ -1,0 +1,149 @@
+"""Pipeline driver with the reference's CLI (infer.py:218-240) and stage order (:206-215):
+Stage 1 SR3 upscale -> uint8 hand-off -> [caption] -> Stage 2 refinement -> PNG.
+
+    python -m rsvld_amd.infer --input_img in.png --output_dir results --upscale_factor 8 --seed 42 \
+        --img_threshold 0.3 --edm_steps 50 [--no_llava] [--caption "..."] [--sr3_steps 50]
+
+Both diffusion stages run on ONE MI355X through librsvld_hip.so.  The LLaVA-Next captioner stays on stock
+PyTorch-ROCm and is optional here (``--caption`` supplies the text, empty = prompt-free like ``no_llava``);
+loading it needs network access for the checkpoints, which this build does not assume."""
+import argparse
+from dataclasses import dataclass
+from pathlib import Path
+
+import torch
+from PIL import Image
+
+from .configs import sr3 as SR3
+from .data import dataset as SR_Dataset
+from .models.util import PIL2Tensor, Tensor2PIL, create_SR_model
+from .sr3_model import create_model
+from .utils import logger as Logger
+from .utils import tensor2img as T2I
+
+_HERE = Path(__file__).resolve().parent
+
+
+@dataclass
+class PipelineConfig:
+    """Field-for-field the reference's PipelineConfig (infer.py:21-69) minus the LLaVA device."""
+    input_img: str
+    output_dir: str = "./results"
+    model_yaml: str = str(_HERE / "model_configs" / "juggernautXL.yaml")
+    sr_model_device: str = "cuda:0"
+    upscale_factor: int = 8
+    a_prompt: str = ("Cinematic, High Contrast, highly detailed aerial photo taken using a high-resolution drone or satellite, "
+                     "hyper detailed photo-realistic maximum detail, 32k, Color Grading, ultra HD, "
+                     "extreme meticulous detailing of terrain textures and structures, hyper sharpness, no deformations.")
+    n_prompt: str = ("painting, oil painting, illustration, drawing, art, sketch, oil painting, cartoon, CG Style, "
+                     "3D render, unreal engine, blurring, dirty, messy, worst quality, low quality, frames, watermark, "
+                     "signature, jpeg artifacts, deformed, lowres, over-smooth, cloud cover, heavy fog, motion blur, lens flare")
+    min_size: int = 1024
+    edm_steps: int = 50
+    s_churn: int = 5
+    s_noise: float = 1.003
+    s_cfg: float = 7.5
+    s_stage1: int = -1
+    s_stage2: float = 1.0
+    img_threshold: float = 0.3
+    seed: int = -1
+    num_samples: int = 1
+    color_fix_type: str = "Wavelet"
+    linear_cfg: bool = True
+    linear_s_stage2: bool = False
+    spt_linear_cfg: float = 4.0
+    spt_linear_s_stage2: float = 0.0
+    ae_dtype: str = "bf16"
+    diff_dtype: str = "fp16"
+    no_llava: bool = True
+    caption: str = ""
+    use_tile_vae: bool = False
+    encoder_tile_size: int = 512
+    decoder_tile_size: int = 64
+    sr3_steps: int = 0            # 0 = the option file's 'val' schedule (500 steps, configs/sr_sr3.json)
+
+    def __post_init__(self):
+        self.output_dir = Path(self.output_dir)
+        self.output_dir.mkdir(parents=True, exist_ok=True)
+        self.input_path = Path(self.input_img)
+        self.filename = self.input_path.stem
+
+
+class SuperResolutionPipeline:
+    def __init__(self, cfg: PipelineConfig):
+        self.cfg = cfg
+        if cfg.seed >= 0:
+            torch.manual_seed(cfg.seed)
+        self._load_sr3_model()
+        self._load_refinement_model()
+
+    def _load_sr3_model(self):
+        opt = Logger.parse(SR3.SR3_Config())
+        self.sr3_model = create_model(opt)
+        sched = dict(opt["model"]["beta_schedule"]["val"])
+        if self.cfg.sr3_steps > 0:
+            sched["n_timestep"] = self.cfg.sr3_steps
+        self.sr3_model.set_new_noise_schedule(sched, schedule_phase="val")
+
+    def _load_refinement_model(self):
+        self.refinement_model = create_SR_model(self.cfg.model_yaml)
+        self.refinement_model.to(self.cfg.sr_model_device)
+        if self.cfg.use_tile_vae:
+            self.refinement_model.init_tile_vae(self.cfg.encoder_tile_size, self.cfg.decoder_tile_size)
+
+    def run_stage1_sr3_upscale(self, image_path: Path) -> Image.Image:
+        val_data = SR_Dataset.load_sr_input(str(image_path), self.cfg.upscale_factor)
+        self.sr3_model.feed_data(val_data)
+        self.sr3_model.test(continous=True)
+        sr = self.sr3_model.SR
+        if sr.dim() == 4:
+            sr = sr[-1]
+        sr_pil = Image.fromarray(T2I.tensor2img(sr, min_max=(-1, 1)))      # 8-bit hand-off, as the reference
+        sr_pil.save(self.cfg.output_dir / f"sr3_{self.cfg.filename}.png")
+        return sr_pil
+
+    def run_stage2_captioning(self, sr_image) -> str:
+        return "" if self.cfg.no_llava else self.cfg.caption
+
+    def run_stage3_refinement(self, sr_image, caption: str):
+        lq, h0, w0 = PIL2Tensor(sr_image, upscale=1, min_size=self.cfg.min_size)
+        lq = lq.unsqueeze(0).to(self.cfg.sr_model_device)[:, :3]
+        c = self.cfg
+        samples = self.refinement_model.just_sampling(
+            lq, [caption], num_steps=c.edm_steps, restoration_scale=c.s_stage1, s_churn=c.s_churn, s_noise=c.s_noise,
+            cfg_scale=c.s_cfg, control_scale=c.s_stage2, seed=c.seed, num_samples=c.num_samples, p_p=c.a_prompt,
+            n_p=c.n_prompt, color_fix_type=c.color_fix_type, use_linear_CFG=c.linear_cfg,
+            use_linear_control_scale=c.linear_s_stage2, cfg_scale_start=c.spt_linear_cfg,
+            control_scale_start=c.spt_linear_s_stage2, img_threshold=c.img_threshold, dec_img=1)
+        outs = []
+        for i, s in enumerate(samples):
+            path = c.output_dir / f"{c.filename}_final_{i}.png"
+            Tensor2PIL(s, h0, w0).save(path)
+            outs.append(path)
+        return outs
+
+    def process(self):
+        sr3 = self.run_stage1_sr3_upscale(self.cfg.input_path)
+        return self.run_stage3_refinement(sr3, self.run_stage2_captioning(sr3))
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description="MI355X-native two-stage super-resolution pipeline")
+    p.add_argument("--input_img", type=str, required=True)
+    p.add_argument("--output_dir", type=str, default="./results")
+    p.add_argument("--upscale_factor", type=int, default=8)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--img_threshold", type=float, default=0.3)
+    p.add_argument("--edm_steps", type=int, default=50)
+    p.add_argument("--sr3_steps", type=int, default=0)
+    p.add_argument("--caption", type=str, default="")
+    p.add_argument("--use_tile_vae", action="store_true")
+    a = p.parse_args(argv)
+    cfg = PipelineConfig(input_img=a.input_img, output_dir=a.output_dir, upscale_factor=a.upscale_factor, seed=a.seed,
+                         img_threshold=a.img_threshold, edm_steps=a.edm_steps, sr3_steps=a.sr3_steps, caption=a.caption,
+                         no_llava=(a.caption == ""), use_tile_vae=a.use_tile_vae)
+    SuperResolutionPipeline(cfg).process()
+
+
+if __name__ == "__main__":
+    main()

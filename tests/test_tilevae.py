@@ -1,0 +1,109 @@
+"""Tiled VAE: integer tile geometry and cross-tile GroupNorm merge (CPU), oracle vs the reference VAEHook's
+goldens (CPU), and the HIP VAEHook vs the same goldens (GPU)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import s2_common as S
+from oracle import seeded
+from oracle import tilevae_oracle as TO
+
+
+def _build():
+    import yaml
+    from rsvld_amd.sgm.models.autoencoder import AutoencoderKLInferenceWrapper
+    cfg = yaml.safe_load(open(S.YAML))["model"]["params"]["first_stage_config"]["params"]
+    fs = AutoencoderKLInferenceWrapper(**cfg).eval()
+    seeded.seed_module(fs, S.WEIGHT_SEED + 1)
+    return fs, {"first_stage_model." + k: v.detach().clone() for k, v in fs.state_dict().items()}
+
+
+def test_tile_geometry_matches_reference(golden_dir):
+    from rsvld_amd.utils import tilevae as TV
+    geo = json.load(open(os.path.join(golden_dir, "tilevae_geometry.json")))
+    assert len(geo) == 7
+    for key, want in geo.items():
+        hw, t, kind = key.split("_")
+        h, w = (int(v) for v in hw.split("x"))
+        dec = kind == "dec"
+        for fn in (TV.split_tiles, TO.split_tiles):
+            ins, outs = fn(h, w, int(t[1:]), 11 if dec else 32, dec)
+            assert ins == want["in"] and outs == want["out"], key       # bit-exact integer bboxes
+    # crop margins tile the output exactly once
+    ins, outs = TV.split_tiles(512, 512, 64, 11, True)
+    cover = np.zeros((4096, 4096), dtype=np.int32)
+    for ib, ob in zip(ins, outs):
+        m = TV.crop_margins(ib, ob, True)
+        th, tw = (ib[3] - ib[2]) * 8, (ib[1] - ib[0]) * 8
+        assert (th + m[3]) - m[2] == ob[3] - ob[2] and (tw + m[1]) - m[0] == ob[1] - ob[0]
+        cover[ob[2]:ob[3], ob[0]:ob[1]] += 1
+    assert cover.min() == 1 and cover.max() == 1
+
+
+def test_merge_stats_is_reference_summary(golden_dir):
+    """pixel-weighted mean of per-tile means AND variances (tilevae.py:629-648), not the pooled variance."""
+    from rsvld_amd.utils.tilevae import merge_stats
+    z = np.load(os.path.join(golden_dir, "tilevae_golden.npz"))
+    tiles = [S.rnd((2, 64, 12, 10), 1), S.rnd((2, 64, 12, 7), 2, 2.0) + 0.5, S.rnd((2, 64, 5, 10), 3, 0.3)]
+    stats = []
+    for t in tiles:
+        v, m = TO.var_mean(t)
+        stats.append(torch.stack([m.view(2, 32), v.view(2, 32)], -1))
+    merged = merge_stats(stats, [t.shape[2] * t.shape[3] for t in tiles])
+    w, b = S.rnd((64,), 4) * 0.1 + 1, S.rnd((64,), 5) * 0.1
+    x = tiles[1]
+    mean = merged[..., 0].repeat_interleave(2, 1)[:, :, None, None]
+    var = merged[..., 1].repeat_interleave(2, 1)[:, :, None, None]
+    got = (x - mean) / torch.sqrt(var + 1e-6) * w.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    assert float((got - torch.tensor(z["summary.out1"])).abs().max()) < 1e-5
+    lsd = {"n.weight": w, "n.bias": b}
+    assert float((TO.cross_tile_norm(lsd, "n", tiles, False)[1] - torch.tensor(z["summary.out1"])).abs().max()) < 1e-6
+
+
+def test_oracle_tiled_vae(golden_dir):
+    _, sd = _build()
+    z = np.load(os.path.join(golden_dir, "tilevae_golden.npz"))
+    img = seeded.synthetic_image((1, 3, 256, 192), seed=90, smooth=3)
+    assert float((TO.tiled_forward(sd, img, 96, False, "first_stage_model.encoder.") - torch.tensor(z["enc.out"])).abs().max()) < 5e-5
+    from oracle import s2_oracle as O
+    zin = O.conv(sd, "first_stage_model.post_quant_conv", S.rnd((1, 4, 40, 28), 91))
+    assert float((TO.tiled_forward(sd, zin, 12, True, "first_stage_model.decoder.") - torch.tensor(z["dec.out"])).abs().max()) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,rel", [(torch.float16, 8e-3), (torch.bfloat16, 5e-2)])
+def test_hip_vaehook_vs_reference_golden(cuda, golden_dir, dt, rel):
+    """The product's VAEHook (all tiles HBM-resident, merged GroupNorm statistics) against the reference's
+    VAEHook output.  fp16 storage: 8e-3 x range; bf16 (the reference's ae_dtype): 5e-2 x range."""
+    from rsvld_amd import ops
+    from rsvld_amd.utils.tilevae import VAEHook
+    fs, _ = _build()
+    fs.to(cuda)
+    fs.set_compute_dtype(dt)
+    z = np.load(os.path.join(golden_dir, "tilevae_golden.npz"))
+    img = seeded.synthetic_image((1, 3, 256, 192), seed=90, smooth=3).to(cuda)
+    enc = fs.encoder
+    enc.original_forward = enc.forward
+    enc.forward = VAEHook(enc, 96, is_decoder=False)
+    got = ops.nhwc_to_nchw(enc.forward(img)).cpu()
+    want = torch.tensor(z["enc.out"])
+    e = float((got - want).abs().max())
+    print(f"tiled encoder [{dt}]: max|d| = {e:.3e} (range {float(want.abs().max()):.2f})")
+    assert e < rel * float(want.abs().max())
+    dec = fs.decoder
+    dec.original_forward = dec.forward
+    dec.forward = VAEHook(dec, 12, is_decoder=True)
+    zin = ops.conv2d(ops.nchw_to_nhwc(S.rnd((1, 4, 40, 28), 91).to(cuda), dt), fs.pk(fs.post_quant_conv), pad=0)
+    got = ops.nhwc_to_nchw(dec.forward(zin), channels=3).cpu()
+    want = torch.tensor(z["dec.out"])
+    e = float((got - want).abs().max())
+    print(f"tiled decoder [{dt}]: max|d| = {e:.3e} (range {float(want.abs().max()):.2f})")
+    assert e < rel * float(want.abs().max())
+    # small inputs bypass tiling (tilevae.py:692-694)
+    small = seeded.synthetic_image((1, 3, 64, 64), seed=3, smooth=2).to(cuda)
+    assert torch.equal(enc.forward(small), enc.original_forward(small))
