@@ -42,9 +42,10 @@ def gather_images(local_u8, world):
     """All-gather equally-shaped uint8 image batches; returns [world*B, C, H, W] ordered by rank."""
     if world == 1:
         return local_u8
-    out = torch.empty((world,) + tuple(local_u8.shape), dtype=local_u8.dtype, device=local_u8.device)
+    shape = (world * local_u8.shape[0],) + tuple(local_u8.shape[1:])
+    out = torch.empty(shape, dtype=local_u8.dtype, device=local_u8.device)   # rank-major concatenation
     dist.all_gather_into_tensor(out, local_u8.contiguous())
-    return out.flatten(0, 1)
+    return out
 
 
 def unshard(gathered, n_images, world):
