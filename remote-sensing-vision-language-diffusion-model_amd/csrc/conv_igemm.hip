@@ -7,15 +7,23 @@
 // and, per accumulator register quad, FOUR CONSECUTIVE output channels: the epilogue can
 // then move 16 B per lane into the LDS out-tile and leave HBM in full 16-byte NHWC rows.
 //
-// Data movement (cdna_hip_programming.md §5 "glds vs register staging", T14):
-//   HBM --global_load_dwordx4 (im2col gather, zero-fill by predicate)--> VGPR
-//       --ds_write_b128 (XOR-swizzled 128-B rows)--> LDS (double buffered, BK = 64)
-//       --ds_read_b128 (conflict-free)--> MFMA operands.
-// The next K-tile's global loads are issued BEFORE the current tile's MFMAs and written to
-// the other LDS buffer after them (one barrier per K-step).
+// Data movement, two staging variants selected at run time (A/B-able on hardware):
+//  GLDS (default): HBM --global_load_lds_dwordx4 (LDS-DMA; im2col gather through the per-lane SOURCE
+//       address; padded taps read a zero page)--> LDS, no VGPR round trip.  The LDS image is
+//       lane-linear per wave (8 rows x 128 B), so the XOR swizzle is applied to the source chunk
+//       each lane fetches (cdna_hip_programming.md §5.4 rule 21).  Motivation: with register staging
+//       the ds_write_b128 path (~79 B/clk/CU) carries 2 KiB per 32-cycle MFMA slot = ~80 % busy.
+//  REG : HBM --global_load_dwordx4 (zero-fill by predicate)--> VGPR --ds_write_b128--> LDS.
+// Both: double-buffered BK = 64 tiles, next tile's loads issued BEFORE the current tile's MFMAs,
+// one barrier per K-step; ds_read_b128 of XOR-swizzled 128-B rows is conflict-free.
+// Workgroup -> tile order is XCD-aware: the 8 XCDs get contiguous runs of M tiles (same weight
+// tile, adjacent image rows) so halo rows and weights hit that XCD's private L2.
 //
 // Fusions: nearest x2 up-sampling of the input (index >>1), channel concatenation of two
 // inputs, bias, per-image row vector (time embedding), residual add, SiLU / GEGLU.
+#include <stdlib.h>
+#include <string.h>
+
 #include "rsvld_common.h"
 
 namespace {
@@ -44,13 +52,22 @@ struct ConvArgs {
 
 constexpr int BK_BYTES = 128;  // 64 x 16-bit per LDS row
 
+__device__ uint4 g_zero16;  // zero page: source of padded / out-of-range chunks for the LDS-DMA path
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 // byte offset of 16-byte chunk `c` (0..7) of LDS row `row` (128-B rows).  Two rows share
 // one 256-B bank row; XOR with (row>>1)&7 makes every ds_read_b128 lane group hit 16
 // distinct 16-B slots (MI355X_MICROARCH.md §LDS).
 __device__ __forceinline__ int lds_off(int row, int c) { return row * BK_BYTES + ((c ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+// counted wait: all but the newest `n` LDS-DMA (vector-memory) operations of this wave have landed
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+    static_assert(GLDS ? (STAGES >= 2 && STAGES <= 4) : STAGES == 2, "register staging is double-buffered");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -65,12 +82,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order: linear workgroup id -> (XCD label, slot); each XCD walks a contiguous run of
+    // tiles with m fastest (bijective for any grid size, cdna_hip_programming.md §5 "XCD swizzle")
+    int tile_m, tile_n;
+    {
+        const int nmt = gridDim.x, nwg = gridDim.x * gridDim.y;
+        const int lid = blockIdx.x + blockIdx.y * nmt;
+        const int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, slot = lid >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile_n = t / nmt;
+        tile_m = t - tile_n * nmt;
+    }
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
 
-    // ---- staging roles: thread -> 16-byte chunk c of rows r0, r0+32, ...
-    const int c = tid & 7;
+    // ---- staging roles: thread -> 16-byte chunk of rows r0, r0+32, ...  With LDS-DMA the lane's LDS
+    // slot is fixed (row r0, physical chunk tid&7), so it fetches the LOGICAL chunk that the swizzle
+    // maps there: c = (tid&7) ^ ((r0>>1)&7)  ((row>>1)&7 is the same for r0 and r0+32i).
     const int r0 = tid >> 3;
+    const int c = GLDS ? ((tid & 7) ^ ((r0 >> 1) & 7)) : (tid & 7);
 
     int a_pix[A_LOADS], a_iy0[A_LOADS], a_ix0[A_LOADS];
 #pragma unroll
@@ -135,6 +165,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             rb[i] = v;
         }
     };
+    // LDS-DMA: one wave instruction fills 8 consecutive rows (1 KiB) of the tile
+    auto dma_tile = [&](int kt, int buf) {
+        char* a_s = smem + buf * STAGE;
+        char* b_s = a_s + A_BYTES;
+        const bool kvalid = ky < p.KH;
+        const T* src;
+        int cc, Cs;
+        if (ci < p.C1_8) { src = X1; cc = ci; Cs = p.Cin; } else { src = X2; cc = ci - p.C1_8; Cs = p.Cin2; }
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            const bool valid = kvalid && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+            iy >>= ush; ix >>= ush;
+            const int64_t off = ((int64_t)(a_pix[i] + iy * p.W + ix)) * Cs + cc * 8;
+            const void* g = valid ? (const void*)(src + off) : (const void*)&g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(a_s + (wave * 8 + 32 * i) * BK_BYTES), 16, 0, 0);
+        }
+        const int q = kt * 8 + c;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int n = n0 + r0 + 32 * i;
+            const void* g = (n < p.Cout && q < p.KC) ? (const void*)(Wp + (int64_t)n * Kel + (int64_t)q * 8)
+                                                     : (const void*)&g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(b_s + (wave * 8 + 32 * i) * BK_BYTES), 16, 0, 0);
+        }
+    };
     auto store_tile = [&](int buf) {
         char* a_s = smem + buf * STAGE;
         char* b_s = a_s + A_BYTES;
@@ -152,19 +208,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < p.nk; ++kt) {
-        const bool more = kt + 1 < p.nk;
-        if (more) {
-            ci += 8;
-            normalize();
-            load_tile(kt + 1);
-        }
-        const char* a_s = smem + (kt & 1) * STAGE;
+    auto compute_tile = [&](int buf) {
+        const char* a_s = smem + buf * STAGE;
         const char* b_s = a_s + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -179,8 +225,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
                 for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
         }
-        if (more) store_tile((kt + 1) & 1);
+    };
+
+    if (GLDS && STAGES > 2) {
+        // ---- LDS-DMA ring, STAGES buffers, STAGES-1 tiles in flight (cdna_hip_programming.md §5
+        // "Pipelining across barriers"): per K-step  counted vmcnt -> raw s_barrier -> issue tile
+        // kt+STAGES-1 into the buffer read in step kt-1 -> MFMAs of tile kt.  The barrier both publishes
+        // tile kt (every wave waited for its own DMA pieces) and retires the reads of tile kt-1.
+        constexpr int L = A_LOADS + B_LOADS;   // DMA instructions per wave per tile
+        int issued = 0;
+        for (; issued < STAGES - 1 && issued < p.nk; ++issued) {
+            if (issued > 0) { ci += 8; normalize(); }
+            dma_tile(issued, issued);
+        }
+        for (int kt = 0; kt < p.nk; ++kt) {
+            const int ahead = issued - 1 - kt;   // tiles issued after tile kt: 0 .. STAGES-2
+            if (ahead >= 2) wait_vmcnt<2 * L>();
+            else if (ahead == 1) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (issued < p.nk) {
+                ci += 8;
+                normalize();
+                dma_tile(issued, issued % STAGES);
+                ++issued;
+            }
+            compute_tile(kt % STAGES);
+        }
+        __builtin_amdgcn_s_barrier();          // all waves done with the ring before the epilogue reuses it
+    } else {
+        if (GLDS) {
+            dma_tile(0, 0);
+        } else {
+            load_tile(0);
+            store_tile(0);
+        }
         __syncthreads();
+        for (int kt = 0; kt < p.nk; ++kt) {
+            const bool more = kt + 1 < p.nk;
+            if (more) {
+                ci += 8;
+                normalize();
+                if (GLDS) dma_tile(kt + 1, (kt + 1) & 1);
+                else load_tile(kt + 1);
+            }
+            compute_tile(kt & 1);
+            if (!GLDS && more) store_tile((kt + 1) & 1);
+            __syncthreads();   // with LDS-DMA in flight this also waits vmcnt(0): next tile has landed
+        }
     }
 
     // ---- epilogue: accumulators -> LDS out tile Ct[pixel][cout] (fp32, row stride BN+4)
@@ -257,12 +349,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES = 2>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
-    constexpr int stage = 2 * (BM + BN) * BK_BYTES;
+    constexpr int stage = STAGES * (BM + BN) * BK_BYTES;
     constexpr int epi = BM * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
-    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -274,11 +366,73 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     return rsvld_check_launch();
 }
 
+bool use_glds() {   // RSVLD_CONV_STAGING=reg selects the register-staged variant (A/B on hardware)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RSVLD_CONV_STAGING");
+        v = (e != nullptr && e[0] == 'r') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+int tile_override() {   // RSVLD_CONV_TILE=256x64|128x64|128x128|64x128 forces a tile (benchmarking only)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RSVLD_CONV_TILE");
+        v = 0;
+        if (e != nullptr) {
+            if (!strcmp(e, "256x64")) v = 1;
+            else if (!strcmp(e, "128x64")) v = 2;
+            else if (!strcmp(e, "128x128")) v = 3;
+            else if (!strcmp(e, "64x128")) v = 4;
+        }
+    }
+    return v;
+}
+
+// Tile choice.  Cout <= 32: 256x32.  Cout <= 64: 128x64 (48 KiB LDS -> 3 workgroups per CU: these layers
+// have few K-steps per tile, so co-resident workgroups hide each other's prologue / epilogue).  Otherwise
+// 128x128, except when that grid would leave CUs idle (< 256 workgroups): then 64x128 doubles the grid.
+int stages_override() {   // RSVLD_CONV_STAGES=2|3|4 (benchmarking only; default = per-tile choice below)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RSVLD_CONV_STAGES");
+        v = e != nullptr ? atoi(e) : 0;
+    }
+    return v;
+}
+
+template <typename T, bool GLDS>
+int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
+    if (a.Cout <= 32) return launch_conv<T, 256, 32, 4, 1, GLDS>(a, s);
+    const int ov = tile_override();
+    const int st = GLDS ? stages_override() : 2;
+    if (a.Cout <= 64) {
+        if (ov == 1) return launch_conv<T, 256, 64, 4, 1, GLDS>(a, s);
+        if constexpr (GLDS) {   // measured: 3 WGs/CU x 1 tile in flight (48 KiB) beats 2 WGs/CU x 2 tiles (72 KiB)
+            if (st == 3) return launch_conv<T, 128, 64, 4, 1, true, 3>(a, s);
+            if (st == 4) return launch_conv<T, 128, 64, 4, 1, true, 4>(a, s);
+        }
+        return launch_conv<T, 128, 64, 4, 1, GLDS>(a, s);
+    }
+    const int64_t wg128 = (int64_t)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+    if (ov == 4 || (ov == 0 && wg128 < 256)) {
+        if constexpr (GLDS) {
+            if (st == 3 || st == 0) return launch_conv<T, 64, 128, 2, 2, true, 3>(a, s);   // 72 KiB: 2 WGs / CU
+            if (st == 4) return launch_conv<T, 64, 128, 2, 2, true, 4>(a, s);
+        }
+        return launch_conv<T, 64, 128, 2, 2, GLDS>(a, s);
+    }
+    if constexpr (GLDS) {   // measured: the 96 KiB ring drops to 1 WG/CU and loses 30 % to 2 x 64 KiB double buffers
+        if (st == 3) return launch_conv<T, 128, 128, 2, 2, true, 3>(a, s);
+        if (st == 4) return launch_conv<T, 128, 128, 2, 2, true, 4>(a, s);
+    }
+    return launch_conv<T, 128, 128, 2, 2, GLDS>(a, s);
+}
+
 template <typename T>
 int dispatch_conv(const ConvArgs& a, hipStream_t s) {
-    if (a.Cout <= 32) return launch_conv<T, 256, 32, 4, 1>(a, s);
-    if (a.Cout <= 64) return launch_conv<T, 256, 64, 4, 1>(a, s);
-    return launch_conv<T, 128, 128, 2, 2>(a, s);
+    return use_glds() ? dispatch_conv2<T, true>(a, s) : dispatch_conv2<T, false>(a, s);
 }
 
 }  // namespace

@@ -172,7 +172,13 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride,
         pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=_dt(x), out_f32=int(out_f32),
         act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride)
-    variant = "conv_igemm_256x32" if pc.cout_p <= 32 else ("conv_igemm_256x64" if pc.cout_p <= 64 else "conv_igemm_128x128")
+    if pc.cout_p <= 32:
+        variant = "conv_igemm_256x32"
+    elif pc.cout_p <= 64:
+        variant = "conv_igemm_128x64"
+    else:   # mirrors dispatch_conv2 in csrc/conv_igemm.hip
+        wg128 = ((B * Ho * Wo + 127) // 128) * ((pc.cout_p + 127) // 128)
+        variant = "conv_igemm_64x128" if wg128 < 256 else "conv_igemm_128x128"
     esz = x.element_size()
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
     nbytes = (x.numel() + (0 if x2 is None else x2.numel()) + pc.w.numel()) * esz + out.numel() * out.element_size() \
