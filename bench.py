@@ -154,8 +154,14 @@ def main():
         summ = prof.summary()
         dom = max(summ.values(), key=lambda r: r["ms"])
         tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        traffic = None   # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this workload
+        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_traffic.json")
+        if os.path.exists(pmc) and side == 512 and args.batch == 4:
+            k = json.load(open(pmc))["kernels"].get(dom["name"])
+            traffic = None if k is None else round(k["hbm_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK_TFLOPS_F16,
-                "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
                 "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 2),
                 "kernel_time_share": round(dom["ms"] / sum(r["ms"] for r in summ.values()), 3),
                 "by_kernel": {k: {"ms": round(v["ms"], 3), "n": v["n"],
