@@ -75,6 +75,16 @@ typedef struct rsvld_conv_desc {
 
 int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
 
+/* 3x3 / stride-1 / pad-1 convolution with an LDS-resident input halo patch (each activation byte crosses
+ * L2->LDS once per 64-channel chunk instead of once per tap) and an OPTIONAL fused GroupNorm prologue:
+ * when norm_scale_shift != NULL (fp32 [B][Cin+Cin2][2] from rsvld_groupnorm_scale_shift) the input is
+ * y = act(scale*x + shift) (act = SiLU if norm_silu) applied while the patch is staged, so the
+ * normalised tensor is never written to HBM.  Same descriptor / epilogue as rsvld_conv2d_nhwc.
+ * rsvld_conv3x3_halo_supported tells whether a descriptor is eligible (1) or must use the gather kernel (0).
+ * Replaces GN+SiLU+Conv3x3 of unet.py:81-92, openaimodel.py:263-301, model.py:128-141. */
+int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d);
+int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* norm_scale_shift, int norm_silu, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU / Swish) over NHWC, statistics in fp32, two launches
  * (deterministic partial sums -> finalize+apply).  `ws` must hold
@@ -106,6 +116,12 @@ int rsvld_groupnorm_apply(const void* x, const void* x2, void* y, const float* m
                           const void* mod_scale1p, const void* mod_shift, int mod_stride,
                           int B, int HW, int C1, int C2, int groups, float eps,
                           int silu, int dtype, void* stream);
+
+/* statistics + per-(image, channel) affine of a GroupNorm, for the fused conv prologue:
+ * scale_shift[b][c] = (gamma[c]*rstd[b,g], beta[c] - mean[b,g]*gamma[c]*rstd[b,g]), fp32 [B][C1+C2][2] */
+int rsvld_groupnorm_scale_shift(const void* x, const void* x2, const float* gamma, const float* beta,
+                                float* scale_shift, int B, int HW, int C1, int C2, int groups, float eps,
+                                int dtype, void* ws, void* stream);
 
 /* LayerNorm over the last dim of [rows, C] (eps 1e-5, affine).  attention.py:376-486 */
 int rsvld_layernorm(const void* x, void* y, const float* gamma, const float* beta,

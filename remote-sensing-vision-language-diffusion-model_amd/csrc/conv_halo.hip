@@ -1,0 +1,321 @@
+// conv_halo.hip — 3x3 / stride-1 / pad-1 convolution with an LDS-resident input halo patch and an
+// optional fused GroupNorm(+SiLU) prologue, for gfx950.
+//
+// Why a second conv kernel: the implicit-GEMM kernel (conv_igemm.hip) gathers the im2col operand from
+// L2 for every tap, i.e. each activation byte crosses the L2->LDS path 9 times; rocprofv3 showed
+// ~7x the algorithmic HBM-side bytes and a kernel bound by bytes-in-flight / latency.
+// Here a workgroup owns an 8 x 32 pixel tile of ONE image:
+//   per 64-channel chunk:  the (8+2) x (32+2) x 64ch input patch is loaded ONCE (16-byte vectors),
+//                          normalised and activated in registers  y = silu(a[b,c]*x + b[b,c])  when a
+//                          GroupNorm precedes the conv (zero padding is applied AFTER the activation,
+//                          as nn.Conv2d does), and written to LDS (XOR-swizzled 128-B rows);
+//   per tap (9 per chunk): the [BN x 64] weight slice streams in by LDS-DMA (double buffered) while
+//                          the MFMAs of the previous tap run; the pixel operand of tap (ky,kx) is the
+//                          SAME patch read at a shifted row offset -- no data movement at all.
+// L2->LDS bytes per 256 pixels x 64 channels: 43.5 KiB patch + 9 x BN x 128 B weights, vs
+// 9 x (256+BN) x 128 B for the gather.  MFMA work per barrier doubles (32 MFMAs per wave per tap).
+#include "rsvld_common.h"
+
+namespace {
+
+struct HaloArgs {
+    const void* x;
+    const void* x2;
+    const void* w;
+    const float* bias;
+    const float* rowvec;
+    const void* residual;
+    void* out;
+    const float* ab;     // [B][Cin+Cin2][2] = (scale, shift) of the fused GroupNorm, or nullptr
+    int B, H, W, Cin, Cin2, Cout;
+    int out_f32, act, norm_silu;
+    float alpha, beta;
+    int Ctot, nchunks;   // channels, 64-channel chunks
+    int tiles_x, tiles_y;
+    int rv_stride, Cout_out;
+};
+
+constexpr int TH = 8, TW = 32, PW = TW + 2, PROWS = (TH + 2) * PW;   // 340 patch pixels
+constexpr int PATCH_BYTES = PROWS * 128;
+constexpr int PLOADS = (PROWS * 8 + 255) / 256;                        // 11 16-byte pieces per thread
+
+__device__ uint4 g_halo_zero16;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ int swz_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int BN, int WAVES_M>
+__global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int TM = TH / WAVES_M;               // 32-pixel rows per wave
+    constexpr int TN = BN / (32 * WAVES_N);
+    constexpr int W_BYTES = BN * 128;
+    constexpr int W_LOADS = BN / 32;
+    constexpr int EPI_PASSES = BN > 64 ? 2 : 1;
+    constexpr int EPI_ROWS = 256 / EPI_PASSES;
+    constexpr int CT_STRIDE = BN + 4;
+    typedef typename Mfma<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;
+    char* wbuf = smem + PATCH_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order (same scheme as conv_igemm): linear id -> contiguous run per XCD, x fastest
+    int tx, ty, img, tile_n;
+    {
+        const int nwg = gridDim.x;
+        const int lid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, slot = lid >> 3;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tx = t % p.tiles_x; t /= p.tiles_x;
+        ty = t % p.tiles_y; t /= p.tiles_y;
+        img = t % p.B;
+        tile_n = t / p.B;
+    }
+    const int x0 = tx * TW, y0 = ty * TH, n0 = tile_n * BN;
+
+    // ---- patch roles: piece i of this thread = patch pixel (tid>>3) + 32 i, chunk c = tid & 7
+    const int c = tid & 7;
+    int poff[PLOADS];     // pixel offset inside the image, -1 = outside (zero padding) or beyond the patch
+#pragma unroll
+    for (int i = 0; i < PLOADS; ++i) {
+        const int pp = (tid >> 3) + 32 * i;
+        const int py = pp / PW, px = pp - py * PW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        poff[i] = (pp < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? y * p.W + x : -1;
+    }
+    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.H * p.W * p.Cin;
+    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.H * p.W * p.Cin2 : nullptr;
+    const T* __restrict__ Wp = (const T*)p.w;
+    const int64_t Kel = (int64_t)9 * p.Ctot;
+
+    u32x4 rp[PLOADS];
+    auto load_patch = [&](int kc) {
+        const int ch0 = kc * 64;
+        const T* src;
+        int Cs, coff;
+        if (ch0 < p.Cin) { src = X1; Cs = p.Cin; coff = ch0 + c * 8; } else { src = X2; Cs = p.Cin2; coff = ch0 - p.Cin + c * 8; }
+#pragma unroll
+        for (int i = 0; i < PLOADS; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (poff[i] >= 0) v = *(const u32x4*)(src + (int64_t)poff[i] * Cs + coff);
+            rp[i] = v;
+        }
+    };
+    auto store_patch = [&](int kc) {
+        float sa[8], sb[8];
+        if (p.ab != nullptr) {
+            const float* ab = p.ab + ((int64_t)img * p.Ctot + kc * 64 + c * 8) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sa[e] = ab[2 * e]; sb[e] = ab[2 * e + 1]; }
+        }
+#pragma unroll
+        for (int i = 0; i < PLOADS; ++i) {
+            const int pp = (tid >> 3) + 32 * i;
+            if (pp >= PROWS) continue;
+            u32x4 v = rp[i];
+            if (p.ab != nullptr && poff[i] >= 0) {
+                float f[8];
+                unpack8<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = f[e] * sa[e] + sb[e];
+                    f[e] = p.norm_silu ? silu_f(t) : t;
+                }
+                v = pack8<T>(f);
+            }
+            *(u32x4*)(patch + swz_off(pp, c)) = v;
+        }
+    };
+    // weights of (chunk kc, tap): rows n0.. , k = tap*Ctot + kc*64 ..+64 ; lane-linear LDS image, source-side swizzle
+    const int wr0 = tid >> 3;
+    const int wc = (tid & 7) ^ ((wr0 >> 1) & 7);
+    auto dma_w = [&](int kc, int tap, int buf) {
+        char* dst = wbuf + buf * W_BYTES;
+        const int64_t koff = (int64_t)tap * p.Ctot + kc * 64 + wc * 8;
+#pragma unroll
+        for (int i = 0; i < W_LOADS; ++i) {
+            const int n = n0 + wr0 + 32 * i;
+            const void* g = n < p.Cout ? (const void*)(Wp + (int64_t)n * Kel + koff) : (const void*)&g_halo_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    load_patch(0);
+    dma_w(0, 0, 0);
+    store_patch(0);
+    __syncthreads();   // patch written, weights of step 0 landed (vmcnt(0) + barrier)
+
+    const int nsteps = p.nchunks * 9;
+    int kc = 0, tap = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // next step's weights stream in behind this step's MFMAs
+        const int ntap = tap == 8 ? 0 : tap + 1;
+        const int nkc = tap == 8 ? kc + 1 : kc;
+        if (s + 1 < nsteps) dma_w(nkc, ntap, (s + 1) & 1);
+        if (tap == 6 && kc + 1 < p.nchunks) load_patch(kc + 1);   // next chunk's patch: global loads in flight
+
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const char* w_s = wbuf + (s & 1) * W_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = 2 * ks + lh;
+            v8 fa[TN], fb[TM];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + swz_off(wn * (TN * 32) + ni * 32 + l31, ch));
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int pr = (wm * TM + mi + ky) * PW + l31 + kx;     // shifted window of the same patch
+                fb[mi] = *(const v8*)(patch + swz_off(pr, ch));
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
+        }
+        __syncthreads();   // everyone done with this step's weights (and, at tap 8, with the patch)
+        if (tap == 8 && kc + 1 < p.nchunks) {
+            store_patch(kc + 1);
+            __syncthreads();
+        }
+        tap = ntap;
+        kc = nkc;
+    }
+
+    // ---- epilogue through LDS (fp32), EPI_PASSES passes of EPI_ROWS pixels
+    float* Ct = (float*)smem;
+    constexpr int CPR = BN / 8, RPP = 256 / CPR;
+    const int cc = tid % CPR, rr = tid / CPR;
+    const int n = n0 + cc * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias != nullptr && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+#pragma unroll
+    for (int pass = 0; pass < EPI_PASSES; ++pass) {
+        if (pass > 0) __syncthreads();
+        if ((wm * TM * 32) / EPI_ROWS == pass) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = (wm * TM + mi) * 32 + l31 - pass * EPI_ROWS;
+                        const int col = wn * (TN * 32) + ni * 32 + 8 * g + 4 * lh;
+                        f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+                        *(f32x4*)(Ct + row * CT_STRIDE + col) = v;
+                    }
+        }
+        __syncthreads();
+        if (n < p.Cout) {
+            for (int row = rr; row < EPI_ROWS; row += RPP) {
+                const int prow = pass * EPI_ROWS + row;
+                const int y = y0 + (prow >> 5), x = x0 + (prow & 31);
+                if (y >= p.H || x >= p.W) continue;
+                const int64_t m = ((int64_t)img * p.H + y) * p.W + x;
+                const f32x4 v0 = *(const f32x4*)(Ct + row * CT_STRIDE + cc * 8);
+                const f32x4 v1 = *(const f32x4*)(Ct + row * CT_STRIDE + cc * 8 + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                if (p.rowvec != nullptr) {
+                    const float* rv = p.rowvec + (int64_t)img * p.rv_stride + n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
+                if (p.act == RSVLD_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+                if (p.residual != nullptr) {
+                    float rf[8];
+                    unpack8<T>(*(const u32x4*)((const T*)p.residual + m * p.Cout_out + n), rf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += p.beta * rf[e];
+                }
+                if (p.out_f32) {
+                    float* o = (float*)p.out + m * p.Cout_out + n;
+                    *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    *(u32x4*)((T*)p.out + m * p.Cout_out + n) = pack8<T>(v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BN, int WAVES_M>
+int launch_halo(const HaloArgs& a, hipStream_t s) {
+    constexpr int stage = PATCH_BYTES + 2 * BN * 128;
+    constexpr int epi = (256 / (BN > 64 ? 2 : 1)) * (BN + 4) * 4;
+    constexpr int smem = stage > epi ? stage : epi;
+    auto kern = conv_halo_kernel<T, BN, WAVES_M>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return RSVLD_ELAUNCH;
+        attr_set = true;
+    }
+    const int64_t nwg = (int64_t)a.tiles_x * a.tiles_y * a.B * ((a.Cout + BN - 1) / BN);
+    if (nwg >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
+    return rsvld_check_launch();
+}
+
+template <typename T>
+int dispatch_halo(const HaloArgs& a, hipStream_t s) {
+    if (a.Cout <= 64) return launch_halo<T, 64, 4>(a, s);
+    return launch_halo<T, 128, 2>(a, s);
+}
+
+}  // namespace
+
+// 3x3 / stride 1 / pad 1, no up-sampling, every source a multiple of 64 channels
+extern "C" int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d) {
+    if (d == nullptr) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->upsample) return 0;
+    if (d->Ho != d->H || d->Wo != d->W) return 0;
+    if (d->Cin % 64 != 0 || d->Cin2 % 64 != 0) return 0;
+    if (d->act == RSVLD_ACT_GEGLU) return 0;
+    if (d->out_f32 && d->Cout > 32) return 0;
+    if (d->W < 16 || d->H < 4) return 0;   // tiny maps: the 8x32 tile would be mostly padding
+    return 1;
+}
+
+extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* norm_scale_shift, int norm_silu, void* stream) {
+    if (!rsvld_conv3x3_halo_supported(d)) return RSVLD_EUNSUPPORTED;
+    if (d->x == nullptr || d->w == nullptr || d->out == nullptr) return RSVLD_EINVAL;
+    if (d->B <= 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
+    if ((d->Cin2 > 0) != (d->x2 != nullptr)) return RSVLD_EINVAL;
+    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16) return RSVLD_EINVAL;
+    if ((int64_t)d->H * d->W >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
+    HaloArgs a;
+    a.x = d->x; a.x2 = d->x2; a.w = d->w; a.bias = d->bias; a.rowvec = d->rowvec; a.residual = d->residual; a.out = d->out;
+    a.ab = norm_scale_shift;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
+    a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.norm_silu = norm_silu ? 1 : 0;
+    a.alpha = d->alpha; a.beta = d->beta;
+    a.Ctot = d->Cin + d->Cin2;
+    a.nchunks = a.Ctot / 64;
+    a.tiles_x = (d->W + TW - 1) / TW;
+    a.tiles_y = (d->H + TH - 1) / TH;
+    a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
+    a.Cout_out = d->Cout;
+    hipStream_t s = (hipStream_t)stream;
+    return d->dtype == RSVLD_F16 ? dispatch_halo<f16>(a, s) : dispatch_halo<bf16>(a, s);
+}

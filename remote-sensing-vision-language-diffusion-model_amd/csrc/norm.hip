@@ -101,6 +101,22 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// per-(image, channel) affine of a GroupNorm: ab[b][c] = (gamma*rstd, beta - mean*gamma*rstd); consumed by the
+// fused prologue of conv_halo.hip, which then applies y = act(a*x + b) while staging its input patch
+__global__ void gn_scale_shift_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ ab, int C, int groups,
+                                      float eps, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, ch = i - b * C;
+    const int g = ch / (C / groups);
+    const float mean = stats[((int64_t)b * groups + g) * 2];
+    const float var = stats[((int64_t)b * groups + g) * 2 + 1];
+    const float a = (gamma ? gamma[ch] : 1.f) / sqrtf(var + eps);
+    ab[2 * (int64_t)i] = a;
+    ab[2 * (int64_t)i + 1] = (beta ? beta[ch] : 0.f) - mean * a;
+}
+
 // pass 3: y = act((x-mean)*rstd*gamma+beta) [*(1+scale1p)+shift]
 // grid (row-chunks, B).  Same thread <-> channel-chunk mapping as pass 1: a thread keeps ONE
 // 8-channel chunk, so its 8 (scale, shift) pairs live in registers and the row loop is pure
@@ -321,6 +337,20 @@ extern "C" int rsvld_groupnorm_nhwc(const void* x, const void* x2, void* y, cons
     if (rc != RSVLD_OK) return rc;
     return rsvld_groupnorm_apply(x, x2, y, stats, gamma, beta, mod_scale1p, mod_shift, mod_stride, B, HW, C1, C2, groups,
                                  eps, silu, dtype, stream);
+}
+
+extern "C" int rsvld_groupnorm_scale_shift(const void* x, const void* x2, const float* gamma, const float* beta,
+                                           float* scale_shift, int B, int HW, int C1, int C2, int groups, float eps,
+                                           int dtype, void* ws, void* stream) {
+    if (!ws || !scale_shift || !gn_shape_ok(B, HW, C1, C2, groups)) return RSVLD_EINVAL;
+    const GnPlan pl = gn_plan(B, HW);
+    float* stats = (float*)ws + (int64_t)B * pl.nchunks * groups * 2;
+    int rc = rsvld_groupnorm_stats(x, x2, stats, B, HW, C1, C2, groups, dtype, ws, stream);
+    if (rc != RSVLD_OK) return rc;
+    const int C = C1 + C2, total = B * C;
+    hipLaunchKernelGGL(gn_scale_shift_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma,
+                       beta, scale_shift, C, groups, eps, total);
+    return rsvld_check_launch();
 }
 
 extern "C" int rsvld_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C,

@@ -52,7 +52,8 @@ template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&f)[8]
     return __builtin_bit_cast(u32x4, v);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE division here made the GroupNorm apply pass VALU-bound
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

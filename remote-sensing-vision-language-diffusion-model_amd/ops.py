@@ -135,9 +135,18 @@ def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
 
 
 # ----------------------------------------------------------------------------- conv / linear
+USE_HALO = True      # route eligible 3x3 convs through conv_halo.hip (set False to A/B against the gather kernel)
+HALO_MIN_WGS = 256   # below one workgroup per CU the 8x32-pixel halo tile under-fills the chip (measured 130 vs
+                     # 334 TFLOP/s on 32x32 maps): such layers use the 64x128 gather kernel with the 3-stage ring
+
+
 def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, residual=None,
-           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0):
-    """NHWC convolution through rsvld_conv2d_nhwc.  ``pad`` = int or (top, left, bottom, right)."""
+           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None):
+    """NHWC convolution.  ``pad`` = int or (top, left, bottom, right).
+
+    ``norm=(gamma, beta, groups, eps, silu)``: a GroupNorm(+SiLU) over the input ([x | x2]) precedes the
+    conv.  For 3x3/stride-1 convs it is FUSED into the conv's input staging (rsvld_conv3x3_halo_nhwc): one
+    statistics pass over x, no normalised tensor in HBM.  Otherwise it runs as its own kernels first."""
     _need_gpu(x, x2, pc.w, rowvec, residual)
     B, H, W, Cin = x.shape
     Cin2 = 0 if x2 is None else x2.shape[-1]
@@ -172,6 +181,34 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride,
         pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=_dt(x), out_f32=int(out_f32),
         act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride)
+    lib = L.load()
+    halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
+    if halo:
+        bn = 64 if pc.cout_p <= 64 else 128
+        halo = B * ((H + 7) // 8) * ((W + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= HALO_MIN_WGS
+    if norm is not None and not halo:   # unfused: normalise into a (single) tensor, then convolve it
+        gamma, nbeta, groups, eps, silu = norm
+        xn = group_norm(x, gamma, nbeta, groups, eps, x2=x2, silu=silu)
+        return conv2d(xn, pc, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
+                      out_f32=out_f32, act=act, alpha=alpha, beta=beta)
+    esz = x.element_size()
+    flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
+    nbytes = (x.numel() + (0 if x2 is None else x2.numel()) + pc.w.numel()) * esz + out.numel() * out.element_size() \
+        + (0 if residual is None else residual.numel() * esz)
+    if halo:
+        ab, silu = None, 0
+        if norm is not None:
+            gamma, nbeta, groups, eps, silu = norm
+            ws = torch.empty(lib.rsvld_groupnorm_ws_bytes(B, H * W, Cin + Cin2, groups), device=x.device, dtype=torch.uint8)
+            ab = torch.empty((B, Cin + Cin2, 2), device=x.device, dtype=torch.float32)
+            _launch("groupnorm_stats(3 kernels)", 0.0, x.numel() * esz + (0 if x2 is None else x2.numel() * esz),
+                    lambda: L.check(lib.rsvld_groupnorm_scale_shift(_ptr(x), _ptr(x2), _ptr(gamma), _ptr(nbeta), _ptr(ab), B,
+                                                                    H * W, Cin, Cin2, groups, eps, _dt(x), _ptr(ws), _stream()),
+                                    "rsvld_groupnorm_scale_shift"))
+        name = "conv_halo_64" if pc.cout_p <= 64 else "conv_halo_128"
+        _launch(name, flops, nbytes, lambda: L.check(lib.rsvld_conv3x3_halo_nhwc(C.byref(d), _ptr(ab), int(silu), _stream()),
+                                                     "rsvld_conv3x3_halo_nhwc"))
+        return out
     if pc.cout_p <= 32:
         variant = "conv_igemm_256x32"
     elif pc.cout_p <= 64:
@@ -179,11 +216,6 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     else:   # mirrors dispatch_conv2 in csrc/conv_igemm.hip
         wg128 = ((B * Ho * Wo + 127) // 128) * ((pc.cout_p + 127) // 128)
         variant = "conv_igemm_64x128" if wg128 < 256 else "conv_igemm_128x128"
-    esz = x.element_size()
-    flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
-    nbytes = (x.numel() + (0 if x2 is None else x2.numel()) + pc.w.numel()) * esz + out.numel() * out.element_size() \
-        + (0 if residual is None else residual.numel() * esz)
-    lib = L.load()
     _launch(variant, flops, nbytes, lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
     return out
 

@@ -68,9 +68,13 @@ class ResnetBlock(nn.Module):
     def run(self, rt, x, norm1_stats=None, norm2_stats=None):
         """``norm*_stats``: optional externally supplied (mean, var) ``[B,32,2]`` — the tiled VAE's
         cross-tile GroupNorm statistics (utils/tilevae.py:599-674)."""
+        skip = ops.conv2d(x, rt.pk(self.nin_shortcut), pad=0) if self.in_channels != self.out_channels else x
+        if norm1_stats is None and norm2_stats is None:   # GN+swish fused into each conv's input staging
+            n1, n2 = self.norm1, self.norm2
+            h = ops.conv2d(x, rt.pk(self.conv1), pad=1, norm=(n1.weight, n1.bias, n1.num_groups, n1.eps, True))
+            return ops.conv2d(h, rt.pk(self.conv2), pad=1, residual=skip, norm=(n2.weight, n2.bias, n2.num_groups, n2.eps, True))
         h = _gn(x, self.norm1, True, norm1_stats)
         h = ops.conv2d(h, rt.pk(self.conv1), pad=1)
-        skip = ops.conv2d(x, rt.pk(self.nin_shortcut), pad=0) if self.in_channels != self.out_channels else x
         h = _gn(h, self.norm2, True, norm2_stats)
         return ops.conv2d(h, rt.pk(self.conv2), pad=1, residual=skip)
 
@@ -170,8 +174,8 @@ class Encoder(_VAEHalf):
         h = self.mid.block_1.run(self, h)
         h = self.mid.attn_1.run(self, h)
         h = self.mid.block_2.run(self, h)
-        h = _gn(h, self.norm_out, True)
-        return ops.conv2d(h, self.pk(self.conv_out), pad=1)
+        n = self.norm_out
+        return ops.conv2d(h, self.pk(self.conv_out), pad=1, norm=(n.weight, n.bias, n.num_groups, n.eps, True))
 
 
 class Decoder(_VAEHalf):
@@ -227,5 +231,5 @@ class Decoder(_VAEHalf):
                 h = self.up[i_level].upsample.run(self, h)
         if self.give_pre_end:
             return h
-        h = _gn(h, self.norm_out, True)
-        return ops.conv2d(h, self.pk(self.conv_out), pad=1, out_f32=True)
+        n = self.norm_out
+        return ops.conv2d(h, self.pk(self.conv_out), pad=1, out_f32=True, norm=(n.weight, n.bias, n.num_groups, n.eps, True))

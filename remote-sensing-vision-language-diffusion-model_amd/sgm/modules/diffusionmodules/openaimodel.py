@@ -92,14 +92,14 @@ class ResBlock(TimestepBlock):
     def run(self, rt, x, emb_rows):
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
         gn2, conv2 = self.out_layers[0], self.out_layers[3]
-        h = ops.group_norm(x, gn1.weight, gn1.bias, gn1.num_groups, gn1.eps, silu=True)
-        h = ops.conv2d(h, rt.pk(conv1), pad=conv1.padding[0], rowvec=emb_rows[id(self)])
+        h = ops.conv2d(x, rt.pk(conv1), pad=conv1.padding[0], rowvec=emb_rows[id(self)],
+                       norm=(gn1.weight, gn1.bias, gn1.num_groups, gn1.eps, True))
         if isinstance(self.skip_connection, nn.Conv2d):
             skip = ops.conv2d(x, rt.pk(self.skip_connection), pad=self.skip_connection.padding[0])
         else:
             skip = x
-        h = ops.group_norm(h, gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, silu=True)
-        return ops.conv2d(h, rt.pk(conv2), pad=conv2.padding[0], residual=skip)
+        return ops.conv2d(h, rt.pk(conv2), pad=conv2.padding[0], residual=skip,
+                          norm=(gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, True))
 
 
 class UNetModel(HipNet):
@@ -212,8 +212,8 @@ class UNetModel(HipNet):
 
     def run_out(self, h):
         gn, conv = self.out[0], self.out[2]
-        h = ops.group_norm(h, gn.weight, gn.bias, gn.num_groups, gn.eps, silu=True)
-        return ops.conv2d(h, self.pk(conv), pad=conv.padding[0], out_f32=True)
+        return ops.conv2d(h, self.pk(conv), pad=conv.padding[0], out_f32=True,
+                          norm=(gn.weight, gn.bias, gn.num_groups, gn.eps, True))
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """Plain SDXL UNet forward (openaimodel.py:968-1010) on NHWC 16-bit ``x``; skip connections are

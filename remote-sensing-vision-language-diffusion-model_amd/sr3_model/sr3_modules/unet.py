@@ -216,9 +216,11 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------ forward pieces
     def _block(self, blk, x, x2=None, **conv_kw):
+        """GN(32)+Swish+Conv3x3 as ONE fused conv call: statistics pass + conv with the normalisation applied
+        while the input patch is staged (ops.conv2d norm=...); the skip concat [x | x2] is never built."""
         gn = blk.block[0]
-        h = ops.group_norm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, x2=x2, silu=True)
-        return ops.conv2d(h, self._pk[id(blk.block[3])], **conv_kw)
+        return ops.conv2d(x, self._pk[id(blk.block[3])], x2=x2, norm=(gn.weight, gn.bias, gn.num_groups, gn.eps, True),
+                          **conv_kw)
 
     def _resblock(self, layer, x, x2, nf_all):
         rb = layer.res_block

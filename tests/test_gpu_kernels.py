@@ -64,6 +64,54 @@ def test_conv2d(cuda, dtype, case):
     _close(got.permute(0, 3, 1, 2), want, dtype)
 
 
+HALO_CASES = [
+    # B, C1, C2, Cout, H, W, fuse_norm
+    (2, 64, 0, 64, 16, 32, True),       # exact 8x32 tiles, BN = 64
+    (1, 128, 0, 128, 19, 45, True),     # ragged H and W, BN = 128
+    (2, 128, 64, 256, 9, 33, True),     # two-source (skip concat) + fused GN whose groups straddle the sources
+    (1, 320, 0, 320, 8, 16, True),      # W = 16 (half-filled tile), 5 channel chunks
+    (1, 64, 0, 8, 24, 40, True),        # final conv: Cout 3 padded to 8
+    (1, 192, 0, 64, 12, 64, False),     # plain 3x3 conv through the halo kernel (no norm)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_fused_groupnorm(cuda, dtype, case):
+    """conv_halo.hip: GN(32)+SiLU applied while the input patch is staged, 9 taps from LDS; vs torch fp32."""
+    from rsvld_amd import ops
+    B, C1, C2, Cout, H, W, fuse = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x1 = _rt(torch.randn(B, C1, H, W, generator=g) * 1.5 + 0.3, dtype)
+    x2 = _rt(torch.randn(B, C2, H, W, generator=g), dtype) if C2 else None
+    Ct = C1 + C2
+    w = _rt(torch.randn(Cout, Ct, 3, 3, generator=g) / math.sqrt(Ct * 9), dtype)
+    b = torch.randn(Cout, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(Ct, generator=g), 0.1 * torch.randn(Ct, generator=g)
+    rv = torch.randn(B, pad8 := (Cout + 7) // 8 * 8, generator=g)
+    res = _rt(torch.randn(B, Cout, H, W, generator=g), dtype)
+    xc = x1 if x2 is None else torch.cat([x1, x2], 1)
+    xin = F.silu(F.group_norm(xc, 32, gamma, beta, eps=1e-5)) if fuse else xc
+    want = F.conv2d(xin, w, b, padding=1) + rv[:, :Cout, None, None] + res
+    pc = ops.pack_conv(w, b, dtype, cuda)
+    resp = torch.zeros(B, H, W, pad8, dtype=dtype)
+    resp[..., :Cout] = res.permute(0, 2, 3, 1)
+    norm = (gamma.to(cuda), beta.to(cuda), 32, 1e-5, True) if fuse else None
+    ops.HALO_MIN_WGS = 0   # force the halo kernel at test sizes
+    got = ops.conv2d(_nhwc(x1, dtype, cuda), pc, x2=None if x2 is None else _nhwc(x2, dtype, cuda), pad=1,
+                     rowvec=rv.to(cuda), residual=resp.to(cuda), norm=norm)
+    _close(got[..., :Cout].permute(0, 3, 1, 2), want, dtype)
+    # the same call through the gather kernel (unfused norm) must agree with the fused path
+    ops.USE_HALO = False
+    try:
+        ref = ops.conv2d(_nhwc(x1, dtype, cuda), pc, x2=None if x2 is None else _nhwc(x2, dtype, cuda), pad=1,
+                         rowvec=rv.to(cuda), residual=resp.to(cuda), norm=norm)
+    finally:
+        ops.USE_HALO = True
+        ops.HALO_MIN_WGS = 256
+    _close(got.float(), ref.float().cpu(), dtype, scale=float(want.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_epilogue_rowvec_residual_concat(cuda, dtype):
     from rsvld_amd import ops
