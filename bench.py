@@ -86,8 +86,77 @@ def cpu_baseline(side, T, steps_sampled=2):
                       f"({dt:.2f} s/step, {ncores} threads of {avail} schedulable cores), extrapolated linearly to {T} steps"}
 
 
+def bench_stage2(args, dev, rank, world):
+    """Secondary workload (not the contract line): Stage 2 only — BASELINE configs[2] shape family:
+    full juggernautXL.yaml networks (UNet 2.6 B + ControlNet 1.2 B params, seeded random init with the
+    zero-initialised tensors re-drawn), cached text embeddings (PreparedConditioner), 50 EDM steps,
+    CFG 4.0->7.5 linear, s_churn 5, feature cache threshold 0.3, Wavelet colour fix, untiled VAE."""
+    import yaml
+    from oracle import seeded
+    from rsvld_amd.sgm.util import instantiate_from_config
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "remote-sensing-vision-language-diffusion-model_amd", "model_configs",
+                                           "juggernautXL.yaml")))["model"]["params"]
+    g2, g3 = torch.Generator().manual_seed(2), torch.Generator().manual_seed(3)
+    cfg["conditioner_config"]["params"] = {
+        "cond_pth": {"crossattn": torch.randn(1, 77, 2048, generator=g2), "vector": torch.randn(1, 2816, generator=g2)},
+        "un_cond_pth": {"crossattn": torch.randn(1, 77, 2048, generator=g3), "vector": torch.randn(1, 2816, generator=g3)}}
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    m = instantiate_from_config({"target": "rsvld_amd.models.SR_model.SR_backbone", "params": cfg})
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p_ in m.parameters():                  # zero_module() outputs would make the network output 0
+            if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
+    m.to(dev).eval()
+    side = args.s2_side
+    img = torch.cat([seeded.synthetic_image((1, 3, side, side), seed=1234 + rank * args.batch + i, smooth=4)
+                     for i in range(args.batch)]).to(dev)
+    thr = args.s2_threshold if args.batch == 1 else 0.0
+    kw = dict(p_p="", n_p="", img_threshold=thr, dec_img=1.0, num_steps=args.ddpm_steps, restoration_scale=-1,
+              s_churn=5, s_noise=1.003, cfg_scale=7.5, control_scale=1.0, color_fix_type="Wavelet", use_linear_CFG=True,
+              cfg_scale_start=4.0)
+    build_s = time.perf_counter() - t0
+
+    def one_pass():
+        return m.just_sampling(img, [""] * args.batch, **kw)
+
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    from rsvld_amd import ops
+    prof = ops.LaunchProfiler()
+    ops.set_profiler(prof)
+    one_pass()
+    torch.cuda.synchronize()
+    ops.set_profiler(None)
+    summ = prof.summary()
+    L = side // 8
+    tf_step = {64: 4.76, 128: 20.3, 256: 107.8, 512: 865.9}.get(L)
+    line = {"metric": "Stage-2 images/sec (secondary workload)", "value": round(args.batch * args.steps / dt, 4), "unit": "img/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 1),
+            "dtype": "f16 (UNet/ControlNet), bf16 (VAE)", "data": "synthetic",
+            "config": {"workload": f"Stage 2 only, {side}x{side} input (latent {L}), batch {args.batch}, {args.ddpm_steps} EDM steps, "
+                                   f"cache threshold {thr}, Wavelet, untiled VAE, full juggernautXL.yaml sizes",
+                       "model_build_s": round(build_s, 1), "finite": bool(torch.isfinite(out).all()),
+                       "algorithmic_tflops_no_cache": None if tf_step is None else round(
+                           tf_step * args.ddpm_steps * args.batch * args.steps / dt, 1)},
+            "by_kernel": {k: {"ms": round(v["ms"], 1), "n": v["n"],
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
+                          for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c2", choices=["c2", "s2"], help="c2 = the contract line (default); s2 = Stage-2 secondary")
+    ap.add_argument("--s2-side", type=int, default=1024)
+    ap.add_argument("--s2-threshold", type=float, default=0.3)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -106,6 +175,10 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.workload == "s2":
+        if args.batch == 4 and "--batch" not in " ".join(sys.argv):
+            args.batch = 1
+        return bench_stage2(args, dev, rank, world)
     side = args.lr_side * args.scale
     T = args.ddpm_steps
 

@@ -416,6 +416,13 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
         return launch_conv<T, 128, 64, 4, 1, GLDS>(a, s);
     }
     const int64_t wg128 = (int64_t)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+    const int64_t wg64x128 = (int64_t)((a.M + 63) / 64) * ((a.Cout + 127) / 128);
+    if constexpr (GLDS) {
+        // small-M linears (Stage-2 transformer blocks at 16x16 / 32x32 tokens): even 64x128 leaves most CUs idle and
+        // the K loop is a latency-bound weight stream.  64x64 tiles double the grid again; 4 x 16 KiB stages keep
+        // 3 tiles in flight per workgroup at 2 workgroups per CU.
+        if (ov == 0 && wg64x128 < 256) return launch_conv<T, 64, 64, 2, 2, true, 4>(a, s);
+    }
     if (ov == 4 || (ov == 0 && wg128 < 256)) {
         if constexpr (GLDS) {
             if (st == 3 || st == 0) return launch_conv<T, 64, 128, 2, 2, true, 3>(a, s);   // 72 KiB: 2 WGs / CU

@@ -215,7 +215,8 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         variant = "conv_igemm_128x64"
     else:   # mirrors dispatch_conv2 in csrc/conv_igemm.hip
         wg128 = ((B * Ho * Wo + 127) // 128) * ((pc.cout_p + 127) // 128)
-        variant = "conv_igemm_64x128" if wg128 < 256 else "conv_igemm_128x128"
+        wg64 = ((B * Ho * Wo + 63) // 64) * ((pc.cout_p + 127) // 128)
+        variant = "conv_igemm_64x64" if wg64 < 256 else ("conv_igemm_64x128" if wg128 < 256 else "conv_igemm_128x128")
     _launch(variant, flops, nbytes, lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
     return out
 
