@@ -27,7 +27,8 @@ struct HaloArgs {
     const void* residual;
     void* out;
     const float* ab;     // [B][Cin+Cin2][2] = (scale, shift) of the fused GroupNorm, or nullptr
-    int B, H, W, Cin, Cin2, Cout;
+    int B, H, W, Cin, Cin2, Cout;   // H, W: OUTPUT map (= input map, or 2x the input when ush = 1)
+    int Hs, Ws, ush;                // source map and the nearest-x2 shift
     int out_f32, act, norm_silu;
     float alpha, beta;
     int Ctot, nchunks;   // channels, 64-channel chunks
@@ -86,10 +87,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
         const int pp = (tid >> 3) + 32 * i;
         const int py = pp / PW, px = pp - py * PW;
         const int y = y0 - 1 + py, x = x0 - 1 + px;
-        poff[i] = (pp < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? y * p.W + x : -1;
+        // with ush = 1 the conv runs on the nearest-x2 up-sampled map: output-grid pixel (y, x) reads source (y>>1, x>>1)
+        poff[i] = (pp < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y >> p.ush) * p.Ws + (x >> p.ush) : -1;
     }
-    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.H * p.W * p.Cin;
-    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.H * p.W * p.Cin2 : nullptr;
+    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * p.Cin;
+    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * p.Cin2 : nullptr;
     const T* __restrict__ Wp = (const T*)p.w;
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
@@ -153,45 +155,44 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-    load_patch(0);
-    dma_w(0, 0, 0);
-    store_patch(0);
-    __syncthreads();   // patch written, weights of step 0 landed (vmcnt(0) + barrier)
-
+    // Loop structure.  hipcc drains vmcnt(0) in front of the first ds_read of a loop body whenever ordinary
+    // (VGPR-destination) global loads are live across iterations next to LDS-DMA (cdna_hip_programming.md §5
+    // "Three .s-level traps" (b)); measured here as a full weight-DMA round trip exposed on EVERY tap.  So the tap
+    // loop contains LDS-DMA only; the register-staged patch phase (load -> normalise -> ds_write) runs between
+    // chunks, while the first tap's weight slice of that chunk is already in flight.
     const int nsteps = p.nchunks * 9;
-    int kc = 0, tap = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        // next step's weights stream in behind this step's MFMAs
-        const int ntap = tap == 8 ? 0 : tap + 1;
-        const int nkc = tap == 8 ? kc + 1 : kc;
-        if (s + 1 < nsteps) dma_w(nkc, ntap, (s + 1) & 1);
-        if (tap == 6 && kc + 1 < p.nchunks) load_patch(kc + 1);   // next chunk's patch: global loads in flight
-
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const char* w_s = wbuf + (s & 1) * W_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int ch = 2 * ks + lh;
-            v8 fa[TN], fb[TM];
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + swz_off(wn * (TN * 32) + ni * 32 + l31, ch));
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int pr = (wm * TM + mi + ky) * PW + l31 + kx;     // shifted window of the same patch
-                fb[mi] = *(const v8*)(patch + swz_off(pr, ch));
+    int s = 0;
+    dma_w(0, 0, 0);
+    for (int kc = 0; kc < p.nchunks; ++kc) {
+        load_patch(kc);
+        store_patch(kc);
+        __syncthreads();   // patch visible; weights of (kc, tap 0) landed (vmcnt(0) + barrier)
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            if (s + 1 < nsteps) {   // next step's weights stream in behind this step's MFMAs
+                if (tap == 8) dma_w(kc + 1, 0, (s + 1) & 1);
+                else dma_w(kc, tap + 1, (s + 1) & 1);
             }
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const char* w_s = wbuf + (s & 1) * W_BYTES;
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ch = 2 * ks + lh;
+                v8 fa[TN], fb[TM];
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
+                for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + swz_off(wn * (TN * 32) + ni * 32 + l31, ch));
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int pr = (wm * TM + mi + ky) * PW + l31 + kx;     // shifted window of the same patch
+                    fb[mi] = *(const v8*)(patch + swz_off(pr, ch));
+                }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
+            }
+            __syncthreads();   // next weights landed; everyone done with this step's weights (at tap 8: with the patch)
         }
-        __syncthreads();   // everyone done with this step's weights (and, at tap 8, with the patch)
-        if (tap == 8 && kc + 1 < p.nchunks) {
-            store_patch(kc + 1);
-            __syncthreads();
-        }
-        tap = ntap;
-        kc = nkc;
     }
 
     // ---- epilogue through LDS (fp32), EPI_PASSES passes of EPI_ROWS pixels
@@ -288,12 +289,13 @@ int dispatch_halo(const HaloArgs& a, hipStream_t s) {
 // 3x3 / stride 1 / pad 1, no up-sampling, every source a multiple of 64 channels
 extern "C" int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d) {
     if (d == nullptr) return 0;
-    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->upsample) return 0;
-    if (d->Ho != d->H || d->Wo != d->W) return 0;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1) return 0;
+    const int up = d->upsample ? 2 : 1;
+    if (d->Ho != up * d->H || d->Wo != up * d->W) return 0;
     if (d->Cin % 64 != 0 || d->Cin2 % 64 != 0) return 0;
     if (d->act == RSVLD_ACT_GEGLU) return 0;
     if (d->out_f32 && d->Cout > 32) return 0;
-    if (d->W < 16 || d->H < 4) return 0;   // tiny maps: the 8x32 tile would be mostly padding
+    if (d->Wo < 16 || d->Ho < 4) return 0;   // tiny maps: the 8x32 tile would be mostly padding
     return 1;
 }
 
@@ -303,17 +305,19 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     if (d->B <= 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
     if ((d->Cin2 > 0) != (d->x2 != nullptr)) return RSVLD_EINVAL;
     if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16) return RSVLD_EINVAL;
-    if ((int64_t)d->H * d->W >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
+    if ((int64_t)d->Ho * d->Wo >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
+    if (norm_scale_shift != nullptr && d->upsample) return RSVLD_EUNSUPPORTED;   // no GroupNorm sits before an Upsample conv
     HaloArgs a;
     a.x = d->x; a.x2 = d->x2; a.w = d->w; a.bias = d->bias; a.rowvec = d->rowvec; a.residual = d->residual; a.out = d->out;
     a.ab = norm_scale_shift;
-    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
+    a.B = d->B; a.H = d->Ho; a.W = d->Wo; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
+    a.Hs = d->H; a.Ws = d->W; a.ush = d->upsample ? 1 : 0;
     a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.norm_silu = norm_silu ? 1 : 0;
     a.alpha = d->alpha; a.beta = d->beta;
     a.Ctot = d->Cin + d->Cin2;
     a.nchunks = a.Ctot / 64;
-    a.tiles_x = (d->W + TW - 1) / TW;
-    a.tiles_y = (d->H + TH - 1) / TH;
+    a.tiles_x = (d->Wo + TW - 1) / TW;
+    a.tiles_y = (d->Ho + TH - 1) / TH;
     a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
     a.Cout_out = d->Cout;
     hipStream_t s = (hipStream_t)stream;

@@ -185,7 +185,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
     if halo:
         bn = 64 if pc.cout_p <= 64 else 128
-        halo = B * ((H + 7) // 8) * ((W + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= HALO_MIN_WGS
+        halo = B * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= HALO_MIN_WGS and not (upsample and norm is not None)
     if norm is not None and not halo:   # unfused: normalise into a (single) tensor, then convolve it
         gamma, nbeta, groups, eps, silu = norm
         xn = group_norm(x, gamma, nbeta, groups, eps, x2=x2, silu=silu)

@@ -113,6 +113,24 @@ def test_conv3x3_halo_fused_groupnorm(cuda, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_halo_fused_upsample(cuda, dtype):
+    """nearest x2 folded into the halo patch staging (Upsample modules of all three networks)."""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = _rt(torch.randn(2, 128, 9, 21, generator=g), dtype)
+    w = _rt(torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(128 * 9), dtype)
+    b = torch.randn(128, generator=g) * 0.1
+    want = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    ops.HALO_MIN_WGS = 0
+    try:
+        got = ops.conv2d(_nhwc(x, dtype, cuda), ops.pack_conv(w, b, dtype, cuda), pad=1, upsample=True)
+    finally:
+        ops.HALO_MIN_WGS = 256
+    assert got.shape == (2, 18, 42, 128)
+    _close(got.permute(0, 3, 1, 2), want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_epilogue_rowvec_residual_concat(cuda, dtype):
     from rsvld_amd import ops
     g = torch.Generator().manual_seed(5)
