@@ -33,10 +33,13 @@ constexpr int A5_SP = 65536;
 constexpr int A5_SP_STRIDE = 36;  // floats per (wave,q) row: 32 + 4 pad -> conflict-free b128 writes
 constexpr int A5_PS = A5_SP + 4 * 64 * A5_SP_STRIDE * 4;
 constexpr int A5_AL = A5_PS + 64 * 64;
-constexpr int A5_SMEM = A5_AL + 2 * 64 * 4;
+constexpr int A5_SMEM = A5_AL + 2 * 64 * 4 + 2 * 16;   // + two rescale flags (ping-pong)
+constexpr float A5_DEFER_LOG2 = 8.0f;   // rescale O only when a row's running max grows by more than 2^8
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_d512_kernel(AttnArgs p) {
+__global__ __launch_bounds__(512) void attn_d512_kernel(AttnArgs p) {
+    // 8 waves: wave = (query half qh, d-slice dw).  Two waves share each SIMD, so one wave's LDS / barrier waits
+    // are covered by the other's MFMAs; per wave: 32 query rows x 128 head dims of O (64 accumulator registers).
     constexpr int D = 512;
     typedef typename Mfma<T>::v8 v8;
     typedef typename Mfma<T>::v4 v4;
@@ -47,8 +50,10 @@ __global__ __launch_bounds__(256) void attn_d512_kernel(AttnArgs p) {
     char* Ps = smem + A5_PS;
     float* alpha_s = (float*)(smem + A5_AL);
     float* l_s = alpha_s + 64;
+    int* resc_flag = (int*)(l_s + 64);   // [2]: any row of this tile rescaled? (ping-pong so the reset never races)
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
+    const int dw = w8 & 3, qh = w8 >> 2;
     const int l31 = lane & 31, lh = lane >> 5;
     const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const T* Qb = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
@@ -57,45 +62,43 @@ __global__ __launch_bounds__(256) void attn_d512_kernel(AttnArgs p) {
     T* Ob = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)h * D;
 
     // Q fragments (MFMA B operand: col = query row on the lane, k = d)
-    v8 qf[2][8];
+    v8 qf[8];
+    const int qrow = q0 + qh * 32 + l31;
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int row = q0 + qt * 32 + l31;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < p.Nq) v = *(const u32x4*)(Qb + (int64_t)row * p.q_ts + w * 128 + ks * 16 + lh * 8);
-            qf[qt][ks] = __builtin_bit_cast(v8, v);
-        }
-
-    f32x16 oacc[4][2];
+    for (int ks = 0; ks < 8; ++ks) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (qrow < p.Nq) v = *(const u32x4*)(Qb + (int64_t)qrow * p.q_ts + dw * 128 + ks * 16 + lh * 8);
+        qf[ks] = __builtin_bit_cast(v8, v);
+    }
+    f32x16 oacc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][qt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
 
-    // softmax role: row sq, 8 keys starting at 8*part
-    const int sq = tid >> 2, part = tid & 3;
+    // softmax role: row sq, 4 keys starting at 4*part (8 threads per row)
+    const int sq = tid >> 3, part = tid & 7;
     float m_run = -INFINITY, l_run = 0.f;
+    if (tid < 2) resc_flag[tid] = 0;
 
-    // staging roles
-    const int kvb = tid & 3, db = tid >> 2;
-    u32x4 rk[8], rv[8];
-    auto load_kv = [&](int t) {
+    // staging roles.  K: 4 x 16 B per thread.  V: a 4(kv) x 8(d) micro-block per thread, transposed in registers.
+    const int kvb = tid & 7, db = tid >> 3;
+    u32x4 rk[4], rv[4];
+    auto load_k = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
             const int row = idx >> 6, ch = idx & 63;
             const int kv = t * 32 + row;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (kv < p.Nk) v = *(const u32x4*)(Kb + (int64_t)kv * p.k_ts + ch * 8);
             rk[i] = v;
         }
+    };
+    auto load_v = [&](int t) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int kv = t * 32 + kvb * 8 + r;
+        for (int r = 0; r < 4; ++r) {
+            const int kv = t * 32 + kvb * 4 + r;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (kv < p.Nk) v = *(const u32x4*)(Vb + (int64_t)kv * p.v_ts + db * 8);
             rv[r] = v;
@@ -103,119 +106,126 @@ __global__ __launch_bounds__(256) void attn_d512_kernel(AttnArgs p) {
     };
     auto store_k = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
             const int row = idx >> 6, ch = idx & 63;
             *(u32x4*)(Ks + row * 1024 + ((ch ^ (row & 15)) << 4)) = rk[i];
         }
     };
     auto store_v = [&]() {
-        v8 vin[8];
+        v8 vin[4];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) vin[r] = __builtin_bit_cast(v8, rv[r]);
+        for (int r = 0; r < 4; ++r) vin[r] = __builtin_bit_cast(v8, rv[r]);
 #pragma unroll
         for (int dd = 0; dd < 8; ++dd) {
-            v8 o;
+            v4 o;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) o[r] = vin[r][dd];
+            for (int r = 0; r < 4; ++r) o[r] = vin[r][dd];
             const int d = db * 8 + dd;
-            *(v8*)(VTs + d * 64 + ((kvb ^ ((d >> 2) & 3)) << 4)) = o;
+            *(v4*)(VTs + d * 64 + (((kvb >> 1) ^ ((d >> 2) & 3)) << 4) + (kvb & 1) * 8) = o;
         }
     };
 
+    // Prefetch distances: the K registers are free as soon as a K tile has been written to LDS (after barrier A),
+    // so K(t+2) is requested a full tile ahead; V(t+1) is requested at the top of tile t and consumed after barrier C.
     const int ntiles = (p.Nk + 31) / 32;
-    load_kv(0);
+    load_k(0);
+    load_v(0);
     store_k();
     store_v();
     __syncthreads();
+    if (ntiles > 1) load_k(1);
 
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles;
-        if (more) load_kv(t + 1);
+        if (more) load_v(t + 1);
 
         // ---- S phase: partial S^T[kv][q] over this wave's d-slice
-        f32x16 sacc[2];
+        f32x16 sacc;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[qt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const int ch = w * 16 + ks * 2 + lh;
+            const int ch = dw * 16 + ks * 2 + lh;
             const v8 kf = *(const v8*)(Ks + l31 * 1024 + ((ch ^ (l31 & 15)) << 4));
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) sacc[qt] = Mfma<T>::mma(kf, qf[qt][ks], sacc[qt]);
+            sacc = Mfma<T>::mma(kf, qf[ks], sacc);
         }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int qq = qt * 32 + l31;
-                const int kvc = 8 * g + 4 * lh;
-                f32x4 v = {sacc[qt][4 * g], sacc[qt][4 * g + 1], sacc[qt][4 * g + 2], sacc[qt][4 * g + 3]};
-                *(f32x4*)(Sp + (w * 64 + qq) * A5_SP_STRIDE + kvc) = v;
-            }
+        for (int g = 0; g < 4; ++g) {
+            const int qq = qh * 32 + l31;
+            const int kvc = 8 * g + 4 * lh;
+            f32x4 v = {sacc[4 * g], sacc[4 * g + 1], sacc[4 * g + 2], sacc[4 * g + 3]};
+            *(f32x4*)(Sp + (dw * 64 + qq) * A5_SP_STRIDE + kvc) = v;
+        }
         __syncthreads();  // (A) partial scores visible; K tile free
-        if (more) store_k();
+        if (more) {
+            store_k();
+            if (t + 2 < ntiles) load_k(t + 2);
+        }
 
-        // ---- softmax over the 32 keys of this tile (4 threads per row)
+        // ---- softmax over the 32 keys of this tile (8 threads per row, 4 keys each)
         {
-            float s[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] = 0.f;
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) {
-                const float* src = Sp + (ww * 64 + sq) * A5_SP_STRIDE + part * 8;
-                const f32x4 a = *(const f32x4*)src;
-                const f32x4 c = *(const f32x4*)(src + 4);
+                const f32x4 a = *(const f32x4*)(Sp + (ww * 64 + sq) * A5_SP_STRIDE + part * 4);
                 s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3];
-                s[4] += c[0]; s[5] += c[1]; s[6] += c[2]; s[7] += c[3];
             }
             float mx = -INFINITY;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int kv = t * 32 + part * 8 + e;
+            for (int e = 0; e < 4; ++e) {
+                const int kv = t * 32 + part * 4 + e;
                 s[e] = kv < p.Nk ? s[e] * p.scale_log2e : -INFINITY;
                 mx = fmaxf(mx, s[e]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 1));
             mx = fmaxf(mx, __shfl_xor(mx, 2));
-            const float m_new = fmaxf(m_run, mx);
-            const float a = exp2f(m_run - m_new);
-            float pr[8], rs = 0.f;
+            mx = fmaxf(mx, __shfl_xor(mx, 4));
+            // Deferred max (cdna_hip_programming.md T13): the reference point m_run of a row only moves when the
+            // tile's max exceeds it by more than 2^8, so the rescale of O (accumulators live in AGPRs: every VALU
+            // touch costs accvgpr read+write) is skipped on almost every tile.  Softmax is invariant to the
+            // reference point; P <= 2^8 stays exact enough in 16-bit, l and O are fp32.
+            float a = 1.0f;
+            if (mx > m_run + A5_DEFER_LOG2) {     // also true on the first tile (m_run = -inf)
+                a = exp2f(m_run - mx);
+                m_run = mx;
+                resc_flag[t & 1] = 1;
+            }
+            float pr[4], rs = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { pr[e] = exp2f(s[e] - m_new); rs += pr[e]; }
+            for (int e = 0; e < 4; ++e) { pr[e] = exp2f(s[e] - m_run); rs += pr[e]; }
             rs += __shfl_xor(rs, 1);
             rs += __shfl_xor(rs, 2);
+            rs += __shfl_xor(rs, 4);
             l_run = l_run * a + rs;
-            m_run = m_new;
-            *(u32x4*)(Ps + sq * 64 + ((part ^ ((sq >> 2) & 3)) << 4)) = pack8<T>(pr);
+            v4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (T)pr[e];
+            *(v4*)(Ps + sq * 64 + (((part >> 1) ^ ((sq >> 2) & 3)) << 4) + (part & 1) * 8) = pk;
             if (part == 0) alpha_s[sq] = a;
+            if (tid == 0) resc_flag[(t + 1) & 1] = 0;   // next tile's flag; nobody reads it before barrier (B) of t+1
         }
         __syncthreads();  // (B) P and rescale factors visible
 
         // ---- PV phase: O^T[d][q] = alpha*O^T + V^T P^T over this wave's d-slice
         {
-            const float a0 = alpha_s[l31], a1 = alpha_s[32 + l31];
+            if (resc_flag[t & 1] != 0) {   // workgroup-uniform (LDS word written before barrier B)
+                const float a0 = alpha_s[qh * 32 + l31];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+                for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { oacc[dt][0][r] *= a0; oacc[dt][1][r] *= a1; }
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= a0;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int ch = 2 * ks + lh;
-                v8 pf[2];
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    const int qq = qt * 32 + l31;
-                    pf[qt] = *(const v8*)(Ps + qq * 64 + ((ch ^ ((qq >> 2) & 3)) << 4));
-                }
+                const int qq = qh * 32 + l31;
+                const v8 pf = *(const v8*)(Ps + qq * 64 + ((ch ^ ((qq >> 2) & 3)) << 4));
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const int d = w * 128 + dt * 32 + l31;
+                    const int d = dw * 128 + dt * 32 + l31;
                     const v8 vf = *(const v8*)(VTs + d * 64 + ((ch ^ ((d >> 2) & 3)) << 4));
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = Mfma<T>::mma(vf, pf[qt], oacc[dt][qt]);
+                    oacc[dt] = Mfma<T>::mma(vf, pf, oacc[dt]);
                 }
             }
         }
@@ -225,23 +235,24 @@ __global__ __launch_bounds__(256) void attn_d512_kernel(AttnArgs p) {
 
     if (part == 0) l_s[sq] = l_run;
     __syncthreads();
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int row = q0 + qt * 32 + l31;
-        if (row >= p.Nq) continue;
-        const float inv = 1.0f / l_s[qt * 32 + l31];
+    if (qrow < p.Nq) {
+        const float inv = 1.0f / l_s[qh * 32 + l31];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 v4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (T)(oacc[dt][qt][4 * g + e] * inv);
-                const int d = w * 128 + dt * 32 + 8 * g + 4 * lh;
-                *(v4*)(Ob + (int64_t)row * p.o_ts + d) = o;
+                for (int e = 0; e < 4; ++e) o[e] = (T)(oacc[dt][4 * g + e] * inv);
+                const int d = dw * 128 + dt * 32 + 8 * g + 4 * lh;
+                *(v4*)(Ob + (int64_t)qrow * p.o_ts + d) = o;
             }
     }
 }
+
+}  // namespace
+
+namespace {
 
 // ---------------------------------------------------------------------------------------
 // D = 64 (multi-head: sgm CrossAttention / MemoryEfficientCrossAttention, ZeroCrossAttn)
@@ -472,7 +483,7 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
                     return RSVLD_ELAUNCH;
                 set = true;
             }
-            hipLaunchKernelGGL(attn_d512_kernel<f16>, grid, dim3(256), A5_SMEM, s, a);
+            hipLaunchKernelGGL(attn_d512_kernel<f16>, grid, dim3(512), A5_SMEM, s, a);
         } else {
             static bool set = false;
             if (!set) {
@@ -481,7 +492,7 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
                     return RSVLD_ELAUNCH;
                 set = true;
             }
-            hipLaunchKernelGGL(attn_d512_kernel<bf16>, grid, dim3(256), A5_SMEM, s, a);
+            hipLaunchKernelGGL(attn_d512_kernel<bf16>, grid, dim3(512), A5_SMEM, s, a);
         }
         return rsvld_check_launch();
     }
