@@ -81,9 +81,13 @@ int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
  * y = act(scale*x + shift) (act = SiLU if norm_silu) applied while the patch is staged, so the
  * normalised tensor is never written to HBM.  Same descriptor / epilogue as rsvld_conv2d_nhwc.
  * rsvld_conv3x3_halo_supported tells whether a descriptor is eligible (1) or must use the gather kernel (0).
- * Replaces GN+SiLU+Conv3x3 of unet.py:81-92, openaimodel.py:263-301, model.py:128-141. */
+ * Replaces GN+SiLU+Conv3x3 of unet.py:81-92, openaimodel.py:263-301, model.py:128-141.
+ * out_stats_partials (optional, fp32 [B][ceil(Ho/8)*ceil(Wo/32)][Cout][2]): per-tile per-channel (sum, sum of squares)
+ * of the stored output, produced in the epilogue, so that the NEXT GroupNorm needs no pass over the tensor
+ * (consumed by rsvld_groupnorm_scale_shift_from_partials).  Deterministic: plain stores, merged later in fp64. */
 int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d);
-int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* norm_scale_shift, int norm_silu, void* stream);
+int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* norm_scale_shift, int norm_silu,
+                            float* out_stats_partials, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU / Swish) over NHWC, statistics in fp32, two launches
@@ -122,6 +126,12 @@ int rsvld_groupnorm_apply(const void* x, const void* x2, void* y, const float* m
 int rsvld_groupnorm_scale_shift(const void* x, const void* x2, const float* gamma, const float* beta,
                                 float* scale_shift, int B, int HW, int C1, int C2, int groups, float eps,
                                 int dtype, void* ws, void* stream);
+
+/* same affine from per-channel partial sums written by conv epilogues (one or two producers: [x | x2]) */
+int rsvld_groupnorm_scale_shift_from_partials(const float* part1, int ntiles1, int C1,
+                                              const float* part2, int ntiles2, int C2,
+                                              const float* gamma, const float* beta, float* scale_shift,
+                                              int B, int HW, int groups, float eps, void* stream);
 
 /* LayerNorm over the last dim of [rows, C] (eps 1e-5, affine).  attention.py:376-486 */
 int rsvld_layernorm(const void* x, void* y, const float* gamma, const float* beta,

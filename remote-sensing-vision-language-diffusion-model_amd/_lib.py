@@ -40,7 +40,8 @@ SIGNATURES = {
     "rsvld_version": (C.c_char_p, []),
     "rsvld_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
     "rsvld_conv3x3_halo_supported": (_i, [C.POINTER(ConvDesc)]),
-    "rsvld_conv3x3_halo_nhwc": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp]),
+    "rsvld_conv3x3_halo_nhwc": (_i, [C.POINTER(ConvDesc), _vp, _i, _vp, _vp]),
+    "rsvld_groupnorm_scale_shift_from_partials": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "rsvld_groupnorm_scale_shift": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "rsvld_groupnorm_ws_bytes": (_i64, [_i, _i, _i, _i]),
     "rsvld_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp]),

@@ -27,6 +27,7 @@ struct HaloArgs {
     const void* residual;
     void* out;
     const float* ab;     // [B][Cin+Cin2][2] = (scale, shift) of the fused GroupNorm, or nullptr
+    float* stats;        // [B][tiles_y*tiles_x][Cout][2] per-tile per-channel (sum, sumsq) of the OUTPUT, or nullptr
     int B, H, W, Cin, Cin2, Cout;   // H, W: OUTPUT map (= input map, or 2x the input when ush = 1)
     int Hs, Ws, ush;                // source map and the nearest-x2 shift
     int out_f32, act, norm_silu;
@@ -203,6 +204,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = (p.bias != nullptr && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+    // statistics of the stored tensor for the NEXT GroupNorm: this thread's 8 channels, summed over its pixels
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
 #pragma unroll
     for (int pass = 0; pass < EPI_PASSES; ++pass) {
         if (pass > 0) __syncthreads();
@@ -248,6 +253,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += p.beta * rf[e];
                 }
+                if (p.stats != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
+                }
                 if (p.out_f32) {
                     float* o = (float*)p.out + m * p.Cout_out + n;
                     *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
@@ -258,10 +267,29 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
             }
         }
     }
+    if (p.stats != nullptr) {   // workgroup-uniform
+        __syncthreads();        // Ct is dead: reuse it as [RPP][BN][2]
+        float* red = (float*)smem;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((rr * BN) + cc * 8 + e) * 2] = st_s[e];
+            red[((rr * BN) + cc * 8 + e) * 2 + 1] = st_q[e];
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Cout) {
+            float a = 0.f, q = 0.f;
+            for (int r = 0; r < RPP; ++r) { a += red[(r * BN + tid) * 2]; q += red[(r * BN + tid) * 2 + 1]; }
+            const int64_t tile = (int64_t)ty * p.tiles_x + tx;
+            float* o = p.stats + (((int64_t)img * p.tiles_x * p.tiles_y + tile) * p.Cout + n0 + tid) * 2;
+            o[0] = a;
+            o[1] = q;
+        }
+    }
 }
 
 template <typename T, int BN, int WAVES_M>
-int launch_halo(const HaloArgs& a, hipStream_t s) {
+int launch_halo(
+const HaloArgs& a, hipStream_t s) {
     constexpr int stage = PATCH_BYTES + 2 * BN * 128;
     constexpr int epi = (256 / (BN > 64 ? 2 : 1)) * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
@@ -299,7 +327,8 @@ extern "C" int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d) {
     return 1;
 }
 
-extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* norm_scale_shift, int norm_silu, void* stream) {
+extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* norm_scale_shift, int norm_silu,
+                                       float* out_stats_partials, void* stream) {
     if (!rsvld_conv3x3_halo_supported(d)) return RSVLD_EUNSUPPORTED;
     if (d->x == nullptr || d->w == nullptr || d->out == nullptr) return RSVLD_EINVAL;
     if (d->B <= 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
@@ -310,6 +339,7 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     HaloArgs a;
     a.x = d->x; a.x2 = d->x2; a.w = d->w; a.bias = d->bias; a.rowvec = d->rowvec; a.residual = d->residual; a.out = d->out;
     a.ab = norm_scale_shift;
+    a.stats = d->out_f32 ? nullptr : out_stats_partials;
     a.B = d->B; a.H = d->Ho; a.W = d->Wo; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
     a.Hs = d->H; a.Ws = d->W; a.ush = d->upsample ? 1 : 0;
     a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.norm_silu = norm_silu ? 1 : 0;

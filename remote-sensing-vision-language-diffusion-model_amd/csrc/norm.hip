@@ -101,6 +101,68 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// One block per (image, group): merge partial sums in fp64 (fixed order -> deterministic) and emit the
+// per-channel affine ab[b][c] = (gamma*rstd, beta - mean*gamma*rstd) of that group's channels.
+//   PER_CHANNEL = false: partials [b][chunk][group][2] from gn_partial_kernel (a statistics pass over x)
+//   PER_CHANNEL = true : partials [b][tile][Cset][2] written by a conv epilogue (conv_halo.hip), one or two
+//                        producers (the skip concat [x | x2] is normalised jointly)
+template <bool PER_CHANNEL>
+__global__ __launch_bounds__(256) void gn_ab_kernel(const float* __restrict__ part1, int n1, int C1,
+                                                    const float* __restrict__ part2, int n2, int C2,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ ab, float* __restrict__ stats_out, int groups,
+                                                    float eps, double inv_count) {
+    __shared__ double red[2][4];
+    __shared__ float mr[2];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int C = C1 + C2, gs = C / groups;
+    double s = 0.0, ss = 0.0;
+    if (PER_CHANNEL) {
+        for (int c = g * gs; c < (g + 1) * gs; ++c) {
+            const float* base;
+            int n, Cs, cc;
+            if (c < C1) { base = part1 + (int64_t)b * n1 * C1 * 2; n = n1; Cs = C1; cc = c; }
+            else { base = part2 + (int64_t)b * n2 * C2 * 2; n = n2; Cs = C2; cc = c - C1; }
+            for (int t = tid; t < n; t += 256) {
+                s += (double)base[((int64_t)t * Cs + cc) * 2];
+                ss += (double)base[((int64_t)t * Cs + cc) * 2 + 1];
+            }
+        }
+    } else {
+        for (int t = tid; t < n1; t += 256) {
+            const float* q = part1 + (((int64_t)b * n1 + t) * groups + g) * 2;
+            s += (double)q[0];
+            ss += (double)q[1];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = ss; }
+    __syncthreads();
+    if (tid == 0) {
+        s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double mean = s * inv_count;
+        double var = ss * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[0] = (float)mean;
+        mr[1] = (float)var;
+        if (stats_out != nullptr) {
+            stats_out[((int64_t)b * groups + g) * 2] = (float)mean;
+            stats_out[((int64_t)b * groups + g) * 2 + 1] = (float)var;
+        }
+    }
+    __syncthreads();
+    if (ab != nullptr) {
+        const float mean = mr[0], rstd = 1.0f / sqrtf(mr[1] + eps);
+        for (int c = g * gs + tid; c < (g + 1) * gs; c += 256) {
+            const float a = (gamma ? gamma[c] : 1.f) * rstd;
+            ab[((int64_t)b * C + c) * 2] = a;
+            ab[((int64_t)b * C + c) * 2 + 1] = (beta ? beta[c] : 0.f) - mean * a;
+        }
+    }
+}
+
 // per-(image, channel) affine of a GroupNorm: ab[b][c] = (gamma*rstd, beta - mean*gamma*rstd); consumed by the
 // fused prologue of conv_halo.hip, which then applies y = act(a*x + b) while staging its input patch
 __global__ void gn_scale_shift_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -342,14 +404,33 @@ extern "C" int rsvld_groupnorm_nhwc(const void* x, const void* x2, void* y, cons
 extern "C" int rsvld_groupnorm_scale_shift(const void* x, const void* x2, const float* gamma, const float* beta,
                                            float* scale_shift, int B, int HW, int C1, int C2, int groups, float eps,
                                            int dtype, void* ws, void* stream) {
-    if (!ws || !scale_shift || !gn_shape_ok(B, HW, C1, C2, groups)) return RSVLD_EINVAL;
+    if (!x || !ws || !scale_shift || !gn_shape_ok(B, HW, C1, C2, groups) || ((C2 > 0) != (x2 != nullptr))) return RSVLD_EINVAL;
+    if (dtype != RSVLD_F16 && dtype != RSVLD_BF16) return RSVLD_EINVAL;
     const GnPlan pl = gn_plan(B, HW);
-    float* stats = (float*)ws + (int64_t)B * pl.nchunks * groups * 2;
-    int rc = rsvld_groupnorm_stats(x, x2, stats, B, HW, C1, C2, groups, dtype, ws, stream);
-    if (rc != RSVLD_OK) return rc;
-    const int C = C1 + C2, total = B * C;
-    hipLaunchKernelGGL(gn_scale_shift_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma,
-                       beta, scale_shift, C, groups, eps, total);
+    const int C = C1 + C2, C8 = C / 8;
+    const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
+    const size_t smem = (size_t)rif * C * 2 * sizeof(float);
+    float* part = (float*)ws;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RSVLD_F16)
+        hipLaunchKernelGGL(gn_partial_kernel<f16>, dim3(pl.nchunks, B), dim3(256), smem, s, (const f16*)x, (const f16*)x2, part, HW, C1, C2, groups, pl.rows_per_chunk, pl.nchunks);
+    else
+        hipLaunchKernelGGL(gn_partial_kernel<bf16>, dim3(pl.nchunks, B), dim3(256), smem, s, (const bf16*)x, (const bf16*)x2, part, HW, C1, C2, groups, pl.rows_per_chunk, pl.nchunks);
+    const double inv_count = 1.0 / ((double)HW * (double)(C / groups));
+    hipLaunchKernelGGL(gn_ab_kernel<false>, dim3(groups, B), dim3(256), 0, s, part, pl.nchunks, C, nullptr, 0, 0, gamma, beta,
+                       scale_shift, nullptr, groups, eps, inv_count);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_groupnorm_scale_shift_from_partials(const float* part1, int ntiles1, int C1, const float* part2,
+                                                         int ntiles2, int C2, const float* gamma, const float* beta,
+                                                         float* scale_shift, int B, int HW, int groups, float eps,
+                                                         void* stream) {
+    if (!part1 || !scale_shift || B <= 0 || HW <= 0 || C1 <= 0 || C2 < 0 || ntiles1 <= 0 || groups <= 0) return RSVLD_EINVAL;
+    if ((C2 > 0) != (part2 != nullptr) || (C2 > 0 && ntiles2 <= 0) || (C1 + C2) % groups != 0 || B > 65535) return RSVLD_EINVAL;
+    const double inv_count = 1.0 / ((double)HW * (double)((C1 + C2) / groups));
+    hipLaunchKernelGGL(gn_ab_kernel<true>, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, part1, ntiles1, C1, part2,
+                       ntiles2, C2, gamma, beta, scale_shift, nullptr, groups, eps, inv_count);
     return rsvld_check_launch();
 }
 

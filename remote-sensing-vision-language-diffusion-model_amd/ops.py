@@ -141,12 +141,16 @@ HALO_MIN_WGS = 256   # below one workgroup per CU the 8x32-pixel halo tile under
 
 
 def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, residual=None,
-           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None):
+           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False):
     """NHWC convolution.  ``pad`` = int or (top, left, bottom, right).
 
     ``norm=(gamma, beta, groups, eps, silu)``: a GroupNorm(+SiLU) over the input ([x | x2]) precedes the
     conv.  For 3x3/stride-1 convs it is FUSED into the conv's input staging (rsvld_conv3x3_halo_nhwc): one
-    statistics pass over x, no normalised tensor in HBM.  Otherwise it runs as its own kernels first."""
+    statistics pass over x, no normalised tensor in HBM.  Otherwise it runs as its own kernels first.
+
+    ``stats=True``: the caller will feed the output to a GroupNorm; when the halo kernel runs it also writes
+    per-tile per-channel (sum, sumsq) of the output from its epilogue and attaches them to the returned tensor
+    (``_gn_part``), so the consumer's ``norm=`` needs no statistics pass at all."""
     _need_gpu(x, x2, pc.w, rowvec, residual)
     B, H, W, Cin = x.shape
     Cin2 = 0 if x2 is None else x2.shape[-1]
@@ -190,14 +194,23 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         gamma, nbeta, groups, eps, silu = norm
         xn = group_norm(x, gamma, nbeta, groups, eps, x2=x2, silu=silu)
         return conv2d(xn, pc, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
-                      out_f32=out_f32, act=act, alpha=alpha, beta=beta)
+                      out_f32=out_f32, act=act, alpha=alpha, beta=beta, stats=stats)
     esz = x.element_size()
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
     nbytes = (x.numel() + (0 if x2 is None else x2.numel()) + pc.w.numel()) * esz + out.numel() * out.element_size() \
         + (0 if residual is None else residual.numel() * esz)
     if halo:
         ab, silu = None, 0
-        if norm is not None:
+        part1 = getattr(x, "_gn_part", None)
+        part2 = None if x2 is None else getattr(x2, "_gn_part", None)
+        if norm is not None and part1 is not None and (x2 is None or part2 is not None):
+            gamma, nbeta, groups, eps, silu = norm     # statistics came with the producers' epilogues
+            ab = torch.empty((B, Cin + Cin2, 2), device=x.device, dtype=torch.float32)
+            _launch("groupnorm_ab_from_partials", 0.0, 0.0, lambda: L.check(lib.rsvld_groupnorm_scale_shift_from_partials(
+                _ptr(part1[0]), part1[1], Cin, None if part2 is None else _ptr(part2[0]), 0 if part2 is None else part2[1],
+                Cin2, _ptr(gamma), _ptr(nbeta), _ptr(ab), B, H * W, groups, eps, _stream()),
+                "rsvld_groupnorm_scale_shift_from_partials"))
+        elif norm is not None:
             gamma, nbeta, groups, eps, silu = norm
             ws = torch.empty(lib.rsvld_groupnorm_ws_bytes(B, H * W, Cin + Cin2, groups), device=x.device, dtype=torch.uint8)
             ab = torch.empty((B, Cin + Cin2, 2), device=x.device, dtype=torch.float32)
@@ -206,8 +219,14 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
                                                                     H * W, Cin, Cin2, groups, eps, _dt(x), _ptr(ws), _stream()),
                                     "rsvld_groupnorm_scale_shift"))
         name = "conv_halo_64" if pc.cout_p <= 64 else "conv_halo_128"
-        _launch(name, flops, nbytes, lambda: L.check(lib.rsvld_conv3x3_halo_nhwc(C.byref(d), _ptr(ab), int(silu), _stream()),
-                                                     "rsvld_conv3x3_halo_nhwc"))
+        part_out = None
+        if stats and not out_f32:
+            ntiles = ((Ho + 7) // 8) * ((Wo + 31) // 32)
+            part_out = torch.empty((B, ntiles, pc.cout_p, 2), device=x.device, dtype=torch.float32)
+        _launch(name, flops, nbytes, lambda: L.check(lib.rsvld_conv3x3_halo_nhwc(C.byref(d), _ptr(ab), int(silu), _ptr(part_out),
+                                                                                 _stream()), "rsvld_conv3x3_halo_nhwc"))
+        if part_out is not None:
+            out._gn_part = (part_out, ntiles)
         return out
     if pc.cout_p <= 32:
         variant = "conv_igemm_256x32"

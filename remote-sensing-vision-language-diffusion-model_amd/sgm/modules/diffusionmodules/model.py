@@ -71,8 +71,9 @@ class ResnetBlock(nn.Module):
         skip = ops.conv2d(x, rt.pk(self.nin_shortcut), pad=0) if self.in_channels != self.out_channels else x
         if norm1_stats is None and norm2_stats is None:   # GN+swish fused into each conv's input staging
             n1, n2 = self.norm1, self.norm2
-            h = ops.conv2d(x, rt.pk(self.conv1), pad=1, norm=(n1.weight, n1.bias, n1.num_groups, n1.eps, True))
-            return ops.conv2d(h, rt.pk(self.conv2), pad=1, residual=skip, norm=(n2.weight, n2.bias, n2.num_groups, n2.eps, True))
+            h = ops.conv2d(x, rt.pk(self.conv1), pad=1, stats=True, norm=(n1.weight, n1.bias, n1.num_groups, n1.eps, True))
+            return ops.conv2d(h, rt.pk(self.conv2), pad=1, residual=skip, stats=True,
+                              norm=(n2.weight, n2.bias, n2.num_groups, n2.eps, True))
         h = _gn(x, self.norm1, True, norm1_stats)
         h = ops.conv2d(h, rt.pk(self.conv1), pad=1)
         h = _gn(h, self.norm2, True, norm2_stats)

@@ -92,7 +92,7 @@ class ResBlock(TimestepBlock):
     def run(self, rt, x, emb_rows):
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
         gn2, conv2 = self.out_layers[0], self.out_layers[3]
-        h = ops.conv2d(x, rt.pk(conv1), pad=conv1.padding[0], rowvec=emb_rows[id(self)],
+        h = ops.conv2d(x, rt.pk(conv1), pad=conv1.padding[0], rowvec=emb_rows[id(self)], stats=True,
                        norm=(gn1.weight, gn1.bias, gn1.num_groups, gn1.eps, True))
         if isinstance(self.skip_connection, nn.Conv2d):
             skip = ops.conv2d(x, rt.pk(self.skip_connection), pad=self.skip_connection.padding[0])

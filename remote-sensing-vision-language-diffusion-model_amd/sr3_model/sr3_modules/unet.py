@@ -226,13 +226,13 @@ class UNet(nn.Module):
         rb = layer.res_block
         off, width = self._pk[("nf", id(layer))]
         rowvec = nf_all[:, off:off + width]
-        h = self._block(rb.block1, x, x2, rowvec=rowvec)
+        h = self._block(rb.block1, x, x2, rowvec=rowvec, stats=True)     # its output feeds block2's GroupNorm
         if isinstance(rb.res_conv, nn.Conv2d):
             split = None if x2 is None else (x.shape[-1], x2.shape[-1])
             res = ops.conv2d(x, self._res_conv_packed(rb, split), x2=x2, pad=0)
         else:
             res = x
-        h = self._block(rb.block2, h, residual=res)
+        h = self._block(rb.block2, h, residual=res, stats=not layer.with_attn)   # ... and the next block's, unless attention follows
         if layer.with_attn:
             h = self._attention(layer.attn, h)
         return h
@@ -272,7 +272,7 @@ class UNet(nn.Module):
             if isinstance(layer, ResnetBlocWithAttn):
                 x = self._resblock(layer, x, feats.pop(), nf_all)
             else:
-                x = ops.conv2d(x, pk[id(layer.conv)], pad=1, upsample=True)
+                x = ops.conv2d(x, pk[id(layer.conv)], pad=1, upsample=True, stats=True)
         return self._block(self.final_conv, x, out_f32=True)
 
     def forward(self, x, time):

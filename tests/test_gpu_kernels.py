@@ -113,6 +113,38 @@ def test_conv3x3_halo_fused_groupnorm(cuda, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_groupnorm_statistics_from_conv_epilogue(cuda, dtype):
+    """Producer convs write per-tile per-channel (sum, sumsq) from their epilogue; the consumer's fused GroupNorm
+    uses them instead of a pass over the tensor.  Two producers feed one consumer (skip concat, groups straddle)."""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 2, 19, 40
+    xa = _rt(torch.randn(B, 64, H, W, generator=g), dtype)
+    xb = _rt(torch.randn(B, 128, H, W, generator=g), dtype)
+    wa = _rt(torch.randn(128, 64, 3, 3, generator=g) / 24, dtype)
+    wb = _rt(torch.randn(64, 128, 3, 3, generator=g) / 34, dtype)
+    wc = _rt(torch.randn(128, 192, 3, 3, generator=g) / 41, dtype)
+    res = _rt(torch.randn(B, 128, H, W, generator=g), dtype)
+    gamma, beta = 1 + 0.1 * torch.randn(192, generator=g), 0.1 * torch.randn(192, generator=g)
+    ops.HALO_MIN_WGS = 0
+    try:
+        ya = ops.conv2d(_nhwc(xa, dtype, cuda), ops.pack_conv(wa, None, dtype, cuda), pad=1, residual=_nhwc(res, dtype, cuda), stats=True)
+        yb = ops.conv2d(_nhwc(xb, dtype, cuda), ops.pack_conv(wb, None, dtype, cuda), pad=1, stats=True)
+        assert hasattr(ya, "_gn_part") and hasattr(yb, "_gn_part")
+        norm = (gamma.to(cuda), beta.to(cuda), 32, 1e-5, True)
+        pcc = ops.pack_conv(wc, None, dtype, cuda)
+        got = ops.conv2d(ya, pcc, x2=yb, pad=1, norm=norm)                       # statistics from the epilogues
+        ya2, yb2 = ya.clone(), yb.clone()                                          # clones carry no partials
+        ref = ops.conv2d(ya2, pcc, x2=yb2, pad=1, norm=norm)                     # statistics pass over the tensors
+    finally:
+        ops.HALO_MIN_WGS = 256
+    cat = torch.cat([ya.float().cpu().permute(0, 3, 1, 2), yb.float().cpu().permute(0, 3, 1, 2)], 1)
+    want = F.conv2d(F.silu(F.group_norm(cat, 32, gamma, beta, eps=1e-5)), wc, None, padding=1)
+    _close(got.permute(0, 3, 1, 2), want, dtype)
+    _close(got.float(), ref.float().cpu(), dtype, scale=float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_halo_fused_upsample(cuda, dtype):
     """nearest x2 folded into the halo patch staging (Upsample modules of all three networks)."""
     from rsvld_amd import ops
