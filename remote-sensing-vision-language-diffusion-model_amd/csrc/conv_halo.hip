@@ -47,12 +47,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int swz_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int BN, int WAVES_M>
+// TPS = taps of weights staged per pipeline step (per barrier): 1 for BN = 128, 2 for BN = 64, so that every
+// step carries a 16 KiB weight slice and 32 MFMAs per wave
+template <typename T, int BN, int WAVES_M, int TPS>
 __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int SPC = (9 + TPS - 1) / TPS;       // steps per 64-channel chunk
     constexpr int TM = TH / WAVES_M;               // 32-pixel rows per wave
     constexpr int TN = BN / (32 * WAVES_N);
-    constexpr int W_BYTES = BN * 128;
+    constexpr int W_BYTES = TPS * BN * 128;        // one step's weight stage
     constexpr int W_LOADS = BN / 32;
     constexpr int EPI_PASSES = BN > 64 ? 2 : 1;
     constexpr int EPI_ROWS = 256 / EPI_PASSES;
@@ -137,14 +140,19 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     // weights of (chunk kc, tap): rows n0.. , k = tap*Ctot + kc*64 ..+64 ; lane-linear LDS image, source-side swizzle
     const int wr0 = tid >> 3;
     const int wc = (tid & 7) ^ ((wr0 >> 1) & 7);
-    auto dma_w = [&](int kc, int tap, int buf) {
-        char* dst = wbuf + buf * W_BYTES;
-        const int64_t koff = (int64_t)tap * p.Ctot + kc * 64 + wc * 8;
+    auto dma_w = [&](int kc, int step, int buf) {   // taps step*TPS .. of chunk kc
 #pragma unroll
-        for (int i = 0; i < W_LOADS; ++i) {
-            const int n = n0 + wr0 + 32 * i;
-            const void* g = n < p.Cout ? (const void*)(Wp + (int64_t)n * Kel + koff) : (const void*)&g_halo_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+        for (int j = 0; j < TPS; ++j) {
+            const int tap = step * TPS + j;
+            if (tap >= 9) break;
+            char* dst = wbuf + buf * W_BYTES + j * (BN * 128);
+            const int64_t koff = (int64_t)tap * p.Ctot + kc * 64 + wc * 8;
+#pragma unroll
+            for (int i = 0; i < W_LOADS; ++i) {
+                const int n = n0 + wr0 + 32 * i;
+                const void* g = n < p.Cout ? (const void*)(Wp + (int64_t)n * Kel + koff) : (const void*)&g_halo_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+            }
         }
     };
 
@@ -161,38 +169,43 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     // "Three .s-level traps" (b)); measured here as a full weight-DMA round trip exposed on EVERY tap.  So the tap
     // loop contains LDS-DMA only; the register-staged patch phase (load -> normalise -> ds_write) runs between
     // chunks, while the first tap's weight slice of that chunk is already in flight.
-    const int nsteps = p.nchunks * 9;
+    const int nsteps = p.nchunks * SPC;
     int s = 0;
     dma_w(0, 0, 0);
     for (int kc = 0; kc < p.nchunks; ++kc) {
         load_patch(kc);
         store_patch(kc);
-        __syncthreads();   // patch visible; weights of (kc, tap 0) landed (vmcnt(0) + barrier)
+        __syncthreads();   // patch visible; weights of (kc, step 0) landed (vmcnt(0) + barrier)
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++s) {
+        for (int st = 0; st < SPC; ++st, ++s) {
             if (s + 1 < nsteps) {   // next step's weights stream in behind this step's MFMAs
-                if (tap == 8) dma_w(kc + 1, 0, (s + 1) & 1);
-                else dma_w(kc, tap + 1, (s + 1) & 1);
+                if (st == SPC - 1) dma_w(kc + 1, 0, (s + 1) & 1);
+                else dma_w(kc, st + 1, (s + 1) & 1);
             }
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const char* w_s = wbuf + (s & 1) * W_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int ch = 2 * ks + lh;
-                v8 fa[TN], fb[TM];
+            for (int j = 0; j < TPS; ++j) {
+                const int tap = st * TPS + j;
+                if (tap >= 9) break;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const char* w_s = wbuf + (s & 1) * W_BYTES + j * (BN * 128);
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + swz_off(wn * (TN * 32) + ni * 32 + l31, ch));
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ch = 2 * ks + lh;
+                    v8 fa[TN], fb[TM];
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    const int pr = (wm * TM + mi + ky) * PW + l31 + kx;     // shifted window of the same patch
-                    fb[mi] = *(const v8*)(patch + swz_off(pr, ch));
+                    for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + swz_off(wn * (TN * 32) + ni * 32 + l31, ch));
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const int pr = (wm * TM + mi + ky) * PW + l31 + kx;     // shifted window of the same patch
+                        fb[mi] = *(const v8*)(patch + swz_off(pr, ch));
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
                 }
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
             }
-            __syncthreads();   // next weights landed; everyone done with this step's weights (at tap 8: with the patch)
+            __syncthreads();   // next weights landed; everyone done with this step's weights (last step: with the patch)
         }
     }
 
@@ -287,13 +300,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     }
 }
 
-template <typename T, int BN, int WAVES_M>
-int launch_halo(
-const HaloArgs& a, hipStream_t s) {
-    constexpr int stage = PATCH_BYTES + 2 * BN * 128;
+template <typename T, int BN, int WAVES_M, int TPS>
+int launch_halo(const HaloArgs& a, hipStream_t s) {
+    constexpr int stage = PATCH_BYTES + 2 * TPS * BN * 128;
     constexpr int epi = (256 / (BN > 64 ? 2 : 1)) * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
-    auto kern = conv_halo_kernel<T, BN, WAVES_M>;
+    auto kern = conv_halo_kernel<T, BN, WAVES_M, TPS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -308,8 +320,8 @@ const HaloArgs& a, hipStream_t s) {
 
 template <typename T>
 int dispatch_halo(const HaloArgs& a, hipStream_t s) {
-    if (a.Cout <= 64) return launch_halo<T, 64, 4>(a, s);
-    return launch_halo<T, 128, 2>(a, s);
+    if (a.Cout <= 64) return launch_halo<T, 64, 4, 2>(a, s);
+    return launch_halo<T, 128, 2, 1>(a, s);
 }
 
 }  // namespace
