@@ -1,0 +1,76 @@
+"""Folder driver with the reference's CLI (infer_dir.py:212-217): every image of ``--image_dir`` goes through the
+two-stage pipeline; a failing image is reported and skipped (per-image isolation, infer_dir.py:199-202), the models
+are loaded once.
+
+    python -m rsvld_amd.infer_dir --image_dir in/ --save_dir out/ --upscale 8 --num_steps 50 --seed 42 --img_threshold 0.3
+
+Multi-GPU: launch one process per GPU with ``python -m torch.distributed.run --nproc-per-node N -m rsvld_amd.infer_dir ...``;
+image i is processed by rank i mod N (rsvld_amd.parallel.shard_indices), no communication is needed because every
+rank writes its own PNGs."""
+import argparse
+import gc
+import traceback
+from pathlib import Path
+
+import torch
+
+from . import parallel
+from .infer import PipelineConfig, SuperResolutionPipeline
+
+EXTS = {".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".webp"}
+
+
+class ImageBatchProcessor:
+    def __init__(self, image_dir, save_dir, upscale=8, num_steps=50, seed=42, img_threshold=0.3, sr3_steps=0, device="cuda:0"):
+        self.files = sorted(p for p in Path(image_dir).iterdir() if p.suffix.lower() in EXTS)
+        self.save_dir, self.seed = Path(save_dir), seed
+        self.save_dir.mkdir(parents=True, exist_ok=True)
+        self.pipe = None
+        self.kw = dict(output_dir=str(self.save_dir), upscale_factor=upscale, edm_steps=num_steps, seed=seed,
+                       img_threshold=img_threshold, sr3_steps=sr3_steps, sr_model_device=device)
+
+    def _process_single_image(self, path):
+        cfg = PipelineConfig(input_img=str(path), **self.kw)
+        if self.pipe is None:
+            self.pipe = SuperResolutionPipeline(cfg)          # models are built once
+        else:
+            self.pipe.cfg = cfg
+        if self.seed >= 0:
+            torch.manual_seed(self.seed)
+        return self.pipe.process()
+
+    def run(self, rank=0, world=1):
+        done, failed = [], []
+        for i in parallel.shard_indices(len(self.files), rank, world):
+            path = self.files[i]
+            try:
+                done += self._process_single_image(path)
+            except Exception:                                   # keep going, like the reference
+                failed.append(path)
+                print(f"[rank {rank}] failed on {path}:\n{traceback.format_exc()}")
+            finally:
+                gc.collect()
+                torch.cuda.empty_cache()
+        return done, failed
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description="Batch two-stage super-resolution over a folder")
+    p.add_argument("--image_dir", type=str, required=True)
+    p.add_argument("--save_dir", type=str, required=True)
+    p.add_argument("--upscale", type=int, default=8)
+    p.add_argument("--num_steps", type=int, default=50)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--img_threshold", type=float, default=0.3)
+    p.add_argument("--sr3_steps", type=int, default=0)
+    a = p.parse_args(argv)
+    rank, world, local = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    proc = ImageBatchProcessor(a.image_dir, a.save_dir, a.upscale, a.num_steps, a.seed, a.img_threshold, a.sr3_steps,
+                               device=f"cuda:{local}")
+    done, failed = proc.run(rank, world)
+    print(f"[rank {rank}] wrote {len(done)} images, {len(failed)} failures")
+
+
+if __name__ == "__main__":
+    main()
