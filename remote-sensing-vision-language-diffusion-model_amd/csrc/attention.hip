@@ -187,13 +187,13 @@ __global__ __launch_bounds__(512) void attn_d512_kernel(AttnArgs p) {
             // reference point; P <= 2^8 stays exact enough in 16-bit, l and O are fp32.
             float a = 1.0f;
             if (mx > m_run + A5_DEFER_LOG2) {     // also true on the first tile (m_run = -inf)
-                a = exp2f(m_run - mx);
+                a = __builtin_amdgcn_exp2f(m_run - mx);
                 m_run = mx;
                 resc_flag[t & 1] = 1;
             }
             float pr[4], rs = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { pr[e] = exp2f(s[e] - m_run); rs += pr[e]; }
+            for (int e = 0; e < 4; ++e) { pr[e] = __builtin_amdgcn_exp2f(s[e] - m_run); rs += pr[e]; }
             rs += __shfl_xor(rs, 1);
             rs += __shfl_xor(rs, 2);
             rs += __shfl_xor(rs, 4);
@@ -378,7 +378,17 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(AttnArgs p) {
 
         // ---- online softmax, register-local per query row (lane) + its partner lane^32
         v8 pf[QT][4];
-        const bool tail = (t + 1) * 64 > p.Nk;
+        if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch): mask keys beyond Nk
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (kv >= p.Nk) sacc[qt][kt][r] = -INFINITY;
+                    }
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float mx = -INFINITY;
@@ -386,32 +396,36 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(AttnArgs p) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float sv = sacc[qt][kt][r] * p.scale_log2e;
-                    if (tail) {
-                        const int kv = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (kv >= p.Nk) sv = -INFINITY;
-                    }
+                    const float sv = sacc[qt][kt][r] * p.scale_log2e;
                     sacc[qt][kt][r] = sv;
                     mx = fmaxf(mx, sv);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = exp2f(m_run[qt] - m_new);
-            m_run[qt] = m_new;
+            // deferred max (T13): move a row's reference point only when the tile max exceeds it by > 2^8; the
+            // rescale of O (and its accumulator-file traffic) is skipped unless some row of the wave needs it
+            const bool need = mx > m_run[qt] + 8.0f;          // true on the first tile (m_run = -inf)
+            float alpha = 1.0f;
+            if (need) {
+                alpha = __builtin_amdgcn_exp2f(m_run[qt] - mx);
+                m_run[qt] = mx;
+            }
+            const float mref = m_run[qt];
             float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = exp2f(sacc[qt][kt][r] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f(sacc[qt][kt][r] - mref);   // raw v_exp_f32: inputs <= 8, no denormal fix-up needed
                     sacc[qt][kt][r] = pv;
                     rs += pv;
                 }
             l_run[qt] = l_run[qt] * alpha + rs;
+            if (__any(need)) {
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[qt][dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) oacc[qt][dt][r] *= alpha;
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 v8 f;

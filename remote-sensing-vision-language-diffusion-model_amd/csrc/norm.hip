@@ -250,49 +250,62 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
     }
 }
 
-// LayerNorm: one wave per row, row kept in registers (C <= 4096), exact two-pass variance.
-template <typename T>
+// LayerNorm: one wave per row, ROWS rows per wave with all their loads issued up front (a single row per wave
+// is one dependent load -> reduce -> store chain: measured 15 us for 10 MB); rows kept in registers (C <= 4096),
+// exact two-pass variance.
+template <typename T, int MAXC, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int64_t rows, int C, float eps) {
-    constexpr int MAXC = 8;  // chunks of 8 per lane -> C <= 64*8*8 = 4096
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= rows) return;
     const int C8 = C >> 3;
-    float f[MAXC][8];
-    float s = 0.f;
+    u32x4 raw[ROWS][MAXC];
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-        const int cc = lane + 64 * j;
-        if (cc < C8) {
-            unpack8<T>(*(const u32x4*)(x + row * C + cc * 8), f[j]);
+    for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += f[j][e];
+        for (int j = 0; j < MAXC; ++j) {
+            const int cc = lane + 64 * j;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (cc < C8 && row0 + r < rows) v = *(const u32x4*)(x + (row0 + r) * C + cc * 8);
+            raw[r][j] = v;
         }
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-        const int cc = lane + 64 * j;
-        if (cc < C8) {
+    for (int r = 0; r < ROWS; ++r) {
+        if (row0 + r >= rows) break;
+        float f[MAXC][8];
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; ss += d * d; }
-        }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+        for (int j = 0; j < MAXC; ++j) {
+            unpack8<T>(raw[r][j], f[j]);
+            if (lane + 64 * j < C8) {
 #pragma unroll
-    for (int j = 0; j < MAXC; ++j) {
-        const int cc = lane + 64 * j;
-        if (cc < C8) {
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ch = cc * 8 + e;
-                o[e] = (f[j][e] - mean) * rstd * (gamma ? gamma[ch] : 1.f) + (beta ? beta[ch] : 0.f);
+                for (int e = 0; e < 8; ++e) s += f[j][e];
             }
-            *(u32x4*)(y + row * C + cc * 8) = pack8<T>(o);
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            if (lane + 64 * j < C8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; ss += d * d; }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            const int cc = lane + 64 * j;
+            if (cc < C8) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = cc * 8 + e;
+                    o[e] = (f[j][e] - mean) * rstd * (gamma ? gamma[ch] : 1.f) + (beta ? beta[ch] : 0.f);
+                }
+                *(u32x4*)(y + (row0 + r) * C + cc * 8) = pack8<T>(o);
+            }
         }
     }
 }
@@ -434,16 +447,28 @@ extern "C" int rsvld_groupnorm_scale_shift_from_partials(const float* part1, int
     return rsvld_check_launch();
 }
 
+template <typename T>
+static void launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                             hipStream_t s) {
+    const int chunks_per_lane = (C / 8 + 63) / 64;
+    if (chunks_per_lane <= 2) {        // C <= 1024: 4 rows per wave in flight
+        const unsigned nblk = (unsigned)cdiv64(rows, 16);
+        hipLaunchKernelGGL((layernorm_kernel<T, 2, 4>), dim3(nblk), dim3(256), 0, s, (const T*)x, (T*)y, gamma, beta, rows, C, eps);
+    } else if (chunks_per_lane <= 4) { // C <= 2048
+        const unsigned nblk = (unsigned)cdiv64(rows, 8);
+        hipLaunchKernelGGL((layernorm_kernel<T, 4, 2>), dim3(nblk), dim3(256), 0, s, (const T*)x, (T*)y, gamma, beta, rows, C, eps);
+    } else {
+        const unsigned nblk = (unsigned)cdiv64(rows, 4);
+        hipLaunchKernelGGL((layernorm_kernel<T, 8, 1>), dim3(nblk), dim3(256), 0, s, (const T*)x, (T*)y, gamma, beta, rows, C, eps);
+    }
+}
+
 extern "C" int rsvld_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int C,
                                float eps, int dtype, void* stream) {
     if (!x || !y || rows <= 0 || C <= 0 || C % 8 || C > 4096) return RSVLD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const unsigned nblk = (unsigned)cdiv64(rows, 4);
-    if (dtype == RSVLD_F16)
-        hipLaunchKernelGGL(layernorm_kernel<f16>, dim3(nblk), dim3(256), 0, s, (const f16*)x, (f16*)y, gamma, beta, rows, C, eps);
-    else if (dtype == RSVLD_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<bf16>, dim3(nblk), dim3(256), 0, s, (const bf16*)x, (bf16*)y, gamma, beta, rows, C, eps);
-    else
-        return RSVLD_EINVAL;
+    if (dtype == RSVLD_F16) launch_layernorm<f16>(x, y, gamma, beta, rows, C, eps, s);
+    else if (dtype == RSVLD_BF16) launch_layernorm<bf16>(x, y, gamma, beta, rows, C, eps, s);
+    else return RSVLD_EINVAL;
     return rsvld_check_launch();
 }

@@ -291,6 +291,42 @@ def test_attention_d512(cuda, dtype, shape):
     _close(got, want, dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 10, 256, 256), (1, 20, 64, 77), (2, 5, 100, 333), (1, 10, 4096, 4096), (3, 2, 1, 1)])
+def test_attention_d64_multihead(cuda, dtype, shape):
+    """SDXL self / cross attention and ZeroCrossAttn: heads x d=64, keys 77 (text), ragged, 4096 tokens (QT=2 path)."""
+    from rsvld_amd import ops
+    B, heads, Nq, Nk = shape
+    D = 64
+    g = torch.Generator().manual_seed(Nq + 3 * Nk + heads)
+    q = _rt(torch.randn(B, Nq, heads * D, generator=g), dtype)
+    kv = _rt(torch.randn(B, Nk, 2 * heads * D, generator=g), dtype)       # fused k|v projection output
+    k, v = kv[..., :heads * D], kv[..., heads * D:]
+    qh, kh, vh = (t.view(B, -1, heads, D).transpose(1, 2) for t in (q, k, v))
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).transpose(1, 2).reshape(B, Nq, heads * D)
+    dkv = kv.to(cuda, dtype)
+    got = ops.attention(q.to(cuda, dtype), dkv[..., :heads * D], dkv[..., heads * D:], heads=heads)
+    _close(got, want, dtype)
+
+
+def test_attention_d64_rescale_path(cuda):
+    """A late key dominates one query row (running max jumps by >> 2^8 in a late tile) and another row's max creeps
+    up by less than the deferral threshold: both branches of the deferred-max logic."""
+    from rsvld_amd import ops
+    dtype, heads, D, N = torch.float16, 2, 64, 320
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(1, N, heads * D, generator=g)
+    k = torch.randn(1, N, heads * D, generator=g)
+    v = torch.randn(1, N, heads * D, generator=g)
+    k[0, 300, :D] = q[0, 17, :D] * 4.0
+    k[0, 150, D:] = q[0, 40, D:] * 0.5
+    q, k, v = _rt(q, dtype), _rt(k, dtype), _rt(v, dtype)
+    qh, kh, vh = (t.view(1, N, heads, D).transpose(1, 2) for t in (q, k, v))
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).transpose(1, 2).reshape(1, N, heads * D)
+    got = ops.attention(q.to(cuda, dtype), k.to(cuda, dtype), v.to(cuda, dtype), heads=heads)
+    _close(got, want, dtype)
+
+
 def test_attention_online_softmax_rescale_path(cuda):
     """Force the running max to jump at a late key tile (cdna_hip_programming.md rule 26)."""
     from rsvld_amd import ops
