@@ -173,6 +173,8 @@ def main():
     if world != args.gpus:
         if args.gpus != 1 and world == 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`")
+    if os.environ.get("RSVLD_DEVICE_OVERRIDE") is not None:   # debugging aid: several ranks on one GPU (with gloo)
+        local = int(os.environ["RSVLD_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.workload == "s2":
@@ -207,7 +209,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        on_host = torch.distributed.get_backend() == "gloo"
+        tmax = torch.tensor([dt], device="cpu" if on_host else dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     n_img = args.batch * world * args.steps

@@ -163,22 +163,6 @@ __global__ __launch_bounds__(256) void gn_ab_kernel(const float* __restrict__ pa
     }
 }
 
-// per-(image, channel) affine of a GroupNorm: ab[b][c] = (gamma*rstd, beta - mean*gamma*rstd); consumed by the
-// fused prologue of conv_halo.hip, which then applies y = act(a*x + b) while staging its input patch
-__global__ void gn_scale_shift_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, float* __restrict__ ab, int C, int groups,
-                                      float eps, int total) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int b = i / C, ch = i - b * C;
-    const int g = ch / (C / groups);
-    const float mean = stats[((int64_t)b * groups + g) * 2];
-    const float var = stats[((int64_t)b * groups + g) * 2 + 1];
-    const float a = (gamma ? gamma[ch] : 1.f) / sqrtf(var + eps);
-    ab[2 * (int64_t)i] = a;
-    ab[2 * (int64_t)i + 1] = (beta ? beta[ch] : 0.f) - mean * a;
-}
-
 // pass 3: y = act((x-mean)*rstd*gamma+beta) [*(1+scale1p)+shift]
 // grid (row-chunks, B).  Same thread <-> channel-chunk mapping as pass 1: a thread keeps ONE
 // 8-channel chunk, so its 8 (scale, shift) pairs live in registers and the row loop is pure

@@ -19,8 +19,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # RSVLD_DIST_BACKEND=gloo: debugging aid (several ranks sharing one GPU)
+            backend = os.environ.get("RSVLD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -43,6 +43,10 @@ def gather_images(local_u8, world):
     if world == 1:
         return local_u8
     shape = (world * local_u8.shape[0],) + tuple(local_u8.shape[1:])
+    if dist.get_backend() == "gloo" and local_u8.is_cuda:   # gloo gathers host tensors
+        out = torch.empty(shape, dtype=local_u8.dtype)
+        dist.all_gather_into_tensor(out, local_u8.cpu().contiguous())
+        return out.to(local_u8.device)
     out = torch.empty(shape, dtype=local_u8.dtype, device=local_u8.device)   # rank-major concatenation
     dist.all_gather_into_tensor(out, local_u8.contiguous())
     return out
