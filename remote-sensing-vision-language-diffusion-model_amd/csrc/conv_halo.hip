@@ -41,11 +41,16 @@ constexpr int TH = 8, TW = 32, PW = TW + 2, PROWS = (TH + 2) * PW;   // 340 patc
 constexpr int PATCH_BYTES = PROWS * 128;
 constexpr int PLOADS = (PROWS * 8 + 255) / 256;                        // 11 16-byte pieces per thread
 
-__device__ uint4 g_halo_zero16;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int swz_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+// Patch image: pixel (py, px) of the (TH+2) x PW patch owns the 128-B row py*PW + px; its 16-B channel chunk c sits
+// at slot c ^ ((px>>1)&7).  The swizzle depends on the patch COLUMN only (PW is even, so a row of the patch starts
+// on a 256-B bank row), which keeps every ds_read_b128 lane group on 16 distinct slots for any tap shift AND makes the
+// per-lane part of a tap's read address a function of (kx, k-step) alone: 12 precomputed registers, the rest is an
+// immediate offset -- no address arithmetic inside the tap loop.
+__device__ __forceinline__ int patch_off(int py, int px, int c) { return (py * PW + px) * 128 + ((c ^ ((px >> 1) & 7)) << 4); }
 
 // TPS = taps of weights staged per pipeline step (per barrier): 1 for BN = 128, 2 for BN = 64, so that every
 // step carries a 16 KiB weight slice and 32 MFMAs per wave
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
         for (int i = 0; i < PLOADS; ++i) {
             const int pp = (tid >> 3) + 32 * i;
             if (pp >= PROWS) continue;
+            const int py = pp / PW, px = pp - py * PW;
             u32x4 v = rp[i];
             if (p.ab != nullptr && poff[i] >= 0) {
                 float f[8];
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
                 }
                 v = pack8<T>(f);
             }
-            *(u32x4*)(patch + swz_off(pp, c)) = v;
+            *(u32x4*)(patch + patch_off(py, px, c)) = v;
         }
     };
     // weights of (chunk kc, tap): rows n0.. , k = tap*Ctot + kc*64 ..+64 ; lane-linear LDS image, source-side swizzle
@@ -149,9 +155,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
             const int64_t koff = (int64_t)tap * p.Ctot + kc * 64 + wc * 8;
 #pragma unroll
             for (int i = 0; i < W_LOADS; ++i) {
-                const int n = n0 + wr0 + 32 * i;
-                const void* g = n < p.Cout ? (const void*)(Wp + (int64_t)n * Kel + koff) : (const void*)&g_halo_zero16;
-                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (wave * 8 + 32 * i) * 128), 16, 0, 0);
+                // rows past Cout re-read the last row: their accumulators are never stored
+                const int n = min(n0 + wr0 + 32 * i, p.Cout - 1);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wp + (int64_t)n * Kel + koff), (lptr_t)(dst + (wave * 8 + 32 * i) * 128), 16, 0, 0);
             }
         }
     };
@@ -169,6 +175,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     // "Three .s-level traps" (b)); measured here as a full weight-DMA round trip exposed on EVERY tap.  So the tap
     // loop contains LDS-DMA only; the register-staged patch phase (load -> normalise -> ds_write) runs between
     // chunks, while the first tap's weight slice of that chunk is already in flight.
+    // per-lane part of the operand addresses: patch [kx][k-step], weights [k-step]
+    int fb_off[3][4], fa_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) fb_off[kx][ks] = patch_off(wm * TM, l31 + kx, 2 * ks + lh);
+        fa_off[ks] = swz_off(wn * (TN * 32) + l31, 2 * ks + lh);
+    }
     const int nsteps = p.nchunks * SPC;
     int s = 0;
     dma_w(0, 0, 0);
@@ -176,29 +190,27 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
         load_patch(kc);
         store_patch(kc);
         __syncthreads();   // patch visible; weights of (kc, step 0) landed (vmcnt(0) + barrier)
-#pragma unroll 1
-        for (int st = 0; st < SPC; ++st, ++s) {
+#pragma unroll
+        for (int st = 0; st < SPC; ++st, ++s) {   // unrolled: the tap of every read is a compile-time constant
             if (s + 1 < nsteps) {   // next step's weights stream in behind this step's MFMAs
                 if (st == SPC - 1) dma_w(kc + 1, 0, (s + 1) & 1);
                 else dma_w(kc, st + 1, (s + 1) & 1);
             }
+            const char* w_st = wbuf + (s & 1) * W_BYTES;
 #pragma unroll
             for (int j = 0; j < TPS; ++j) {
                 const int tap = st * TPS + j;
                 if (tap >= 9) break;
                 const int ky = tap / 3, kx = tap - ky * 3;
-                const char* w_s = wbuf + (s & 1) * W_BYTES + j * (BN * 128);
+                const char* w_s = w_st + j * (BN * 128);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const int ch = 2 * ks + lh;
                     v8 fa[TN], fb[TM];
 #pragma unroll
-                    for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + swz_off(wn * (TN * 32) + ni * 32 + l31, ch));
+                    for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + fa_off[ks] + ni * (32 * 128));
 #pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) {
-                        const int pr = (wm * TM + mi + ky) * PW + l31 + kx;     // shifted window of the same patch
-                        fb[mi] = *(const v8*)(patch + swz_off(pr, ch));
-                    }
+                    for (int mi = 0; mi < TM; ++mi)   // shifted window of the same patch
+                        fb[mi] = *(const v8*)(patch + fb_off[kx][ks] + (mi + ky) * (PW * 128));
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll

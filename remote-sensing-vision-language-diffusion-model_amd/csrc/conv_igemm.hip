@@ -36,6 +36,7 @@ struct ConvArgs {
     const float* rowvec;
     const void* residual;
     void* out;
+    const void* zero;   // 16 zero bytes in device memory: source of padded / out-of-range chunks for the LDS-DMA path
     int B, H, W, Cin, Cin2, Cout;
     int KH, KW, stride, pad_t, pad_l, Ho, Wo, upsample;
     int out_f32, act;
@@ -65,10 +66,14 @@ __device__ __forceinline__ int lds_off(int row, int c) { return row * BK_BYTES +
 // counted wait: all but the newest `n` LDS-DMA (vector-memory) operations of this wave have landed
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+// KS = intra-workgroup split of K: KS groups of 4 waves each own every KS-th K-step of the SAME output tile (own
+// LDS ring, shared barriers) and their accumulators are summed through LDS before the epilogue.  For small-M layers
+// whose grid is one workgroup per CU this doubles the waves per SIMD without partial sums in HBM.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES, int KS>
+__global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
     static_assert(GLDS ? (STAGES >= 2 && STAGES <= 4) : STAGES == 2, "register staging is double-buffered");
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per K group");
+    static_assert(KS == 1 || (GLDS && STAGES > 2), "split K runs on the LDS-DMA ring");
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
@@ -76,9 +81,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int STAGE = A_BYTES + B_BYTES;
     typedef typename Mfma<T>::v8 v8;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
-    const int tid = threadIdx.x;
+    const int kg = KS > 1 ? (int)(threadIdx.x >> 8) : 0;   // K group (wave-uniform)
+    const int tid = threadIdx.x & 255;                      // thread inside its K group
+    char* smem = smem_all + kg * (STAGES * STAGE);
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int ush = p.upsample ? 1 : 0;
 
     // K position of this thread's chunk: (ky, kx, ci) advanced by 8 chunks per K-step
-    int ci = c, ky = 0, kx = 0;
+    int ci = c + 8 * kg, ky = 0, kx = 0;
     auto normalize = [&]() {
         while (ci >= p.Ctot8) {
             ci -= p.Ctot8;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const bool valid = kvalid && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
             iy >>= ush; ix >>= ush;
             const int64_t off = ((int64_t)(a_pix[i] + iy * p.W + ix)) * Cs + cc * 8;
-            const void* g = valid ? (const void*)(src + off) : (const void*)&g_zero16;
+            const void* g = valid ? (const void*)(src + off) : p.zero;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(a_s + (wave * 8 + 32 * i) * BK_BYTES), 16, 0, 0);
         }
         const int q = kt * 8 + c;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         for (int i = 0; i < B_LOADS; ++i) {
             const int n = n0 + r0 + 32 * i;
             const void* g = (n < p.Cout && q < p.KC) ? (const void*)(Wp + (int64_t)n * Kel + (int64_t)q * 8)
-                                                     : (const void*)&g_zero16;
+                                                     : p.zero;
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(b_s + (wave * 8 + 32 * i) * BK_BYTES), 16, 0, 0);
         }
     };
@@ -232,25 +239,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         // "Pipelining across barriers"): per K-step  counted vmcnt -> raw s_barrier -> issue tile
         // kt+STAGES-1 into the buffer read in step kt-1 -> MFMAs of tile kt.  The barrier both publishes
         // tile kt (every wave waited for its own DMA pieces) and retires the reads of tile kt-1.
+        // With KS groups, group kg walks the global K-steps kg, kg+KS, ...; every wave executes the same
+        // number of barriers (the step count of group 0), a group that has run out only waits.
         constexpr int L = A_LOADS + B_LOADS;   // DMA instructions per wave per tile
+        const int nk_g = (p.nk - kg + KS - 1) / KS;      // this group's K-steps
+        const int nk_0 = (p.nk + KS - 1) / KS;           // barriers of the loop
         int issued = 0;
-        for (; issued < STAGES - 1 && issued < p.nk; ++issued) {
-            if (issued > 0) { ci += 8; normalize(); }
-            dma_tile(issued, issued);
+        for (; issued < STAGES - 1 && issued < nk_g; ++issued) {
+            if (issued > 0) { ci += 8 * KS; normalize(); }
+            dma_tile(issued * KS + kg, issued);
         }
-        for (int kt = 0; kt < p.nk; ++kt) {
-            const int ahead = issued - 1 - kt;   // tiles issued after tile kt: 0 .. STAGES-2
+        for (int kt = 0; kt < nk_0; ++kt) {
+            const int ahead = issued - 1 - kt;   // tiles issued after tile kt: -1 (group ran out) .. STAGES-2
             if (ahead >= 2) wait_vmcnt<2 * L>();
             else if (ahead == 1) wait_vmcnt<L>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (issued < p.nk) {
-                ci += 8;
+            if (issued < nk_g) {
+                ci += 8 * KS;
                 normalize();
-                dma_tile(issued, issued % STAGES);
+                dma_tile(issued * KS + kg, issued % STAGES);
                 ++issued;
             }
-            compute_tile(kt % STAGES);
+            if (KS == 1 || kt < nk_g) compute_tile(kt % STAGES);
         }
         __builtin_amdgcn_s_barrier();          // all waves done with the ring before the epilogue reuses it
     } else {
@@ -277,24 +288,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     // ---- epilogue: accumulators -> LDS out tile Ct[pixel][cout] (fp32, row stride BN+4)
     constexpr int CT_STRIDE = BN + 4;
-    float* Ct = (float*)smem;
+    float* Ct = (float*)smem_all;
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
+    for (int g2 = 0; g2 < KS; ++g2) {    // K groups add their partial tiles one after the other (fixed order)
+        if (kg == g2) {
 #pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
+            for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = wm * WTM + mi * 32 + l31;
-                const int col = wn * WTN + ni * 32 + 8 * g + 4 * lh;
-                f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
-                *(f32x4*)(Ct + row * CT_STRIDE + col) = v;
-            }
-    __syncthreads();
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = wm * WTM + mi * 32 + l31;
+                        const int col = wn * WTN + ni * 32 + 8 * g + 4 * lh;
+                        f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+                        if (g2 > 0) v += *(const f32x4*)(Ct + row * CT_STRIDE + col);
+                        *(f32x4*)(Ct + row * CT_STRIDE + col) = v;
+                    }
+        }
+        __syncthreads();
+    }
 
-    constexpr int CPR = BN / 8;          // 8-channel chunks per tile row
-    constexpr int RPP = 256 / CPR;       // rows per pass
-    const int cc = tid % CPR;
-    const int rr = tid / CPR;
+    constexpr int CPR = BN / 8;               // 8-channel chunks per tile row
+    constexpr int RPP = 256 * KS / CPR;       // rows per pass
+    const int cc = (int)threadIdx.x % CPR;
+    const int rr = (int)threadIdx.x / CPR;
     const int n = n0 + cc * 8;
     if (n >= p.Cout) return;
     float bv[8];
@@ -349,12 +366,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES = 2>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES = 2, int KS = 1>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
-    constexpr int stage = STAGES * (BM + BN) * BK_BYTES;
+    constexpr int stage = KS * STAGES * (BM + BN) * BK_BYTES;
     constexpr int epi = BM * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
-    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES>;
+    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -362,7 +379,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, a);
     return rsvld_check_launch();
 }
 
@@ -402,6 +419,15 @@ int stages_override() {   // RSVLD_CONV_STAGES=2|3|4 (benchmarking only; default
     return v;
 }
 
+bool ksplit_enabled() {   // RSVLD_CONV_KSPLIT=0 disables the intra-workgroup split-K variants (A/B on hardware)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RSVLD_CONV_KSPLIT");
+        v = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <typename T, bool GLDS>
 int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     if (a.Cout <= 32) return launch_conv<T, 256, 32, 4, 1, GLDS>(a, s);
@@ -421,10 +447,16 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
         // small-M linears (Stage-2 transformer blocks at 16x16 / 32x32 tokens): even 64x128 leaves most CUs idle and
         // the K loop is a latency-bound weight stream.  64x64 tiles double the grid again; 4 x 16 KiB stages keep
         // 3 tiles in flight per workgroup at 2 workgroups per CU.
-        if (ov == 0 && wg64x128 < 256) return launch_conv<T, 64, 64, 2, 2, true, 4>(a, s);
+        if (ov == 0 && wg64x128 < 256) {
+            const int64_t wg64 = (int64_t)((a.M + 63) / 64) * ((a.Cout + 63) / 64);
+            if (ksplit_enabled() && st == 0 && wg64 <= 256 && a.nk >= 16) return launch_conv<T, 64, 64, 2, 2, true, 4, 2>(a, s);
+            return launch_conv<T, 64, 64, 2, 2, true, 4>(a, s);
+        }
     }
     if (ov == 4 || (ov == 0 && wg128 < 256)) {
         if constexpr (GLDS) {
+            // one 64x128 workgroup per CU at most and a long K loop: two K groups (8 waves) per tile
+            if (ksplit_enabled() && st == 0 && wg64x128 <= 256 && a.nk >= 16) return launch_conv<T, 64, 128, 2, 2, true, 3, 2>(a, s);
             if (st == 3 || st == 0) return launch_conv<T, 64, 128, 2, 2, true, 3>(a, s);   // 72 KiB: 2 WGs / CU
             if (st == 4) return launch_conv<T, 64, 128, 2, 2, true, 4>(a, s);
         }
@@ -463,6 +495,16 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     ConvArgs a;
     a.x = d->x; a.x2 = d->x2; a.w = d->w; a.bias = d->bias; a.rowvec = d->rowvec;
     a.residual = d->residual; a.out = d->out;
+    {   // the zero page's address is a kernel argument: taking &g_zero16 in device code reloads it through the GOT
+        // inside the K loop, and an outstanding scalar load forces every LDS wait there to lgkmcnt(0)
+        static const void* zero = nullptr;
+        if (zero == nullptr) {
+            void* z = nullptr;
+            if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero16)) != hipSuccess || z == nullptr) return RSVLD_ELAUNCH;
+            zero = z;
+        }
+        a.zero = zero;
+    }
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
     a.Ho = d->Ho; a.Wo = d->Wo; a.upsample = d->upsample ? 1 : 0;

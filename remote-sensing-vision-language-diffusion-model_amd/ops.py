@@ -7,6 +7,7 @@ current HIP stream; every computation is a kernel of librsvld_hip.so.  Activatio
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -136,7 +137,7 @@ def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
 
 # ----------------------------------------------------------------------------- conv / linear
 USE_HALO = True      # route eligible 3x3 convs through conv_halo.hip (set False to A/B against the gather kernel)
-HALO_MIN_WGS = 256   # below one workgroup per CU the 8x32-pixel halo tile under-fills the chip (measured 130 vs
+HALO_MIN_WGS = int(os.environ.get("RSVLD_HALO_MIN_WGS", "256"))   # below one workgroup per CU the 8x32-pixel halo tile under-fills the chip (measured 130 vs
                      # 334 TFLOP/s on 32x32 maps): such layers use the 64x128 gather kernel with the 3-stage ring
 
 

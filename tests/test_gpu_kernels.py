@@ -44,6 +44,9 @@ CONV_CASES = [
     (1, 256, 256, 6, 5, 3, 1, 1, True),      # fused nearest x2
     (1, 320, 640, 8, 8, 3, 1, 1, False),     # K = 2880 (not a multiple of 64 per tap)
     (1, 72, 40, 10, 10, 3, 1, 1, False),     # Cin, Cout multiples of 8 only
+    (1, 128, 512, 64, 64, 3, 1, 1, False),   # 256 tiles of 64x128: two K groups per workgroup, 18 K-steps
+    (1, 192, 512, 64, 64, 3, 1, 1, False),   # same, 27 K-steps (the second K group runs one step fewer)
+    (1, 512, 128, 31, 33, 1, 1, 0, False),   # 64x64 tiles with two K groups, ragged M
 ]
 
 
