@@ -15,6 +15,8 @@
 // L2->LDS bytes per 256 pixels x 64 channels: 43.5 KiB patch + 9 x BN x 128 B weights, vs
 // 9 x (256+BN) x 128 B for the gather.  MFMA work per barrier doubles (32 MFMAs per wave per tap).
 #include "rsvld_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -52,6 +54,105 @@ __device__ __forceinline__ int swz_off(int row, int c) { return row * 128 + ((c 
 // immediate offset -- no address arithmetic inside the tap loop.
 __device__ __forceinline__ int patch_off(int py, int px, int c) { return (py * PW + px) * 128 + ((c ^ ((px >> 1) & 7)) << 4); }
 
+// ---- epilogue shared by both halo kernels: accumulators -> LDS (fp32) -> bias / row vector / SiLU / residual ->
+// 16-byte NHWC stores, plus the per-tile per-channel (sum, sumsq) partials for the next GroupNorm.
+// EPI_PASSES passes of EPI_ROWS pixels; the staging tile aliases the (dead) operand buffers.
+template <typename T, int BN, int TM, int TN>
+__device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32x16 (&acc)[TN][TM], int tid, int wm, int wn,
+                                              int l31, int lh, int x0, int y0, int n0, int img, int tx, int ty) {
+    constexpr int EPI_PASSES = BN > 64 ? 2 : 1;
+    constexpr int EPI_ROWS = 256 / EPI_PASSES;
+    constexpr int CT_STRIDE = BN + 4;
+    float* Ct = (float*)smem;
+    constexpr int CPR = BN / 8, RPP = 256 / CPR;
+    const int cc = tid % CPR, rr = tid / CPR;
+    const int n = n0 + cc * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (p.bias != nullptr && n + e < p.Cout) ? p.bias[n + e] : 0.f;
+    // statistics of the stored tensor for the NEXT GroupNorm: this thread's 8 channels, summed over its pixels
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
+#pragma unroll
+    for (int pass = 0; pass < EPI_PASSES; ++pass) {
+        if (pass > 0) __syncthreads();
+        if ((wm * TM * 32) / EPI_ROWS == pass) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = (wm * TM + mi) * 32 + l31 - pass * EPI_ROWS;
+                        const int col = wn * (TN * 32) + ni * 32 + 8 * g + 4 * lh;
+                        f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+                        *(f32x4*)(Ct + row * CT_STRIDE + col) = v;
+                    }
+        }
+        __syncthreads();
+        if (n < p.Cout) {
+            for (int row = rr; row < EPI_ROWS; row += RPP) {
+                const int prow = pass * EPI_ROWS + row;
+                const int y = y0 + (prow >> 5), x = x0 + (prow & 31);
+                if (y >= p.H || x >= p.W) continue;
+                const int64_t m = ((int64_t)img * p.H + y) * p.W + x;
+                const f32x4 v0 = *(const f32x4*)(Ct + row * CT_STRIDE + cc * 8);
+                const f32x4 v1 = *(const f32x4*)(Ct + row * CT_STRIDE + cc * 8 + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                if (p.rowvec != nullptr) {
+                    const float* rv = p.rowvec + (int64_t)img * p.rv_stride + n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
+                if (p.act == RSVLD_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+                if (p.residual != nullptr) {
+                    float rf[8];
+                    unpack8<T>(*(const u32x4*)((const T*)p.residual + m * p.Cout_out + n), rf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += p.beta * rf[e];
+                }
+                if (p.stats != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
+                }
+                if (p.out_f32) {
+                    float* o = (float*)p.out + m * p.Cout_out + n;
+                    *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    *(u32x4*)((T*)p.out + m * p.Cout_out + n) = pack8<T>(v);
+                }
+            }
+        }
+    }
+    if (p.stats != nullptr) {   // workgroup-uniform
+        __syncthreads();        // Ct is dead: reuse it as [RPP][BN][2]
+        float* red = (float*)smem;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((rr * BN) + cc * 8 + e) * 2] = st_s[e];
+            red[((rr * BN) + cc * 8 + e) * 2 + 1] = st_q[e];
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Cout) {
+            float a = 0.f, q = 0.f;
+            for (int r = 0; r < RPP; ++r) { a += red[(r * BN + tid) * 2]; q += red[(r * BN + tid) * 2 + 1]; }
+            const int64_t tile = (int64_t)ty * p.tiles_x + tx;
+            float* o = p.stats + (((int64_t)img * p.tiles_x * p.tiles_y + tile) * p.Cout + n0 + tid) * 2;
+            o[0] = a;
+            o[1] = q;
+        }
+    }
+}
+
 // TPS = taps of weights staged per pipeline step (per barrier): 1 for BN = 128, 2 for BN = 64, so that every
 // step carries a 16 KiB weight slice and 32 MFMAs per wave
 template <typename T, int BN, int WAVES_M, int TPS>
@@ -62,9 +163,6 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     constexpr int TN = BN / (32 * WAVES_N);
     constexpr int W_BYTES = TPS * BN * 128;        // one step's weight stage
     constexpr int W_LOADS = BN / 32;
-    constexpr int EPI_PASSES = BN > 64 ? 2 : 1;
-    constexpr int EPI_ROWS = 256 / EPI_PASSES;
-    constexpr int CT_STRIDE = BN + 4;
     typedef typename Mfma<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;
@@ -221,95 +319,286 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
         }
     }
 
-    // ---- epilogue through LDS (fp32), EPI_PASSES passes of EPI_ROWS pixels
-    float* Ct = (float*)smem;
-    constexpr int CPR = BN / 8, RPP = 256 / CPR;
-    const int cc = tid % CPR, rr = tid / CPR;
-    const int n = n0 + cc * 8;
-    float bv[8];
+    halo_epilogue<T, BN, TM, TN>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv_halo32: the same halo-patch convolution with 32-channel K chunks and the patch DOUBLE-BUFFERED in LDS.
+//
+// In conv_halo_kernel the patch phase of every 64-channel chunk (global load -> GroupNorm+SiLU -> ds_write) sits between
+// two tap loops with nothing to hide it but the other workgroup of the CU (measured: the same GEMM shape runs at
+// 660-800 TFLOP/s with the fused norm and 980-1120 without).  Holding the next 64-channel patch in registers costs 44
+// VGPRs on top of 128 accumulators -- over the 2-waves-per-SIMD budget.  With 32-channel chunks a patch buffer is
+// 21.25 KiB, two of them fit where one 64-channel patch was, the prefetch needs 24 VGPRs, and the normalised pieces
+// are written straight into the idle buffer a few at a time BESIDE the MFMAs of the same wave:
+//
+//   body = two chunks A (buffer 0), B (buffer 1) = 18 taps = 9 steps of 2 taps (32 MFMAs per wave per barrier)
+//   step 0 : ...........................  end: B's loads (issued in step 8 of the previous body) are waited for
+//   step 1-3: normalise + write B, 2 pieces per step -> buffer 1 (idle since step 8 of the previous body)
+//   step 4 : taps A8, B0; request A' = first chunk of the next body (asm loads, left in flight over the barrier)
+//   step 5 : ...........................  end: A' landed
+//   step 6-8: normalise + write A' -> buffer 0 (idle since step 4);  step 8 then requests B'
+//
+// The tap loop has no load hipcc tracks: patch loads are inline asm (cdna_hip_programming.md §5.7 form ii), weights
+// and the (scale, shift) rows are LDS-DMA, waits are counted by hand (vmcnt(6) leaves exactly the 6 patch loads,
+// issued after the step's DMAs, in flight) and the barrier is raw.  NORM / NEXT are compile-time so that a step is
+// one basic block and the scheduler can place the VALU between the MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int P32_BYTES = PROWS * 64;   // one 32-channel patch buffer
+constexpr int P32_LOADS = 6;            // 340 x 4 sixteen-byte pieces over 256 threads
+constexpr int AB32_BYTES = 1024;        // one LDS-DMA wave-instruction: 512 B of (scale, shift) + 512 B duplicate
+
+// pixel (py, px) owns a 64-B row; 16-B slot s sits at s ^ ((px>>2)&3): conflict-free ds_read_b128 for every tap shift
+// (brute-forced over the lane groups of MI355X_MICROARCH.md), ky stays an immediate offset
+__device__ __forceinline__ int p32_off(int py, int px, int slot) { return (py * PW + px) * 64 + ((slot ^ ((px >> 2) & 3)) << 4); }
+__device__ __forceinline__ int w32_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int N> __device__ __forceinline__ void halo_wait_barrier() {
+    // DMA pieces older than the N youngest vector-memory operations have landed, this wave's LDS writes are done
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <typename T, int BN, int WAVES_M, int NORM>   // NORM: 0 none, 1 scale/shift, 2 scale/shift + SiLU
+__global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int TM = TH / WAVES_M;
+    constexpr int TN = BN / (32 * WAVES_N);
+    constexpr int TAP_BYTES = BN * 64;       // [BN x 32 ch] weight slice of one tap
+    constexpr int W_BYTES = 2 * TAP_BYTES;   // a step stages two taps
+    constexpr int W_LOADS = BN / 64;         // LDS-DMA instructions per thread per tap
+    typedef typename Mfma<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;                      // [2][P32_BYTES]
+    char* wbuf = smem + 2 * P32_BYTES;       // [2][W_BYTES]
+    char* abuf = wbuf + 2 * W_BYTES;         // [2][AB32_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int tx, ty, img, tile_n;
+    {
+        const int nwg = gridDim.x;
+        const int lid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, slot = lid >> 3;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tx = t % p.tiles_x; t /= p.tiles_x;
+        ty = t % p.tiles_y; t /= p.tiles_y;
+        img = t % p.B;
+        tile_n = t / p.B;
+    }
+    const int x0 = tx * TW, y0 = ty * TH, n0 = tile_n * BN;
+
+    // ---- patch roles: piece i of this thread = patch pixel (tid>>2) + 64 i, 16-byte slot c4 = tid & 3
+    const int c4 = tid & 3;
+    int poff[P32_LOADS];   // source pixel offset, -1 = zero padding / past the patch
+    int pdst[P32_LOADS];   // LDS byte offset inside a patch buffer; pieces past the patch write a dead LDS word
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = (p.bias != nullptr && n + e < p.Cout) ? p.bias[n + e] : 0.f;
-    // statistics of the stored tensor for the NEXT GroupNorm: this thread's 8 channels, summed over its pixels
-    float st_s[8], st_q[8];
+    for (int i = 0; i < P32_LOADS; ++i) {
+        const int pp = (tid >> 2) + 64 * i;
+        const int py = pp / PW, px = pp - py * PW;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        poff[i] = (pp < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y >> p.ush) * p.Ws + (x >> p.ush) : -1;
+        // dead target: the duplicate half of (scale, shift) buffer 0, never read
+        pdst[i] = pp < PROWS ? p32_off(py, px, c4) : (int)(abuf - patch) + 512 + (tid & 31) * 16;
+    }
+    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * p.Cin;
+    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * p.Cin2 : nullptr;
+    const T* __restrict__ Wp = (const T*)p.w;
+    const int64_t Kel = (int64_t)9 * p.Ctot;
+
+    u32x4 rp[P32_LOADS];
+    auto issue_patch = [&](int k32, u32x4 (&r)[P32_LOADS]) {
+        const int ch0 = k32 * 32;
+        const T* src;
+        int Cs, coff;
+        if (ch0 < p.Cin) { src = X1; Cs = p.Cin; coff = ch0 + c4 * 8; } else { src = X2; Cs = p.Cin2; coff = ch0 - p.Cin + c4 * 8; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
-#pragma unroll
-    for (int pass = 0; pass < EPI_PASSES; ++pass) {
-        if (pass > 0) __syncthreads();
-        if ((wm * TM * 32) / EPI_ROWS == pass) {
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = (wm * TM + mi) * 32 + l31 - pass * EPI_ROWS;
-                        const int col = wn * (TN * 32) + ni * 32 + 8 * g + 4 * lh;
-                        f32x4 v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
-                        *(f32x4*)(Ct + row * CT_STRIDE + col) = v;
-                    }
+        for (int i = 0; i < P32_LOADS; ++i) {
+            const T* ptr = src + (int64_t)(poff[i] < 0 ? 0 : poff[i]) * Cs + coff;   // padding reads a valid dummy, zeroed later
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[i]) : "v"(ptr) : "memory");
         }
-        __syncthreads();
-        if (n < p.Cout) {
-            for (int row = rr; row < EPI_ROWS; row += RPP) {
-                const int prow = pass * EPI_ROWS + row;
-                const int y = y0 + (prow >> 5), x = x0 + (prow & 31);
-                if (y >= p.H || x >= p.W) continue;
-                const int64_t m = ((int64_t)img * p.H + y) * p.W + x;
-                const f32x4 v0 = *(const f32x4*)(Ct + row * CT_STRIDE + cc * 8);
-                const f32x4 v1 = *(const f32x4*)(Ct + row * CT_STRIDE + cc * 8 + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    };
+    auto wait_patch = [&](u32x4 (&r)[P32_LOADS]) {   // names every destination: no consumer is scheduled above it
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : : "memory");
+    };
+    // normalise piece i and write it into patch buffer P; ab16 = (scale, shift) of this thread's 8 channels.  Branch-free.
+    auto norm_write = [&](u32x4 v, int i, const float (&ab16)[16], char* P) {
+        if (NORM != 0) {
+            float f[8];
+            unpack8<T>(v, f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bv[e];
-                if (p.rowvec != nullptr) {
-                    const float* rv = p.rowvec + (int64_t)img * p.rv_stride + n;
+            for (int e = 0; e < 8; ++e) {
+                const float t = f[e] * ab16[2 * e] + ab16[2 * e + 1];
+                f[e] = NORM == 2 ? silu_f(t) : t;
+            }
+            v = pack8<T>(f);
+        }
+        const bool inside = poff[i] >= 0;   // zero padding is applied AFTER the activation, as nn.Conv2d does
+        v = (u32x4){inside ? v[0] : 0u, inside ? v[1] : 0u, inside ? v[2] : 0u, inside ? v[3] : 0u};
+        *(u32x4*)(P + pdst[i]) = v;
+    };
+    auto lds_ab = [&](const char* row, float (&ab16)[16]) {
+        if (NORM != 0) {
+            const f32x4* a4 = (const f32x4*)row;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
-                }
-                if (p.act == RSVLD_ACT_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-                if (p.residual != nullptr) {
-                    float rf[8];
-                    unpack8<T>(*(const u32x4*)((const T*)p.residual + m * p.Cout_out + n), rf);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += p.beta * rf[e];
-                }
-                if (p.stats != nullptr) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
-                }
-                if (p.out_f32) {
-                    float* o = (float*)p.out + m * p.Cout_out + n;
-                    *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                } else {
-                    *(u32x4*)((T*)p.out + m * p.Cout_out + n) = pack8<T>(v);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = a4[q];
+                ab16[4 * q] = v[0]; ab16[4 * q + 1] = v[1]; ab16[4 * q + 2] = v[2]; ab16[4 * q + 3] = v[3];
             }
         }
-    }
-    if (p.stats != nullptr) {   // workgroup-uniform
-        __syncthreads();        // Ct is dead: reuse it as [RPP][BN][2]
-        float* red = (float*)smem;
+    };
+    // weights of flat tap g (0..17) of body b: chunk 2b + (g >= 9), tap g % 9; lane-linear LDS image, source-side swizzle.
+    // Address = uniform base (SGPR pair: tap, chunk) + 32-bit per-lane offset (row, swizzled slot): two VGPRs in all --
+    // with 64-bit per-lane pointers hipcc hoists one pointer per (tap, row group) out of the loop and spills them.
+    const int wr0 = tid >> 2;
+    const int wsl = (tid & 3) ^ ((wr0 >> 2) & 3);
+    uint32_t wvoff[W_LOADS];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[((rr * BN) + cc * 8 + e) * 2] = st_s[e];
-            red[((rr * BN) + cc * 8 + e) * 2 + 1] = st_q[e];
+    for (int i = 0; i < W_LOADS; ++i)   // rows past Cout re-read the last row; their accumulators are never stored
+        wvoff[i] = (uint32_t)(((int64_t)min(n0 + wr0 + 64 * i, p.Cout - 1) * Kel + wsl * 8) * (int64_t)sizeof(T));
+    auto dma_w = [&](int b, int st, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = 2 * st + j;
+            const int k32 = 2 * b + (g >= 9 ? 1 : 0), tap = g >= 9 ? g - 9 : g;
+            char* dst = wbuf + buf * W_BYTES + j * TAP_BYTES;
+            const char* base = (const char*)(Wp + (int64_t)tap * p.Ctot + k32 * 32);   // wave-uniform
+#pragma unroll
+            for (int i = 0; i < W_LOADS; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + wvoff[i]), (lptr_t)(dst + (wave * 16 + 64 * i) * 64), 16, 0, 0);
         }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.Cout) {
-            float a = 0.f, q = 0.f;
-            for (int r = 0; r < RPP; ++r) { a += red[(r * BN + tid) * 2]; q += red[(r * BN + tid) * 2 + 1]; }
-            const int64_t tile = (int64_t)ty * p.tiles_x + tx;
-            float* o = p.stats + (((int64_t)img * p.tiles_x * p.tiles_y + tile) * p.Cout + n0 + tid) * 2;
-            o[0] = a;
-            o[1] = q;
+    };
+    auto dma_ab = [&](int b, int buf) {   // (scale, shift) of the 64 channels of body b: 512 B, lanes 32..63 duplicate it
+        if (NORM != 0) {   // every wave issues the same piece (identical bytes): no branch in the step, uniform vmcnt
+            const float* src = p.ab + ((int64_t)img * p.Ctot + b * 64) * 2 + (lane & 31) * 4;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abuf + buf * AB32_BYTES), 16, 0, 0);
         }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    int fb_off[3][2], fa_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) fb_off[kx][ks] = p32_off(wm * TM, l31 + kx, 2 * ks + lh);
+        fa_off[ks] = w32_off(wn * (TN * 32) + l31, 2 * ks + lh);
     }
+
+    // ---- prologue: chunk 0 is the one exposed load -> normalise -> write; chunk 1 is requested with it
+    const int nb = p.nchunks;   // bodies = 64-channel pairs of 32-channel chunks
+    dma_w(0, 0, 0);
+    dma_ab(0, 0);
+    {
+        u32x4 ra[P32_LOADS];
+        issue_patch(0, ra);
+        issue_patch(1, rp);
+        float ab16[16];
+        if (NORM != 0) {
+            const float* ab = p.ab + ((int64_t)img * p.Ctot + c4 * 8) * 2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ab16[e] = ab[e];
+        }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(rp[0]), "+v"(rp[1]),
+                       "+v"(rp[2]), "+v"(rp[3]), "+v"(rp[4]), "+v"(rp[5])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int i = 0; i < P32_LOADS; ++i) norm_write(ra[i], i, ab16, patch);
+    }
+    halo_wait_barrier<0>();
+
+    int s = 0;   // global step: weight stage parity
+    auto body = [&](int b, auto next_c) {
+        constexpr bool NEXT = decltype(next_c)::value;
+#pragma unroll
+        for (int st = 0; st < 9; ++st, ++s) {
+            if (st < 8) dma_w(b, st + 1, (s + 1) & 1);
+            else if (NEXT) dma_w(b + 1, 0, (s + 1) & 1);
+            if (st == 4 && NEXT) {
+                dma_ab(b + 1, (b + 1) & 1);
+                issue_patch(2 * b + 2, rp);
+            }
+            if (st >= 1 && st <= 3) {          // B of this body -> buffer 1
+                float ab16[16];
+                lds_ab(abuf + (b & 1) * AB32_BYTES + 256 + c4 * 64, ab16);
+                norm_write(rp[2 * (st - 1)], 2 * (st - 1), ab16, patch + P32_BYTES);
+                norm_write(rp[2 * (st - 1) + 1], 2 * (st - 1) + 1, ab16, patch + P32_BYTES);
+            }
+            if (st >= 6 && NEXT) {             // A' of the next body -> buffer 0
+                float ab16[16];
+                lds_ab(abuf + ((b + 1) & 1) * AB32_BYTES + c4 * 64, ab16);
+                norm_write(rp[2 * (st - 6)], 2 * (st - 6), ab16, patch);
+                norm_write(rp[2 * (st - 6) + 1], 2 * (st - 6) + 1, ab16, patch);
+            }
+            if (st == 8 && NEXT) issue_patch(2 * b + 3, rp);
+            const char* w_st = wbuf + (s & 1) * W_BYTES;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = 2 * st + j;
+                const int par = g >= 9 ? 1 : 0, tap = g >= 9 ? g - 9 : g;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const char* P = patch + par * P32_BYTES;
+                const char* w_s = w_st + j * TAP_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    v8 fa[TN], fb[TM];
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + fa_off[ks] + ni * (32 * 64));
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) fb[mi] = *(const v8*)(P + fb_off[kx][ks] + (mi + ky) * (PW * 64));
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
+                }
+            }
+            // end of step: the DMAs of this step (weights of the next step, (scale, shift) rows) must have landed; patch
+            // loads issued in this step (after those DMAs) stay in flight
+            if ((st == 4 || st == 8) && NEXT) {
+                halo_wait_barrier<P32_LOADS>();
+            } else {
+                if ((st == 5 || st == 0)) wait_patch(rp);
+                halo_wait_barrier<0>();
+            }
+        }
+    };
+    for (int b = 0; b + 1 < nb; ++b) body(b, std::true_type{});
+    body(nb - 1, std::false_type{});
+
+    halo_epilogue<T, BN, TM, TN>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
+}
+
+template <typename T, int BN, int WAVES_M>
+int launch_halo32(const HaloArgs& a, hipStream_t s) {
+    constexpr int stage = 2 * P32_BYTES + 2 * (2 * BN * 64) + 2 * AB32_BYTES;
+    constexpr int epi = (256 / (BN > 64 ? 2 : 1)) * (BN + 4) * 4;
+    constexpr int smem = stage > epi ? stage : epi;
+    const int norm = a.ab == nullptr ? 0 : (a.norm_silu ? 2 : 1);
+    const int64_t nwg = (int64_t)a.tiles_x * a.tiles_y * a.B * ((a.Cout + BN - 1) / BN);
+    if (nwg >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
+    auto go = [&](auto kern) -> int {
+        // per-instantiation flag: the lambda is instantiated once per kernel type
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+                return RSVLD_ELAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
+        return rsvld_check_launch();
+    };
+    if (norm == 0) return go(conv_halo32_kernel<T, BN, WAVES_M, 0>);
+    if (norm == 1) return go(conv_halo32_kernel<T, BN, WAVES_M, 1>);
+    return go(conv_halo32_kernel<T, BN, WAVES_M, 2>);
 }
 
 template <typename T, int BN, int WAVES_M, int TPS>
@@ -333,7 +622,9 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
 template <typename T>
 int dispatch_halo(const HaloArgs& a, hipStream_t s) {
     if (a.Cout <= 64) return launch_halo<T, 64, 4, 2>(a, s);
-    return launch_halo<T, 128, 2, 1>(a, s);
+    static const bool old128 = getenv("RSVLD_HALO_OLD128") != nullptr;   // A/B switch: the single-buffered 64-channel kernel
+    if (old128) return launch_halo<T, 128, 2, 1>(a, s);
+    return launch_halo32<T, 128, 2>(a, s);
 }
 
 }  // namespace

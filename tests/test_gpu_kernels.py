@@ -75,6 +75,9 @@ HALO_CASES = [
     (1, 320, 0, 320, 8, 16, True),      # W = 16 (half-filled tile), 5 channel chunks
     (1, 64, 0, 8, 24, 40, True),        # final conv: Cout 3 padded to 8
     (1, 192, 0, 64, 12, 64, False),     # plain 3x3 conv through the halo kernel (no norm)
+    (2, 192, 0, 128, 10, 35, False),    # no norm, BN = 128 (double-buffered 32-channel patch pipeline), 3 bodies, batch 2
+    (2, 512, 512, 128, 8, 32, True),    # 16 bodies across two sources: every steady-state prefetch slot is exercised
+    (3, 64, 0, 128, 9, 31, True),       # single body (no prefetch beyond the prologue), batch 3
 ]
 
 

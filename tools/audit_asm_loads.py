@@ -1,0 +1,74 @@
+"""Audit of hipcc output for kernels that hide register loads in inline asm (cdna_hip_programming.md §5.7 item 1):
+between an inline-asm `global_load_*` and the next inline-asm `s_waitcnt vmcnt(0)`, no instruction may read or write
+the load's destination registers (hipcc considers them written at ASMEND).  Linear scan of the .s text per kernel
+(every asm wait in these kernels post-dominates the loads of its pipeline stage, so program order is sufficient).
+
+usage: python tools/audit_asm_loads.py file.s [kernel-name-substring]
+"""
+import re
+import sys
+
+
+def regs(code):
+    out = []
+    for m in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', code):
+        out.append((int(m.group(1)), int(m.group(2))) if m.group(1) else (int(m.group(3)), int(m.group(3))))
+    return out
+
+
+def audit(lines, name):
+    pending, bad, in_asm, n_loads = [], 0, False, 0
+    for ln, line in enumerate(lines, 1):
+        t = line.strip()
+        if t.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if t.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        code = t.split(';')[0]
+        if not code or code.endswith(':') or code.startswith('.'):
+            continue
+        if in_asm and code.startswith('global_load'):
+            r = regs(code)
+            pending.append(r[0])
+            n_loads += 1
+            for a, b in r[1:]:   # address registers of this load must not be an in-flight destination
+                for lo, hi in pending[:-1]:
+                    if a <= hi and b >= lo:
+                        print(f"{name}:{ln}: address reads in-flight destination: {t}")
+                        bad += 1
+            continue
+        if in_asm and code.startswith('s_waitcnt') and 'vmcnt(0)' in code:
+            pending = []
+            continue
+        for a, b in regs(code):
+            for lo, hi in pending:
+                if a <= hi and b >= lo:
+                    print(f"{name}:{ln}: touches in-flight v[{lo}:{hi}]: {t}")
+                    bad += 1
+    return n_loads, bad
+
+
+def main():
+    text = open(sys.argv[1]).read().split('\n')
+    want = sys.argv[2] if len(sys.argv) > 2 else ''
+    cur, buf, total_bad = None, [], 0
+    for line in text:
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            cur, buf = m.group(1), []
+        elif cur is not None:
+            buf.append(line)
+            if 's_endpgm' in line:
+                if want in cur:
+                    n, bad = audit(buf, cur)
+                    if n:
+                        print(f"{cur}: {n} asm loads, {bad} violations")
+                    total_bad += bad
+                cur = None
+    sys.exit(1 if total_bad else 0)
+
+
+if __name__ == '__main__':
+    main()
