@@ -156,7 +156,10 @@ int rsvld_attention(const void* q, const void* k, const void* v, void* out,
                     int64_t k_batch_stride, int64_t k_tok_stride,
                     int64_t v_batch_stride, int64_t v_tok_stride,
                     int64_t o_batch_stride, int64_t o_tok_stride,
-                    float scale, int dtype, void* stream);
+                    float scale, int dtype, void* ws, void* stream);
+/* bytes of `ws` the call above needs (0 = none, ws may be NULL): the D = 512 kernel splits the keys over
+ * workgroups when the query tiles alone cannot fill the chip and merges the partial results from ws. */
+int64_t rsvld_attention_ws_bytes(int B, int heads, int Nq, int Nk, int D);
 
 /* ---------------------------------------------------------------------------------------
  * Small dense layers on embeddings (rows <= 64): y = act_out( W * act_in(x) + b ), fp32.

@@ -14,6 +14,7 @@
 //   V^T [d][kv] so both MFMA operands are ds_read_b128 along the contraction dim.
 //   Next tile's K/V global loads are issued before the S phase (register prefetch).
 #include "rsvld_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -26,6 +27,9 @@ struct AttnArgs {
     int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
     float scale_log2e;
 };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int A5_KS = 0;
 constexpr int A5_VT = 32768;
@@ -250,6 +254,279 @@ __global__ __launch_bounds__(512) void attn_d512_kernel(AttnArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// D = 512, second generation: one wave owns 32 query rows over the WHOLE head dimension.
+//
+// attn_d512_kernel above splits the head dimension over waves, so every 32-key tile pays a
+// cross-wave reduction of partial scores through LDS (36 KB written and re-read), a softmax by
+// other threads than the ones that hold the scores, P through LDS, and three barriers for
+// 16 MFMAs per wave.  Here (workgroup = 4 waves = 128 query rows, one workgroup per CU,
+// 512 registers per wave):
+//   * Q (32 rows x 512) stays in 128 VGPRs as the B operand of S^T = K Q^T;
+//   * S^T is computed swapped (keys on the accumulator registers, the query on the lane), so the
+//     online softmax is register-local (one shuffle with lane^32) and P is cast in place into
+//     the B operand of O^T += V^T P^T (cdna_hip_programming.md §3 "An accumulator tile as the
+//     next MFMA's operand");
+//   * O^T (512 x 32 per wave) lives in 256 accumulator registers;
+//   * K and V tiles (32 keys x 512, 32 KB each) are double-buffered in LDS and filled by LDS-DMA
+//     only (no staging registers, no transpose pass): K is read row-wise (ds_read_b128), V is
+//     read through the hardware transpose ds_read_b64_tr_b16 (T10), both images XOR-swizzled on
+//     the DMA source side so that every read is bank-conflict-free;
+//   * one barrier per tile, 64 MFMAs per wave between barriers.
+// Split-KV: when the query tiles alone cannot fill the chip, blockIdx.y walks key ranges and the
+// partial (O / l, m, l) triples are merged by attn_combine_kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int A5B_TILE = 32 * 1024;        // one 32-key x 512 tile, 16-bit
+constexpr int A5B_SMEM = 4 * A5B_TILE;     // K[2] | V[2]
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_per_split, float* part_o, float* part_ml) {
+    constexpr int D = 512;
+    typedef typename Mfma<T>::v8 v8;
+    typedef typename Mfma<T>::v4 v4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int b = blockIdx.z / p.heads, h = blockIdx.z % p.heads;
+    const int k_begin = split * keys_per_split;
+    const int k_end = min(p.Nk, k_begin + keys_per_split);
+    const int nt = (k_end - k_begin + 31) >> 5;
+    const T* Qb = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
+    const T* Kb = (const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D;
+    const T* Vb = (const T*)p.v + (int64_t)b * p.v_bs + (int64_t)h * D;
+
+    // ---- tile DMA: wave w moves key rows 8w .. 8w+7 of the tile, one 1-KiB row per wave-instruction.
+    // LDS chunk position `lane` of row r holds source chunk lane ^ (r & 15) (K) / lane ^ ((r & 3) << 2) (V).
+    // Row addresses are wave-uniform (scalar ALU); the per-lane part is a 32-bit byte offset.
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    auto dma_tile = [&](int t, int buf) {
+        char* Kd = smem + buf * A5B_TILE;
+        char* Vd = smem + 2 * A5B_TILE + buf * A5B_TILE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wu * 8 + i;
+            const int key = min(k_begin + t * 32 + r, p.Nk - 1);   // rows past the end re-read the last key; masked below
+            const char* krow = (const char*)(Kb + (int64_t)key * p.k_ts);
+            const char* vrow = (const char*)(Vb + (int64_t)key * p.v_ts);
+            const uint32_t ko = (uint32_t)((lane ^ (r & 15)) << 4), vo = (uint32_t)((lane ^ ((i & 3) << 2)) << 4);
+            __builtin_amdgcn_global_load_lds((gptr_t)(krow + ko), (lptr_t)(Kd + r * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vrow + vo), (lptr_t)(Vd + r * 1024), 16, 0, 0);
+        }
+    };
+    dma_tile(0, 0);
+
+    // ---- Q fragments (B operand: col = query row on the lane, k = d)
+    const int qrow = q0 + l31;
+    v8 qf[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (qrow < p.Nq) v = *(const u32x4*)(Qb + (int64_t)qrow * p.q_ts + ks * 16 + lh * 8);
+        qf[ks] = __builtin_bit_cast(v8, v);
+    }
+    f32x16 oacc[16];
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- per-lane read offsets.  K: row l31, chunk 2ks+lh = 16a + (2c+lh): off = kbase[c] + 256 a.
+    int kbase[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kbase[c] = l31 * 1024 + (((2 * c + lh) ^ (l31 & 15)) << 4);
+    // V (transposed read): lane 16g + 4q + p supplies row (4lh + q) + {16s + 8hf}, d = 32dt + 16(g&1) + 4p .. +3;
+    // chunk = 4dt + 2(g&1) + (p>>1), swizzled by q<<2: with dt = 4e + f  ->  off = vbase[f] + 256 e + 1024 (16s + 8hf)
+    int vbase[4];
+    {
+        const int qq = (lane >> 2) & 3, pp = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            vbase[f] = 2 * A5B_TILE + (4 * lh + qq) * 1024 + ((f ^ qq) << 6) + ((2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
+    }
+
+    __syncthreads();   // tile 0 landed (vmcnt(0) + barrier)
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) dma_tile(t + 1, buf ^ 1);   // the other buffer was last read in tile t-1, before the barrier
+        const char* Ks = smem + buf * A5B_TILE;
+        const int vb = buf * A5B_TILE;
+
+        // ---- S^T[key][q] over the whole head dimension: one accumulation chain of 32 MFMAs.
+        // The chain is issued in its VGPR form by inline asm: all 256 accumulator registers belong to O, and hipcc
+        // otherwise parks the score tile in a0..a15 and shuttles one O tile through VGPRs every iteration.  Back-to-back
+        // MFMAs that take the previous D whole as C need no wait states; the VALU reader after the chain does
+        // (cdna_hip_programming.md §5.7 item 2), hence the trailing s_nop pair.  hipcc never hoists an LDS read above
+        // the MFMA before its consumer, so the fragment ring (KD reads in flight) is written out and its order pinned
+        // with sched_barrier; the waitcnt pass then emits counted lgkmcnt waits.
+        constexpr int KD = 4;
+        auto kread = [&](int ks) { return *(const v8*)(Ks + kbase[ks & 7] + (ks >> 3) * 256); };
+        v8 kfr[KD];
+#pragma unroll
+        for (int i = 0; i < KD; ++i) kfr[i] = kread(i);
+        f32x16 sacc;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            if (ks == 0) {
+                if constexpr (__is_same(T, f16))
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sacc) : "v"(kfr[0]), "v"(qf[0]));
+                else
+                    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sacc) : "v"(kfr[0]), "v"(qf[0]));
+            } else {
+                if constexpr (__is_same(T, f16))
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc) : "v"(kfr[ks % KD]), "v"(qf[ks]));
+                else
+                    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc) : "v"(kfr[ks % KD]), "v"(qf[ks]));
+            }
+            if (ks + KD < 32) kfr[ks % KD] = kread(ks + KD);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // first V fragments: in flight behind the softmax
+        constexpr int VD = 3;
+        auto vread = [&](int n) {
+            const int dt = n >> 1, s2 = n & 1;
+            const int off = vb + vbase[dt & 3] + (dt >> 2) * 256 + (16 * s2) * 1024;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off + 8 * 1024));
+            typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+            return __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        v8 vfr[VD];
+#pragma unroll
+        for (int i = 0; i < VD; ++i) vfr[i] = vread(i);
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc));
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- online softmax, register-local: this lane holds 16 of its query's 32 scores, lane^32 the rest
+        if (k_begin + (t + 1) * 32 > k_end) {   // ragged last tile (uniform branch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = k_begin + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (kv >= k_end) sacc[r] = -INFINITY;
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] *= p.scale_log2e;
+            mx = fmaxf(mx, sacc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // deferred max (T13): the reference point moves only when the tile max exceeds it by more than 2^8, so the
+        // rescale of O (256 accumulator registers through VGPRs) is skipped on almost every tile
+        const bool need = mx > m_run + A5_DEFER_LOG2;   // true on the first tile (m_run = -inf)
+        float alpha = 1.0f;
+        if (need) {
+            alpha = __builtin_amdgcn_exp2f(m_run - mx);
+            m_run = mx;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run);
+            rs += sacc[r];
+        }
+        l_run = l_run * alpha + rs;
+        if (__any(need)) {
+            // O lives in the accumulator file; written as plain C++ (oacc *= alpha) hipcc pulls all 256 values into
+            // VGPRs at once and spills 375 registers.  One element at a time through a scratch VGPR instead; the
+            // write -> MFMA hazard (cdna_hip_programming.md §5.7 item 2) is covered by the s_nop that ends each string,
+            // the MFMA -> read hazard by the 32 S-phase MFMAs since the last PV MFMA.
+#pragma unroll
+            for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = oacc[dt][r], tmp;
+                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1\n\ts_nop 1"
+                                 : "+a"(x), "=&v"(tmp)
+                                 : "v"(alpha));
+                    oacc[dt][r] = x;
+                }
+        }
+        // P as the B operand of k-step s: registers 8s..8s+7 <-> keys 16s + 8(j>>2) + 4lh + (j&3)
+        v8 pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[s2][j] = (T)sacc[8 * s2 + j];
+
+        // ---- O^T[d][q] += V^T P^T; the A operand (row = d, k = the same key order) is two transposed reads:
+        // elements 0..3 = keys 16s + 4lh + 0..3, elements 4..7 = keys 16s + 8 + 4lh + 0..3.  Same explicit ring.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            oacc[n >> 1] = Mfma<T>::mma(vfr[n % VD], pf[n & 1], oacc[n >> 1]);
+            if (n + VD < 32) vfr[n % VD] = vread(n + VD);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();   // next tile landed (vmcnt(0)); everyone done with this tile's buffers
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (qrow >= p.Nq) return;
+    const float inv = 1.0f / l_tot;
+    if (nsplit == 1) {
+        T* Ob = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)h * D + (int64_t)qrow * p.o_ts;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)(oacc[dt][4 * g + e] * inv);
+                *(v4*)(Ob + dt * 32 + 8 * g + 4 * lh) = o;
+            }
+    } else {
+        const int64_t row = ((int64_t)split * gridDim.z + blockIdx.z) * p.Nq + qrow;
+        float* Po = part_o + row * D;
+#pragma unroll
+        for (int dt = 0; dt < 16; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = oacc[dt][4 * g + e] * inv;
+                *(f32x4*)(Po + dt * 32 + 8 * g + 4 * lh) = o;
+            }
+        if (lh == 0) {
+            part_ml[row * 2] = m_run;
+            part_ml[row * 2 + 1] = l_tot;
+        }
+    }
+}
+
+// merge of split-KV partials: out = sum_i w_i O_i / sum_i w_i,  w_i = l_i 2^(m_i - max m)
+template <typename T>
+__global__ __launch_bounds__(128) void attn_combine_kernel(AttnArgs p, int nsplit, const float* part_o, const float* part_ml) {
+    constexpr int D = 512;
+    typedef typename Mfma<T>::v4 v4;
+    const int qrow = blockIdx.x, bh = blockIdx.y;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int64_t nrows = (int64_t)gridDim.y * p.Nq;
+    float mmax = -INFINITY;
+    for (int i = 0; i < nsplit; ++i) mmax = fmaxf(mmax, part_ml[((int64_t)i * nrows + (int64_t)bh * p.Nq + qrow) * 2]);
+    float wsum = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < nsplit; ++i) {
+        const int64_t row = (int64_t)i * nrows + (int64_t)bh * p.Nq + qrow;
+        const float wi = part_ml[row * 2 + 1] * __builtin_amdgcn_exp2f(part_ml[row * 2] - mmax);
+        const f32x4 o = *(const f32x4*)(part_o + row * D + threadIdx.x * 4);
+        acc += o * wi;
+        wsum += wi;
+    }
+    const float inv = 1.0f / wsum;
+    v4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (T)(acc[e] * inv);
+    *(v4*)((T*)p.out + (int64_t)b * p.o_bs + (int64_t)h * D + (int64_t)qrow * p.o_ts + threadIdx.x * 4) = o;
+}
+
 }  // namespace
 
 namespace {
@@ -469,10 +746,34 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(AttnArgs p) {
 
 }  // namespace
 
+// split-KV plan of the D = 512 kernel: key ranges per workgroup so that the grid fills the 256 CUs
+static void attn512_plan(int B, int heads, int Nq, int Nk, int* nsplit, int* keys_per_split) {
+    const int64_t base = (int64_t)((Nq + 127) / 128) * B * heads;
+    int ns = 1;
+    if (base < 192) {
+        ns = (int)((256 + base - 1) / base);
+        const int cap = Nk / 256 > 1 ? Nk / 256 : 1;   // at least 8 key tiles per range
+        if (ns > cap) ns = cap;
+        if (ns > 16) ns = 16;
+    }
+    int kps = ((Nk + ns - 1) / ns + 31) / 32 * 32;
+    *keys_per_split = kps;
+    *nsplit = (Nk + kps - 1) / kps;
+}
+
+extern "C" int64_t rsvld_attention_ws_bytes(int B, int heads, int Nq, int Nk, int D) {
+    if (D != 512 || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return 0;
+    int ns, kps;
+    attn512_plan(B, heads, Nq, Nk, &ns, &kps);
+    if (ns == 1) return 0;
+    return (int64_t)ns * B * heads * Nq * (512 + 2) * 4;
+}
+
 extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
                                int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
                                int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride,
-                               int64_t o_batch_stride, int64_t o_tok_stride, float scale, int dtype, void* stream) {
+                               int64_t o_batch_stride, int64_t o_tok_stride, float scale, int dtype, void* ws,
+                               void* stream) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return RSVLD_EINVAL;
     if (dtype != RSVLD_F16 && dtype != RSVLD_BF16) return RSVLD_EINVAL;
     // 16-byte vector access along d: strides must keep rows 8-element aligned
@@ -488,6 +789,28 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
     a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     if (D == 512) {
+        static const bool v1 = getenv("RSVLD_ATTN512_V1") != nullptr;   // A/B switch: the split-head-dimension kernel
+        if (!v1) {
+            int ns, kps;
+            attn512_plan(B, heads, Nq, Nk, &ns, &kps);
+            if (ns > 1 && ws == nullptr) return RSVLD_EINVAL;
+            float* part_o = (float*)ws;
+            float* part_ml = ns > 1 ? part_o + (int64_t)ns * B * heads * Nq * 512 : nullptr;
+            dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)ns, (unsigned)(B * heads));
+            auto go = [&](auto kern, auto comb) -> int {
+                static bool set = false;
+                if (!set) {
+                    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, A5B_SMEM) != hipSuccess)
+                        return RSVLD_ELAUNCH;
+                    set = true;
+                }
+                hipLaunchKernelGGL(kern, grid, dim3(256), A5B_SMEM, s, a, kps, part_o, part_ml);
+                if (ns > 1) hipLaunchKernelGGL(comb, dim3((unsigned)Nq, (unsigned)(B * heads)), dim3(128), 0, s, a, ns, part_o, part_ml);
+                return rsvld_check_launch();
+            };
+            return dtype == RSVLD_F16 ? go(attn_d512b_kernel<f16>, attn_combine_kernel<f16>)
+                                      : go(attn_d512b_kernel<bf16>, attn_combine_kernel<bf16>);
+        }
         dim3 grid((unsigned)((Nq + 63) / 64), (unsigned)heads, (unsigned)B);
         if (dtype == RSVLD_F16) {
             static bool set = false;

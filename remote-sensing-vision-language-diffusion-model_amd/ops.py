@@ -324,10 +324,12 @@ def attention(q, k, v, heads, scale=None):
     lib = L.load()
     flops = 4.0 * B * heads * Nq * Nk * D
     nbytes = (q.shape[0] * Nq * HD * 2 + 2 * B * Nk * HD) * q.element_size()
+    ws_bytes = lib.rsvld_attention_ws_bytes(B, heads, Nq, Nk, D)   # split-KV partials (D = 512, small grids)
+    ws = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8) if ws_bytes > 0 else None
     _launch(f"attention_d{D}", flops, nbytes, lambda: L.check(
         lib.rsvld_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
                             q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                            out.stride(0), out.stride(1), scale, _dt(q), _stream()), "rsvld_attention"))
+                            out.stride(0), out.stride(1), scale, _dt(q), _ptr(ws), _stream()), "rsvld_attention"))
     return out
 
 

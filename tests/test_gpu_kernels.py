@@ -282,7 +282,8 @@ def test_layer_norm(cuda, dtype, Cc):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(1, 64, 64), (2, 144, 144), (1, 1, 1), (1, 100, 333), (2, 1024, 1024)])
+@pytest.mark.parametrize("shape", [(1, 64, 64), (2, 144, 144), (1, 1, 1), (1, 100, 333), (2, 1024, 1024), (24, 1000, 160),
+                                   (1, 300, 2500)])   # split-KV (4 and 9 key ranges), no split, ragged last range
 def test_attention_d512(cuda, dtype, shape):
     from rsvld_amd import ops
     B, Nq, Nk = shape

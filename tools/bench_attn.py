@@ -1,0 +1,30 @@
+"""Times rsvld_attention on the Stage-1 (d = 512, one head) and Stage-2 (d = 64, multi-head) shapes.
+RSVLD_ATTN512_V1=1 selects the first-generation d = 512 kernel for A/B runs."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rsvld_amd import ops
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+reps = int(os.environ.get("REPS", 10))
+CASES = [(4, 1, 4096, 512), (4, 1, 1024, 512), (1, 1, 16384, 512), (1, 1, 65536, 512),
+         (2, 10, 4096, 64), (2, 20, 1024, 64), (2, 10, 16384, 64)]
+if os.environ.get("ONLY512"):
+    CASES = [c for c in CASES if c[3] == 512]
+print("d512 kernel:", "v1" if os.environ.get("RSVLD_ATTN512_V1") else "v2")
+for (B, heads, N, D) in CASES:
+    qkv = torch.randn(B, N, 3 * heads * D, device=dev, dtype=torch.float16)
+    q, k, v = qkv[..., :heads * D], qkv[..., heads * D:2 * heads * D], qkv[..., 2 * heads * D:]
+    for _ in range(2):
+        o = ops.attention(q, k, v, heads)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        o = ops.attention(q, k, v, heads)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 4.0 * B * heads * N * N * D
+    print(f"B{B} heads{heads} N{N} D{D}: {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TF/s", flush=True)
