@@ -15,6 +15,8 @@
 //   Next tile's K/V global loads are issued before the S phase (register prefetch).
 #include "rsvld_common.h"
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -30,6 +32,14 @@ struct AttnArgs {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// compile-time loop: f(std::integral_constant<int, i>) for i = 0..N-1 (inline-asm "i" operands need constants)
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 constexpr int A5_KS = 0;
 constexpr int A5_VT = 32768;
@@ -302,23 +312,29 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
 
     // ---- tile DMA: wave w moves key rows 8w .. 8w+7 of the tile, one 1-KiB row per wave-instruction.
     // LDS chunk position `lane` of row r holds source chunk lane ^ (r & 15) (K) / lane ^ ((r & 3) << 2) (V).
-    // Row addresses are wave-uniform (scalar ALU); the per-lane part is a 32-bit byte offset.
+    // Row addresses are wave-uniform (SGPR base), the per-lane part is a 32-bit byte offset.  The DMAs are inline asm:
+    // (1) an LDS-DMA costs the issuing wave ~60-180 cycles, so the 16 of a tile are spread between the MFMAs of the
+    // S chain instead of standing in front of it; (2) hipcc puts s_waitcnt vmcnt(0) in front of the first LDS read that
+    // follows an LDS-DMA it knows of, which would drain the prefetch at the start of every PV phase.  M0 (the LDS
+    // destination) is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md §5.7).
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    auto dma_tile = [&](int t, int buf) {
-        char* Kd = smem + buf * A5B_TILE;
-        char* Vd = smem + 2 * A5B_TILE + buf * A5B_TILE;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = wu * 8 + i;
-            const int key = min(k_begin + t * 32 + r, p.Nk - 1);   // rows past the end re-read the last key; masked below
-            const char* krow = (const char*)(Kb + (int64_t)key * p.k_ts);
-            const char* vrow = (const char*)(Vb + (int64_t)key * p.v_ts);
-            const uint32_t ko = (uint32_t)((lane ^ (r & 15)) << 4), vo = (uint32_t)((lane ^ ((i & 3) << 2)) << 4);
-            __builtin_amdgcn_global_load_lds((gptr_t)(krow + ko), (lptr_t)(Kd + r * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(vrow + vo), (lptr_t)(Vd + r * 1024), 16, 0, 0);
-        }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    auto dma_row = [&](int t, int buf, int i) {
+        const int r = wu * 8 + i;
+        const int key = min(k_begin + t * 32 + r, p.Nk - 1);   // rows past the end re-read the last key; masked below
+        const char* krow = (const char*)(Kb + (int64_t)key * p.k_ts);
+        const char* vrow = (const char*)(Vb + (int64_t)key * p.v_ts);
+        const uint32_t ko = (uint32_t)((lane ^ (r & 15)) << 4), vo = (uint32_t)((lane ^ ((i & 3) << 2)) << 4);
+        const uint32_t kd = lds0 + buf * A5B_TILE + r * 1024, vd = kd + 2 * A5B_TILE;
+        uint32_t keep;
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(ko), "s"(kd), "s"(krow), "s"(vd), "v"(vo), "s"(vrow)
+                     : "memory");
     };
-    dma_tile(0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_row(0, 0, i);
 
     // ---- Q fragments (B operand: col = query row on the lane, k = d)
     const int qrow = q0 + l31;
@@ -350,45 +366,60 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
             vbase[f] = 2 * A5B_TILE + (4 * lh + qq) * 1024 + ((f ^ qq) << 6) + ((2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
     }
 
-    __syncthreads();   // tile 0 landed (vmcnt(0) + barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile 0 landed
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) dma_tile(t + 1, buf ^ 1);   // the other buffer was last read in tile t-1, before the barrier
-        const char* Ks = smem + buf * A5B_TILE;
+        const bool more = t + 1 < nt;   // tile t+1 goes into the other buffer, last read in tile t-1 before the barrier
         const int vb = buf * A5B_TILE;
 
         // ---- S^T[key][q] over the whole head dimension: one accumulation chain of 32 MFMAs.
         // The chain is issued in its VGPR form by inline asm: all 256 accumulator registers belong to O, and hipcc
         // otherwise parks the score tile in a0..a15 and shuttles one O tile through VGPRs every iteration.  Back-to-back
         // MFMAs that take the previous D whole as C need no wait states; the VALU reader after the chain does
-        // (cdna_hip_programming.md §5.7 item 2), hence the trailing s_nop pair.  hipcc never hoists an LDS read above
-        // the MFMA before its consumer, so the fragment ring (KD reads in flight) is written out and its order pinned
-        // with sched_barrier; the waitcnt pass then emits counted lgkmcnt waits.
-        constexpr int KD = 4;
-        auto kread = [&](int ks) { return *(const v8*)(Ks + kbase[ks & 7] + (ks >> 3) * 256); };
+        // (cdna_hip_programming.md §5.7 item 2), hence the trailing s_nop pair.  The K fragment reads are asm as well:
+        // hipcc waits lgkmcnt(0) in front of an asm consumer, which stalls the chain on the read it has just issued;
+        // here KD reads are in flight and MFMA ks waits only for its own (lgkmcnt(min(KD-1, 31-ks)); LDS returns in
+        // order, and any SMEM operation the compiler may have in flight only makes the count more conservative).
+        constexpr int KD = 6;
+        uint32_t ka[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ka[c] = (uint32_t)(uintptr_t)(lptr_t)smem + (uint32_t)(buf * A5B_TILE + kbase[c]);
         v8 kfr[KD];
-#pragma unroll
-        for (int i = 0; i < KD; ++i) kfr[i] = kread(i);
         f32x16 sacc;
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) {
-            if (ks == 0) {
-                if constexpr (__is_same(T, f16))
-                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sacc) : "v"(kfr[0]), "v"(qf[0]));
-                else
-                    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sacc) : "v"(kfr[0]), "v"(qf[0]));
-            } else {
-                if constexpr (__is_same(T, f16))
-                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc) : "v"(kfr[ks % KD]), "v"(qf[ks]));
-                else
-                    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc) : "v"(kfr[ks % KD]), "v"(qf[ks]));
-            }
-            if (ks + KD < 32) kfr[ks % KD] = kread(ks + KD);
-            __builtin_amdgcn_sched_barrier(0);
+        // (macros, not lambdas: clang rejects captured arrays as asm operands inside generic lambdas)
+#define A5B_KREAD(slot, ks) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kfr[slot]) : "v"(ka[(ks) & 7]), "i"(((ks) >> 3) * 256))
+#define A5B_STEP(NAME, ks)                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" NAME " %0, %1, %2, %0"                                                      \
+                 : "+v"(sacc)                                                                                           \
+                 : "v"(kfr[(ks) % KD]), "v"(qf[ks]), "i"(KD - 1 < 31 - (ks) ? KD - 1 : 31 - (ks)));                      \
+    if constexpr ((ks) + KD < 32) A5B_KREAD((ks) % KD, (ks) + KD)
+#define A5B_DMA(i) if (more) dma_row(t + 1, buf ^ 1, i)
+#define A5B_STEP4(NAME, k) A5B_STEP(NAME, k); A5B_STEP(NAME, (k) + 1); A5B_STEP(NAME, (k) + 2); A5B_STEP(NAME, (k) + 3)
+#define A5B_CHAIN(NAME)                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" NAME " %0, %1, %2, 0" : "=&v"(sacc) : "v"(kfr[0]), "v"(qf[0]), "i"(KD - 1)); \
+    A5B_KREAD(0, KD);                                                                                                   \
+    A5B_STEP(NAME, 1); A5B_DMA(0); A5B_STEP(NAME, 2); A5B_STEP(NAME, 3);                                                \
+    A5B_STEP4(NAME, 4); A5B_DMA(1); A5B_STEP4(NAME, 8); A5B_DMA(2); A5B_STEP4(NAME, 12); A5B_DMA(3);                    \
+    A5B_STEP4(NAME, 16); A5B_DMA(4); A5B_STEP4(NAME, 20); A5B_DMA(5); A5B_STEP4(NAME, 24); A5B_DMA(6);                  \
+    A5B_STEP4(NAME, 28); A5B_DMA(7)
+        static_assert(KD == 6, "the prologue below issues 6 reads");
+        A5B_KREAD(0, 0); A5B_KREAD(1, 1); A5B_KREAD(2, 2); A5B_KREAD(3, 3); A5B_KREAD(4, 4); A5B_KREAD(5, 5);
+        if constexpr (__is_same(T, f16)) {
+            A5B_CHAIN("v_mfma_f32_32x32x16_f16");
+        } else {
+            A5B_CHAIN("v_mfma_f32_32x32x16_bf16");
         }
+#undef A5B_CHAIN
+#undef A5B_DMA
+#undef A5B_STEP4
+#undef A5B_STEP
+#undef A5B_KREAD
+        __builtin_amdgcn_sched_barrier(0);
         // first V fragments: in flight behind the softmax
-        constexpr int VD = 3;
+        constexpr int VD = 5;
         auto vread = [&](int n) {
             const int dt = n >> 1, s2 = n & 1;
             const int off = vb + vbase[dt & 3] + (dt >> 2) * 256 + (16 * s2) * 1024;
@@ -465,7 +496,8 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
             if (n + VD < 32) vfr[n % VD] = vread(n + VD);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();   // next tile landed (vmcnt(0)); everyone done with this tile's buffers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of the next tile have landed
+        __syncthreads();   // everyone done with this tile's buffers
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);

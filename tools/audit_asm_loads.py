@@ -1,6 +1,7 @@
 """Audit of hipcc output for kernels that hide register loads in inline asm (cdna_hip_programming.md §5.7 item 1):
 between an inline-asm `global_load_*` and the next inline-asm `s_waitcnt vmcnt(0)`, no instruction may read or write
-the load's destination registers (hipcc considers them written at ASMEND).  Linear scan of the .s text per kernel
+the load's destination registers (hipcc considers them written at ASMEND); likewise between an inline-asm `ds_read_*`
+and the inline-asm MFMA that consumes it behind its own counted `lgkmcnt`.  Linear scan of the .s text per kernel
 (every asm wait in these kernels post-dominates the loads of its pipeline stage, so program order is sufficient).
 
 usage: python tools/audit_asm_loads.py file.s [kernel-name-substring]
@@ -17,7 +18,7 @@ def regs(code):
 
 
 def audit(lines, name):
-    pending, bad, in_asm, n_loads = [], 0, False, 0
+    pending, lds_pending, bad, in_asm, n_loads = [], [], 0, False, 0
     for ln, line in enumerate(lines, 1):
         t = line.strip()
         if t.startswith(';;#ASMSTART'):
@@ -42,6 +43,21 @@ def audit(lines, name):
         if in_asm and code.startswith('s_waitcnt') and 'vmcnt(0)' in code:
             pending = []
             continue
+        if in_asm and code.startswith('ds_read'):      # asm LDS read: pending until an asm MFMA consumes it
+            lds_pending.append(regs(code)[0])
+            n_loads += 1
+            continue
+        if in_asm and code.startswith('v_mfma'):
+            for a, b in regs(code):
+                lds_pending[:] = [(lo, hi) for lo, hi in lds_pending if not (a <= hi and b >= lo)]
+            continue
+        if in_asm:
+            continue
+        for a, b in regs(code):
+            for lo, hi in lds_pending:
+                if a <= hi and b >= lo:
+                    print(f"{name}:{ln}: touches in-flight LDS destination v[{lo}:{hi}]: {t}")
+                    bad += 1
         for a, b in regs(code):
             for lo, hi in pending:
                 if a <= hi and b >= lo:
