@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "librsvld_hip.so")
+# RSVLD_LIB: developer override used by the ablation / A-B tools (another build of the same library)
+LIB_PATH = os.environ.get("RSVLD_LIB") or os.path.join(_PKG_DIR, "librsvld_hip.so")
 
 F16, BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2

@@ -287,6 +287,9 @@ __global__ __launch_bounds__(512) void attn_d512_kernel(AttnArgs p) {
 // Split-KV: when the query tiles alone cannot fill the chip, blockIdx.y walks key ranges and the
 // partial (O / l, m, l) triples are merged by attn_combine_kernel.
 // ---------------------------------------------------------------------------------------
+#ifndef A5B_ABL
+#define A5B_ABL 0   // diagnostic builds (tools/ablate_attn.sh): 1 no softmax VALU, 2 no V reads, 4 no DMA, 8 no K reads
+#endif
 constexpr int A5B_TILE = 32 * 1024;        // one 32-key x 512 tile, 16-bit
 constexpr int A5B_SMEM = 4 * A5B_TILE;     // K[2] | V[2]
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
@@ -319,22 +322,54 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     // destination) is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md §5.7).
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-    auto dma_row = [&](int t, int buf, int i) {
-        const int r = wu * 8 + i;
-        const int key = min(k_begin + t * 32 + r, p.Nk - 1);   // rows past the end re-read the last key; masked below
-        const char* krow = (const char*)(Kb + (int64_t)key * p.k_ts);
-        const char* vrow = (const char*)(Vb + (int64_t)key * p.v_ts);
-        const uint32_t ko = (uint32_t)((lane ^ (r & 15)) << 4), vo = (uint32_t)((lane ^ ((i & 3) << 2)) << 4);
-        const uint32_t kd = lds0 + buf * A5B_TILE + r * 1024, vd = kd + 2 * A5B_TILE;
+    auto dma_one = [&](const char* base, uint32_t voff, uint32_t dst) {
+        if (A5B_ABL & 4) return;
         uint32_t keep;
-        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(ko), "s"(kd), "s"(krow), "s"(vd), "v"(vo), "s"(vrow)
+                     : "v"(voff), "s"(dst), "s"(base)
                      : "memory");
     };
+    // Full tiles: ONE scalar base per tensor (row 8w of the tile, advanced by 32 rows per tile with two SALU adds);
+    // the row i of the piece and its source-side swizzle sit in a precomputed 32-bit lane offset.  The tail tile (rows
+    // past Nk re-read the last key and are masked in the softmax) computes clamped row addresses the long way.
+    const int64_t k_rowb = p.k_ts * (int64_t)sizeof(T), v_rowb = p.v_ts * (int64_t)sizeof(T);
+    uint32_t kvo[8], vvo[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dma_row(0, 0, i);
+    for (int i = 0; i < 8; ++i) {
+        kvo[i] = (uint32_t)(i * k_rowb) + (uint32_t)((lane ^ ((wu * 8 + i) & 15)) << 4);
+        vvo[i] = (uint32_t)(i * v_rowb) + (uint32_t)((lane ^ ((i & 3) << 2)) << 4);
+    }
+    const char* k_tile0 = (const char*)(Kb + (int64_t)(k_begin + wu * 8) * p.k_ts);   // + t * 32 rows
+    const char* v_tile0 = (const char*)(Vb + (int64_t)(k_begin + wu * 8) * p.v_ts);
+    auto dma_k = [&](int t, int i) {   // key row 8w+i of tile t -> K buffer t&1
+        const int r = wu * 8 + i;
+        const uint32_t dst = lds0 + (t & 1) * A5B_TILE + r * 1024;
+        if (k_begin + t * 32 + 32 <= p.Nk) {
+            dma_one(k_tile0 + (int64_t)t * 32 * k_rowb, kvo[i], dst);
+        } else {
+            const int key = min(k_begin + t * 32 + r, p.Nk - 1);
+            dma_one((const char*)(Kb + (int64_t)key * p.k_ts), (uint32_t)((lane ^ (r & 15)) << 4), dst);
+        }
+    };
+    auto dma_v = [&](int t, int i) {   // same row of V -> V buffer t&1
+        const int r = wu * 8 + i;
+        const uint32_t dst = lds0 + (2 + (t & 1)) * A5B_TILE + r * 1024;
+        if (k_begin + t * 32 + 32 <= p.Nk) {
+            dma_one(v_tile0 + (int64_t)t * 32 * v_rowb, vvo[i], dst);
+        } else {
+            const int key = min(k_begin + t * 32 + r, p.Nk - 1);
+            dma_one((const char*)(Vb + (int64_t)key * p.v_ts), (uint32_t)((lane ^ ((i & 3) << 2)) << 4), dst);
+        }
+    };
+    // Software pipeline: iteration t runs S(t+1) beside softmax(t), then PV(t).  K is therefore fetched two tiles ahead
+    // of its PV (K(t+2) lands in the buffer S(t) read in iteration t-1), V one tile ahead.
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dma_k(0, i); dma_v(0, i); }
+    if (nt > 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma_k(1, i);
+    }
 
     // ---- Q fragments (B operand: col = query row on the lane, k = d)
     const int qrow = q0 + l31;
@@ -367,58 +402,136 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // tile 0 landed
+    __syncthreads();   // tiles 0 (K, V) and 1 (K) landed
 
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        const bool more = t + 1 < nt;   // tile t+1 goes into the other buffer, last read in tile t-1 before the barrier
-        const int vb = buf * A5B_TILE;
-
-        // ---- S^T[key][q] over the whole head dimension: one accumulation chain of 32 MFMAs.
-        // The chain is issued in its VGPR form by inline asm: all 256 accumulator registers belong to O, and hipcc
-        // otherwise parks the score tile in a0..a15 and shuttles one O tile through VGPRs every iteration.  Back-to-back
-        // MFMAs that take the previous D whole as C need no wait states; the VALU reader after the chain does
-        // (cdna_hip_programming.md §5.7 item 2), hence the trailing s_nop pair.  The K fragment reads are asm as well:
-        // hipcc waits lgkmcnt(0) in front of an asm consumer, which stalls the chain on the read it has just issued;
-        // here KD reads are in flight and MFMA ks waits only for its own (lgkmcnt(min(KD-1, 31-ks)); LDS returns in
-        // order, and any SMEM operation the compiler may have in flight only makes the count more conservative).
-        constexpr int KD = 6;
-        uint32_t ka[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ka[c] = (uint32_t)(uintptr_t)(lptr_t)smem + (uint32_t)(buf * A5B_TILE + kbase[c]);
-        v8 kfr[KD];
-        f32x16 sacc;
-        // (macros, not lambdas: clang rejects captured arrays as asm operands inside generic lambdas)
+    // ---- S^T[key][q] over the whole head dimension: one accumulation chain of 32 MFMAs per tile.
+    // The chain is issued in its VGPR form by inline asm: all 256 accumulator registers belong to O, and hipcc
+    // otherwise parks the score tile in a0..a15 and shuttles one O tile through VGPRs every iteration.  Back-to-back
+    // MFMAs that take the previous D whole as C need no wait states.  The K fragment reads are asm as well: hipcc
+    // waits lgkmcnt(0) in front of an asm consumer, which stalls the chain on the read it has just issued; here KD
+    // reads are in flight and MFMA ks waits only for its own (lgkmcnt(min(KD-1, 31-ks)); LDS returns in order, and any
+    // SMEM operation the compiler may have in flight only makes the count more conservative).
+    // HOOK(i), i = 0..7, runs after MFMAs 3, 7, .. 31: in the steady state it carries two LDS-DMA rows and one eighth
+    // of the PREVIOUS tile's softmax, pinned there with sched_barrier, so the VALU work issues beside the MFMAs.
+    constexpr int KD = 6;
+    static_assert(KD == 6, "A5B_CHAIN's prologue issues 6 reads");
+    uint32_t ka[8];
+    v8 kfr[KD];
+    // (macros, not lambdas: clang rejects captured arrays as asm operands inside generic lambdas)
 #define A5B_KREAD(slot, ks) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kfr[slot]) : "v"(ka[(ks) & 7]), "i"(((ks) >> 3) * 256))
-#define A5B_STEP(NAME, ks)                                                                                              \
+#define A5B_STEP(NAME, SACC, ks)                                                                                        \
     asm volatile("s_waitcnt lgkmcnt(%3)\n\t" NAME " %0, %1, %2, %0"                                                      \
-                 : "+v"(sacc)                                                                                           \
+                 : "+v"(SACC)                                                                                           \
                  : "v"(kfr[(ks) % KD]), "v"(qf[ks]), "i"(KD - 1 < 31 - (ks) ? KD - 1 : 31 - (ks)));                      \
-    if constexpr ((ks) + KD < 32) A5B_KREAD((ks) % KD, (ks) + KD)
-#define A5B_DMA(i) if (more) dma_row(t + 1, buf ^ 1, i)
-#define A5B_STEP4(NAME, k) A5B_STEP(NAME, k); A5B_STEP(NAME, (k) + 1); A5B_STEP(NAME, (k) + 2); A5B_STEP(NAME, (k) + 3)
-#define A5B_CHAIN(NAME)                                                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" NAME " %0, %1, %2, 0" : "=&v"(sacc) : "v"(kfr[0]), "v"(qf[0]), "i"(KD - 1)); \
+    if constexpr ((ks) + KD < 32 && !(A5B_ABL & 8)) A5B_KREAD((ks) % KD, (ks) + KD)
+#define A5B_STEP4(NAME, SACC, k) \
+    A5B_STEP(NAME, SACC, k); A5B_STEP(NAME, SACC, (k) + 1); A5B_STEP(NAME, SACC, (k) + 2); A5B_STEP(NAME, SACC, (k) + 3)
+#define A5B_CHAIN(NAME, SACC, KBUF, HOOK)                                                                               \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) ka[c] = lds0 + (uint32_t)((KBUF) * A5B_TILE + kbase[c]);              \
+    A5B_KREAD(0, 0); A5B_KREAD(1, 1); A5B_KREAD(2, 2); A5B_KREAD(3, 3); A5B_KREAD(4, 4); A5B_KREAD(5, 5);               \
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" NAME " %0, %1, %2, 0" : "=&v"(SACC) : "v"(kfr[0]), "v"(qf[0]), "i"(KD - 1)); \
     A5B_KREAD(0, KD);                                                                                                   \
-    A5B_STEP(NAME, 1); A5B_DMA(0); A5B_STEP(NAME, 2); A5B_STEP(NAME, 3);                                                \
-    A5B_STEP4(NAME, 4); A5B_DMA(1); A5B_STEP4(NAME, 8); A5B_DMA(2); A5B_STEP4(NAME, 12); A5B_DMA(3);                    \
-    A5B_STEP4(NAME, 16); A5B_DMA(4); A5B_STEP4(NAME, 20); A5B_DMA(5); A5B_STEP4(NAME, 24); A5B_DMA(6);                  \
-    A5B_STEP4(NAME, 28); A5B_DMA(7)
-        static_assert(KD == 6, "the prologue below issues 6 reads");
-        A5B_KREAD(0, 0); A5B_KREAD(1, 1); A5B_KREAD(2, 2); A5B_KREAD(3, 3); A5B_KREAD(4, 4); A5B_KREAD(5, 5);
-        if constexpr (__is_same(T, f16)) {
-            A5B_CHAIN("v_mfma_f32_32x32x16_f16");
+    A5B_STEP(NAME, SACC, 1); A5B_STEP(NAME, SACC, 2); A5B_STEP(NAME, SACC, 3); HOOK(0);                                 \
+    A5B_STEP4(NAME, SACC, 4); HOOK(1); A5B_STEP4(NAME, SACC, 8); HOOK(2); A5B_STEP4(NAME, SACC, 12); HOOK(3);           \
+    A5B_STEP4(NAME, SACC, 16); HOOK(4); A5B_STEP4(NAME, SACC, 20); HOOK(5); A5B_STEP4(NAME, SACC, 24); HOOK(6);         \
+    A5B_STEP4(NAME, SACC, 28); HOOK(7)
+#define A5B_MFMA_NAME(T_) (__is_same(T_, f16) ? "f16" : "bf16")
+#define A5B_NOHOOK(i)
+
+    f32x16 sacc;   // scores of the tile whose softmax is due (S runs one tile ahead of PV)
+    if constexpr (__is_same(T, f16)) {
+        A5B_CHAIN("v_mfma_f32_32x32x16_f16", sacc, 0, A5B_NOHOOK);
+    } else {
+        A5B_CHAIN("v_mfma_f32_32x32x16_bf16", sacc, 0, A5B_NOHOOK);
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc));   // MFMA D -> VALU reader (cdna_hip_programming.md §5.7 item 2)
+    __syncthreads();   // every wave has read K(0): iteration 0 overwrites that buffer with K(2)
+
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt, more2 = t + 2 < nt;
+        const int vb = (t & 1) * A5B_TILE;
+
+        // ---- online softmax of tile t, register-local (this lane holds 16 of its query's 32 scores, lane^32 the
+        // rest), cut into 8 parts for the hooks of the S(t+1) chain
+        float mx = -INFINITY, alpha = 1.0f, rs = 0.f;
+        bool need = false;
+        v8 pf[2];
+        auto sm = [&](int part) {
+            if (A5B_ABL & 1) {
+                if (part == 6) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) pf[s2][j] = (T)sacc[8 * s2 + j];
+                    asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(l_run));
+                }
+                return;
+            }
+            if (part == 0) {
+                if (k_begin + (t + 1) * 32 > k_end) {   // ragged last tile (uniform branch)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = k_begin + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (kv >= k_end) sacc[r] = -INFINITY;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] *= p.scale_log2e;
+                    mx = fmaxf(mx, sacc[r]);
+                }
+                asm volatile("" : "+v"(sacc), "+v"(mx));
+            } else if (part == 1) {
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                // deferred max (T13): the reference point moves only when the tile max exceeds it by more than 2^8, so
+                // the rescale of O (256 accumulator registers through VGPRs) is skipped on almost every tile
+                need = mx > m_run + A5_DEFER_LOG2;   // true on the first tile (m_run = -inf)
+                if (need) {
+                    alpha = __builtin_amdgcn_exp2f(m_run - mx);
+                    m_run = mx;
+                }
+                asm volatile("" : "+v"(alpha), "+v"(m_run));
+            } else if (part >= 2 && part <= 5) {
+                const int r0 = 4 * (part - 2);
+#pragma unroll
+                for (int r = r0; r < r0 + 4; ++r) {
+                    sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run);
+                    rs += sacc[r];
+                }
+                asm volatile("" : "+v"(sacc[r0]), "+v"(sacc[r0 + 1]), "+v"(sacc[r0 + 2]), "+v"(sacc[r0 + 3]), "+v"(rs));
+            } else if (part == 6) {
+                l_run = l_run * alpha + rs;
+                // P as the B operand of k-step s: registers 8s..8s+7 <-> keys 16s + 8(j>>2) + 4lh + (j&3)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[s2][j] = (T)sacc[8 * s2 + j];
+                asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(l_run));
+            }
+        };
+        // (each part ends with an empty volatile asm naming what it produced: volatile asms keep their order, so the part
+        // is computed at its hook; without the pins hipcc sinks the whole softmax behind the chain)
+
+        f32x16 snext;
+        if (more) {
+#define A5B_HOOK(i)                          \
+    if (more2) dma_k(t + 2, i);              \
+    dma_v(t + 1, i);                         \
+    sm(i);                                   \
+    __builtin_amdgcn_sched_barrier(0)
+            if constexpr (__is_same(T, f16)) {
+                A5B_CHAIN("v_mfma_f32_32x32x16_f16", snext, (t + 1) & 1, A5B_HOOK);
+            } else {
+                A5B_CHAIN("v_mfma_f32_32x32x16_bf16", snext, (t + 1) & 1, A5B_HOOK);
+            }
+#undef A5B_HOOK
         } else {
-            A5B_CHAIN("v_mfma_f32_32x32x16_bf16");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sm(i);
         }
-#undef A5B_CHAIN
-#undef A5B_DMA
-#undef A5B_STEP4
-#undef A5B_STEP
-#undef A5B_KREAD
-        __builtin_amdgcn_sched_barrier(0);
-        // first V fragments: in flight behind the softmax
+
+        // first V fragments of PV(t)
         constexpr int VD = 5;
         auto vread = [&](int n) {
             const int dt = n >> 1, s2 = n & 1;
@@ -431,44 +544,13 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
         v8 vfr[VD];
 #pragma unroll
         for (int i = 0; i < VD; ++i) vfr[i] = vread(i);
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc));
-        __builtin_amdgcn_sched_barrier(0);
 
-        // ---- online softmax, register-local: this lane holds 16 of its query's 32 scores, lane^32 the rest
-        if (k_begin + (t + 1) * 32 > k_end) {   // ragged last tile (uniform branch)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = k_begin + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (kv >= k_end) sacc[r] = -INFINITY;
-            }
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sacc[r] *= p.scale_log2e;
-            mx = fmaxf(mx, sacc[r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // deferred max (T13): the reference point moves only when the tile max exceeds it by more than 2^8, so the
-        // rescale of O (256 accumulator registers through VGPRs) is skipped on almost every tile
-        const bool need = mx > m_run + A5_DEFER_LOG2;   // true on the first tile (m_run = -inf)
-        float alpha = 1.0f;
-        if (need) {
-            alpha = __builtin_amdgcn_exp2f(m_run - mx);
-            m_run = mx;
-        }
-        float rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run);
-            rs += sacc[r];
-        }
-        l_run = l_run * alpha + rs;
         if (__any(need)) {
             // O lives in the accumulator file; written as plain C++ (oacc *= alpha) hipcc pulls all 256 values into
             // VGPRs at once and spills 375 registers.  One element at a time through a scratch VGPR instead; the
             // write -> MFMA hazard (cdna_hip_programming.md §5.7 item 2) is covered by the s_nop that ends each string,
-            // the MFMA -> read hazard by the 32 S-phase MFMAs since the last PV MFMA.
+            // the MFMA -> read hazard by the 32 S-chain MFMAs (or the epilogue of the previous PV) before this point.
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
             for (int dt = 0; dt < 16; ++dt)
 #pragma unroll
@@ -480,25 +562,26 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
                     oacc[dt][r] = x;
                 }
         }
-        // P as the B operand of k-step s: registers 8s..8s+7 <-> keys 16s + 8(j>>2) + 4lh + (j&3)
-        v8 pf[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[s2][j] = (T)sacc[8 * s2 + j];
 
         // ---- O^T[d][q] += V^T P^T; the A operand (row = d, k = the same key order) is two transposed reads:
-        // elements 0..3 = keys 16s + 4lh + 0..3, elements 4..7 = keys 16s + 8 + 4lh + 0..3.  Same explicit ring.
+        // elements 0..3 = keys 16s + 4lh + 0..3, elements 4..7 = keys 16s + 8 + 4lh + 0..3.  Explicit fragment ring.
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < 32; ++n) {
             oacc[n >> 1] = Mfma<T>::mma(vfr[n % VD], pf[n & 1], oacc[n >> 1]);
-            if (n + VD < 32) vfr[n % VD] = vread(n + VD);
+            if (n + VD < 32 && !(A5B_ABL & 2)) vfr[n % VD] = vread(n + VD);
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of the next tile have landed
+        if (more) sacc = snext;   // readable by VALU: 32 PV MFMAs have issued since the chain's last MFMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of the next tiles have landed
         __syncthreads();   // everyone done with this tile's buffers
     }
+#undef A5B_NOHOOK
+#undef A5B_MFMA_NAME
+#undef A5B_CHAIN
+#undef A5B_STEP4
+#undef A5B_STEP
+#undef A5B_KREAD
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     if (qrow >= p.Nq) return;

@@ -30,7 +30,7 @@ def audit(lines, name):
         code = t.split(';')[0]
         if not code or code.endswith(':') or code.startswith('.'):
             continue
-        if in_asm and code.startswith('global_load'):
+        if in_asm and code.startswith('global_load') and '_lds_' not in code:   # LDS-DMA has no VGPR destination
             r = regs(code)
             pending.append(r[0])
             n_loads += 1
