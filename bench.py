@@ -86,13 +86,10 @@ def cpu_baseline(side, T, steps_sampled=2):
                       f"({dt:.2f} s/step, {ncores} threads of {avail} schedulable cores), extrapolated linearly to {T} steps"}
 
 
-def bench_stage2(args, dev, rank, world):
-    """Secondary workload (not the contract line): Stage 2 only — BASELINE configs[2] shape family:
-    full juggernautXL.yaml networks (UNet 2.6 B + ControlNet 1.2 B params, seeded random init with the
-    zero-initialised tensors re-drawn), cached text embeddings (PreparedConditioner), 50 EDM steps,
-    CFG 4.0->7.5 linear, s_churn 5, feature cache threshold 0.3, Wavelet colour fix, untiled VAE."""
+def build_stage2(dev, tile_vae):
+    """Full juggernautXL.yaml networks (UNet 2.6 B + ControlNet 1.2 B params, seeded random init with the
+    zero-initialised tensors re-drawn), cached text embeddings (PreparedConditioner)."""
     import yaml
-    from oracle import seeded
     from rsvld_amd.sgm.util import instantiate_from_config
     cfg = yaml.safe_load(open(os.path.join(ROOT, "remote-sensing-vision-language-diffusion-model_amd", "model_configs",
                                            "juggernautXL.yaml")))["model"]["params"]
@@ -101,7 +98,6 @@ def bench_stage2(args, dev, rank, world):
         "cond_pth": {"crossattn": torch.randn(1, 77, 2048, generator=g2), "vector": torch.randn(1, 2816, generator=g2)},
         "un_cond_pth": {"crossattn": torch.randn(1, 77, 2048, generator=g3), "vector": torch.randn(1, 2816, generator=g3)}}
     torch.manual_seed(0)
-    t0 = time.perf_counter()
     m = instantiate_from_config({"target": "rsvld_amd.models.SR_model.SR_backbone", "params": cfg})
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
@@ -109,13 +105,26 @@ def bench_stage2(args, dev, rank, world):
             if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
                 p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
     m.to(dev).eval()
+    if tile_vae:   # SR_model.py:95-125: encoder tiles of 512 px, decoder tiles of 64 latent px, cross-tile GroupNorm
+        m.init_tile_vae(512, 64)
+    return m
+
+
+S2_KW = dict(p_p="", n_p="", dec_img=1.0, restoration_scale=-1, s_churn=5, s_noise=1.003, cfg_scale=7.5, control_scale=1.0,
+             color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=4.0)
+
+
+def bench_stage2(args, dev, rank, world):
+    """Secondary workload (not the contract line): Stage 2 only — BASELINE configs[2] shape family:
+    50 EDM steps, CFG 4.0->7.5 linear, s_churn 5, feature cache threshold 0.3, Wavelet colour fix."""
+    from oracle import seeded
+    t0 = time.perf_counter()
+    m = build_stage2(dev, args.tile_vae)
     side = args.s2_side
     img = torch.cat([seeded.synthetic_image((1, 3, side, side), seed=1234 + rank * args.batch + i, smooth=4)
                      for i in range(args.batch)]).to(dev)
     thr = args.s2_threshold if args.batch == 1 else 0.0
-    kw = dict(p_p="", n_p="", img_threshold=thr, dec_img=1.0, num_steps=args.ddpm_steps, restoration_scale=-1,
-              s_churn=5, s_noise=1.003, cfg_scale=7.5, control_scale=1.0, color_fix_type="Wavelet", use_linear_CFG=True,
-              cfg_scale_start=4.0)
+    kw = dict(S2_KW, img_threshold=thr, num_steps=args.ddpm_steps)
     build_s = time.perf_counter() - t0
 
     def one_pass():
@@ -142,7 +151,8 @@ def bench_stage2(args, dev, rank, world):
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 1),
             "dtype": "f16 (UNet/ControlNet), bf16 (VAE)", "data": "synthetic",
             "config": {"workload": f"Stage 2 only, {side}x{side} input (latent {L}), batch {args.batch}, {args.ddpm_steps} EDM steps, "
-                                   f"cache threshold {thr}, Wavelet, untiled VAE, full juggernautXL.yaml sizes",
+                                   f"cache threshold {thr}, Wavelet, {'tiled VAE (512 / 64)' if args.tile_vae else 'untiled VAE'}, "
+                                   f"full juggernautXL.yaml sizes",
                        "model_build_s": round(build_s, 1), "finite": bool(torch.isfinite(out).all()),
                        "algorithmic_tflops_no_cache": None if tf_step is None else round(
                            tf_step * args.ddpm_steps * args.batch * args.steps / dt, 1)},
@@ -152,11 +162,87 @@ def bench_stage2(args, dev, rank, world):
     print(json.dumps(line), flush=True)
 
 
+def bench_pipeline(args, dev, rank, world):
+    """The headline shape (BASELINE configs[3], one image per pass): 512 -> 4096 x8, Stage 1 (SR3, --ddpm-steps
+    ancestral steps at 4096^2) -> 8-bit hand-off -> Stage 2 (--ddpm-steps EDM steps, ControlNet, feature cache 0.3,
+    tiled VAE 512 / 64, Wavelet colour fix).  The caption comes from cached text embeddings (the LLaVA pass needs
+    checkpoints that are not available offline and stays on PyTorch-ROCm by north_star).  Kernel statistics are taken
+    in the timed pass itself (two HIP events per launch)."""
+    from oracle import seeded
+    from rsvld_amd import ops, parallel
+    T = args.ddpm_steps
+    t0 = time.perf_counter()
+    net = build_model(dev, T)
+    net.use_graph = False   # per-launch HIP events cannot be recorded inside a graph capture; launches are ms-long here
+    m = build_stage2(dev, True)
+    build_s = time.perf_counter() - t0
+    cond = synthetic_batch(1, args.lr_side, args.scale, rank).to(dev)
+    side = args.lr_side * args.scale
+    # one-time work out of the timed region: lazy 16-bit weight packing of the Stage-2 networks (a tiny image, one step)
+    small = seeded.synthetic_image((1, 3, 512, 512), seed=7, smooth=4).to(dev)
+    m.just_sampling(small, [""], **dict(S2_KW, img_threshold=0.0, num_steps=1))
+    torch.cuda.synchronize()
+    stage = {}
+
+    def one_pass():
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        sr = net.super_resolution(cond, continous=True)[-1:]
+        u8 = parallel.to_uint8(sr)                                   # utils/tensor2img.py:4-21: the 8-bit hand-off
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        lq = u8.float() / 127.5 - 1.0                                # models/util.py:132-156 (4096 is a multiple of 64)
+        out = m.just_sampling(lq, [""], **dict(S2_KW, img_threshold=args.s2_threshold, num_steps=T))
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        stage["stage1_s"], stage["stage2_s"] = round(b - a, 2), round(c - b, 2)
+        print(f"pipeline pass: stage 1 {b - a:.2f} s, stage 2 {c - b:.2f} s", flush=True)
+        return out
+
+    for _ in range(args.warmup):
+        one_pass()
+    prof = ops.LaunchProfiler()
+    ops.set_profiler(prof)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_profiler(None)
+    summ = prof.summary()
+    tf_img = UNET_TF_PER_IMAGE_STEP[side] * T + 865.9 * T   # BASELINE.md section 2, VAE and cache hits not counted
+    dom = max(summ.values(), key=lambda r: r["ms"])
+    tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    line = {"metric": METRIC, "value": round(args.steps / dt, 5), "unit": "img/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 (UNets), bf16 (VAE)", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3] shape, one image per pass: {args.lr_side}->{side} x{args.scale}, Stage 1 {T} DDPM "
+                                   f"steps + Stage 2 {T} EDM steps (ControlNet, cache {args.s2_threshold}, tiled VAE 512/64, Wavelet), "
+                                   f"cached text embeddings instead of the live LLaVA prompt, seeded random-init weights",
+                       "global_batch": 1, "parallelism": "dp1", "model_build_s": round(build_s, 1),
+                       "finite": bool(torch.isfinite(out).all()), "out_shape": list(out.shape), **stage,
+                       "algorithmic_tflops_no_cache": round(tf_img * args.steps / dt, 1),
+                       "stage2_trace": getattr(m, "last_trace", None)},
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK_TFLOPS_F16,
+                         "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": None,
+                         "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 2),
+                         "kernel_time_share": round(dom["ms"] / sum(r["ms"] for r in summ.values()), 3),
+                         "by_kernel": {k: {"ms": round(v["ms"], 1), "n": v["n"],
+                                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
+                                       for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}},
+            "cpu_baseline": None}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="c2", choices=["c2", "s2"], help="c2 = the contract line (default); s2 = Stage-2 secondary")
+    ap.add_argument("--workload", default="c2", choices=["c2", "s2", "c4"],
+                    help="c2 = the contract line (default); s2 = Stage 2 only; c4 = the 512->4096 two-stage pipeline, one image")
     ap.add_argument("--s2-side", type=int, default=1024)
     ap.add_argument("--s2-threshold", type=float, default=0.3)
+    ap.add_argument("--tile-vae", action="store_true", help="Stage 2: VAEHook tiling (needed from 2048x2048 up: the VAE's "
+                                                               "single-head attention is quadratic in the pixel count)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -177,6 +263,10 @@ def main():
         local = int(os.environ["RSVLD_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.workload == "c4":
+        if "--lr-side" not in " ".join(sys.argv):
+            args.lr_side, args.scale = 512, 8
+        return bench_pipeline(args, dev, rank, world)
     if args.workload == "s2":
         if args.batch == 4 and "--batch" not in " ".join(sys.argv):
             args.batch = 1

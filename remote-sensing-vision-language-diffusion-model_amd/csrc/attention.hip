@@ -950,7 +950,8 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
     }
     if (D == 64) {
         // 2 query tiles per wave (256 rows per workgroup) once the grid still fills the chip
-        const bool big = (int64_t)((Nq + 255) / 256) * heads * B >= 512;
+        static const char* qt_env = getenv("RSVLD_ATTN64_QT");   // A/B switch: force 1 or 2 query tiles per wave
+        const bool big = qt_env ? qt_env[0] == '2' : (int64_t)((Nq + 255) / 256) * heads * B >= 512;
         const int rows = big ? 256 : 128;
         dim3 grid((unsigned)((Nq + rows - 1) / rows), (unsigned)heads, (unsigned)B);
         if (dtype == RSVLD_F16) {

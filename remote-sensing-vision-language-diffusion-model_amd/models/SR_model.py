@@ -127,11 +127,29 @@ class SR_backbone(DiffusionEngine):
         sp.restore_cfg, sp.s_churn, sp.s_noise = restoration_scale, s_churn, s_noise
         self.sampler = instantiate_from_config(self.sampler_config)
 
+        # RSVLD_TRACE=1: wall time of every stage (device-synchronised), kept in self.last_trace
+        import os, time
+        trace = [] if os.environ.get("RSVLD_TRACE") else None
+
+        def stamp(name, _t=[None]):
+            if trace is None:
+                return
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            if _t[0] is not None:
+                trace.append((name, now - _t[0]))
+            _t[0] = now
+
+        stamp(None)
         x = x.float().contiguous()
         _z = self.encode_first_stage_with_denoise(x, use_sample=False)
+        stamp("vae_denoise_encode")
         x_stage1 = self.decode_first_stage(_z)
+        stamp("vae_decode_stage1")
         z_stage1 = self.encode_first_stage(x_stage1)
+        stamp("vae_encode_stage1")
         c_img, uc_img = self.prepare_condition(_z, p, p_p, n_p, N)
+        stamp("conditioner")
 
         def denoiser(inp, sigma, c, *a, **kw):
             return self.denoiser(self.model, inp, sigma, c, *a, **kw)
@@ -149,10 +167,16 @@ class SR_backbone(DiffusionEngine):
                                                 control_scale_start=control_scale_start, threshold=img_threshold)
                 x_center_cur = z
                 img_threshold = img_threshold * dec_img
+        stamp("edm_sampler_loop")
 
         samples = self.decode_first_stage(z)
+        stamp("vae_decode_final")
         if color_fix_type == "Wavelet":
             samples = wavelet_reconstruction(samples, x_stage1)
         elif color_fix_type == "AdaIn":
             samples = adaptive_instance_normalization(samples, x_stage1)
+        stamp("colour_fix")
+        if trace is not None:
+            self.last_trace = trace
+            print("just_sampling trace: " + ", ".join(f"{n} {dt:.2f}s" for n, dt in trace), flush=True)
         return samples

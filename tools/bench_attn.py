@@ -9,10 +9,12 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 reps = int(os.environ.get("REPS", 10))
 CASES = [(4, 1, 4096, 512), (4, 1, 1024, 512), (1, 1, 16384, 512), (1, 1, 65536, 512),
-         (2, 10, 4096, 64), (2, 20, 1024, 64), (2, 10, 16384, 64)]
+         (2, 10, 4096, 64), (2, 20, 1024, 64), (2, 10, 16384, 64), (2, 20, 16384, 64), (1, 10, 32768, 64)]
 if os.environ.get("ONLY512"):
     CASES = [c for c in CASES if c[3] == 512]
-print("d512 kernel:", "v1" if os.environ.get("RSVLD_ATTN512_V1") else "v2")
+if os.environ.get("ONLY64"):
+    CASES = [c for c in CASES if c[3] == 64]
+print("d512 kernel:", "v1" if os.environ.get("RSVLD_ATTN512_V1") else "v2", " d64 query tiles per wave:", os.environ.get("RSVLD_ATTN64_QT", "auto"))
 for (B, heads, N, D) in CASES:
     qkv = torch.randn(B, N, 3 * heads * D, device=dev, dtype=torch.float16)
     q, k, v = qkv[..., :heads * D], qkv[..., heads * D:2 * heads * D], qkv[..., 2 * heads * D:]
