@@ -861,6 +861,235 @@ __global__ __launch_bounds__(256) void attn_d64_kernel(AttnArgs p) {
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// D = 64, second generation.  attn_d64_kernel above is VALU-bound: per 64-key tile a wave issues 16 MFMAs
+// (512 cycles) beside ~270 vector instructions, of which 32 move the score tile out of the accumulator file,
+// 64 are scale + subtract, ~45 are address arithmetic of the register-staged K / V^T loads, and its QT = 2 form
+// needs 354 registers (one wave per SIMD: nothing overlaps the softmax).  Here:
+//   * MFMAs are issued in their VGPR form (inline asm), so scores and O are plain VGPRs: no v_accvgpr traffic;
+//   * exp2(scale * s - m) is ONE fma + exp2 per element (the max is taken on raw scores, scale > 0);
+//   * K and V tiles are filled by LDS-DMA (asm, one scalar base per tensor per tile, no staging registers), V is
+//     read through ds_read_b64_tr_b16, so no transpose pass exists;
+//   * 4 waves x 32 query rows, ~170 registers -> two workgroups per CU: one wave's softmax runs beside the
+//     other's MFMAs on every SIMD.
+// ---------------------------------------------------------------------------------------
+constexpr int A6B_TILE = 64 * 128;            // 64 keys x 64 d, 16-bit
+constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
+    constexpr int D = 64;
+    typedef typename Mfma<T>::v8 v8;
+    typedef typename Mfma<T>::v4 v4;
+    __shared__ __attribute__((aligned(16))) char smem[A6B_SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + w) * 32, h = blockIdx.y, b = blockIdx.z;
+    const T* Qb = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
+    const T* Kb = (const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D;
+    const T* Vb = (const T*)p.v + (int64_t)b * p.v_bs + (int64_t)h * D;
+    const int nt = (p.Nk + 63) >> 6;
+
+    // ---- tile DMA.  Wave w moves key rows 16w .. 16w+15 of the tile: two wave-instructions of 8 rows x 128 B per tensor.
+    // Lane (row = lane>>3, pos = lane&7) of piece i fills LDS chunk `pos` of row 16w + 8i + row with source chunk
+    // pos ^ ((row'>>1)&7) for K (row' = row within the 16) and pos ^ (((row'>>1)&1)<<2) for V.
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const int64_t k_rowb = p.k_ts * (int64_t)sizeof(T), v_rowb = p.v_ts * (int64_t)sizeof(T);
+    uint32_t kvo[2], vvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = 8 * i + (lane >> 3);
+        kvo[i] = (uint32_t)(rr * k_rowb) + (uint32_t)(((lane & 7) ^ ((rr >> 1) & 7)) << 4);
+        vvo[i] = (uint32_t)(rr * v_rowb) + (uint32_t)(((lane & 7) ^ (((rr >> 1) & 1) << 2)) << 4);
+    }
+    auto dma_fast = [&](const char* base, uint32_t voff, uint32_t dst) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    };
+    auto dma_slow = [&](const char* ptr, uint32_t dst) {   // per-lane 64-bit address (tail tile: clamped rows)
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(ptr), "s"(dst) : "memory");
+    };
+    auto dma_tile = [&](int t) {
+        const int buf = t & 1;
+        const uint32_t kd = lds0 + buf * A6B_TILE + wu * 2048, vd = kd + 2 * A6B_TILE;
+        if (t * 64 + 64 <= p.Nk) {
+            const char* kb = (const char*)(Kb + (int64_t)(t * 64 + wu * 16) * p.k_ts);
+            const char* vb = (const char*)(Vb + (int64_t)(t * 64 + wu * 16) * p.v_ts);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                dma_fast(kb, kvo[i], kd + i * 1024);
+                dma_fast(vb, vvo[i], vd + i * 1024);
+            }
+        } else {   // rows past Nk re-read the last key; their scores are masked
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rr = 8 * i + (lane >> 3);
+                const int key = min(t * 64 + wu * 16 + rr, p.Nk - 1);
+                dma_slow((const char*)(Kb + (int64_t)key * p.k_ts) + (((lane & 7) ^ ((rr >> 1) & 7)) << 4), kd + i * 1024);
+                dma_slow((const char*)(Vb + (int64_t)key * p.v_ts) + (((lane & 7) ^ (((rr >> 1) & 1) << 2)) << 4), vd + i * 1024);
+            }
+        }
+    };
+    dma_tile(0);
+
+    // ---- Q fragments (B operand: col = query row on the lane, k = d)
+    const int qrow = q0 + l31;
+    v8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (qrow < p.Nq) v = *(const u32x4*)(Qb + (int64_t)qrow * p.q_ts + ks * 16 + lh * 8);
+        qf[ks] = __builtin_bit_cast(v8, v);
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // per-lane read offsets.  K (ds_read_b128): row kt*32 + l31, chunk 2ks + lh, swizzled by ((row>>1)&7) [row & 15 = l31 & 15]
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + lh) ^ ((l31 >> 1) & 7)) << 4);
+    // V (transposed read): lane 16g + 4q + p supplies row 16 s4 + 8 hf + 4 lh + q, d = 32 dt + 16 (g&1) + 4p .. +3
+    int voff[2];
+    {
+        const int qq = (lane >> 2) & 3, pp = lane & 3, g1 = (lane >> 4) & 1;
+        const int row = 4 * lh + qq;   // + 16 s4 + 8 hf: multiples of 8, (row>>1)&1 unchanged
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            voff[dt] = 2 * A6B_TILE + row * 128 + (((4 * dt + 2 * g1 + (pp >> 1)) ^ (((row >> 1) & 1) << 2)) << 4) + ((pp & 1) << 3);
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile 0 landed
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) dma_tile(t + 1);   // the other buffers were last read in tile t-1, before the barrier
+        const char* Ks = smem + buf * A6B_TILE;
+        const int vb = buf * A6B_TILE;
+
+        // ---- S^T[key][q]: two 32-key halves x 4 k-steps, VGPR-form MFMAs
+        v8 kf[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const v8*)(Ks + kt * 4096 + koff[ks]);
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if constexpr (__is_same(T, f16)) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sacc[kt]) : "v"(kf[kt][0]), "v"(qf[0]));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][1]), "v"(qf[1]));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][2]), "v"(qf[2]));
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][3]), "v"(qf[3]));
+            } else {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sacc[kt]) : "v"(kf[kt][0]), "v"(qf[0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][1]), "v"(qf[1]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][2]), "v"(qf[2]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][3]), "v"(qf[3]));
+            }
+        }
+        // V fragments of this tile: in flight behind the softmax.  A operand (row = d, k = key in P's register order):
+        // elements 0..3 = keys 16 s4 + 4 lh + 0..3, elements 4..7 = keys 16 s4 + 8 + 4 lh + 0..3
+        v8 vf[2][4];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int off = vb + voff[dt] + s4 * 2048;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off + 1024));
+                typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+                vf[dt][s4] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));   // MFMA D -> VALU reader (§5.7 item 2)
+
+        // ---- online softmax, register-local (this lane: 32 of its query's 64 scores, lane^32 the rest)
+        if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (kv >= p.Nk) sacc[kt][r] = -INFINITY;
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;   // scale > 0: max commutes with it
+        const bool need = mx > m_run + 8.0f;                   // deferred max (T13); true on the first tile
+        float alpha = 1.0f;
+        if (need) {
+            alpha = __builtin_amdgcn_exp2f(m_run - mx);
+            m_run = mx;
+        }
+        const float nm = -m_run;
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][r], p.scale_log2e, nm));
+                sacc[kt][r] = pv;
+                rs += pv;
+            }
+        l_run = l_run * alpha + rs;
+        if (__any(need)) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
+        v8 pf[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[s4][j] = (T)sacc[s4 >> 1][8 * (s4 & 1) + j];
+
+        // ---- O^T[d][q] += V^T P^T, VGPR form
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                if constexpr (__is_same(T, f16))
+                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
+                else
+                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
+            }
+        asm volatile("s_nop 15\n\ts_nop 3\n\ts_waitcnt vmcnt(0)" : "+v"(oacc[0]), "+v"(oacc[1]) : : "memory");   // O readable by VALU; next tile landed
+        __syncthreads();   // everyone done with this tile's buffers
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (qrow >= p.Nq) return;
+    const float inv = 1.0f / l_tot;
+    T* Ob = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)h * D + (int64_t)qrow * p.o_ts;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (T)(oacc[dt][4 * g + e] * inv);
+            *(v4*)(Ob + dt * 32 + 8 * g + 4 * lh) = o;
+        }
+}
+
+}  // namespace
+
 // split-KV plan of the D = 512 kernel: key ranges per workgroup so that the grid fills the 256 CUs
 static void attn512_plan(int B, int heads, int Nq, int Nk, int* nsplit, int* keys_per_split) {
     const int64_t base = (int64_t)((Nq + 127) / 128) * B * heads;
@@ -949,9 +1178,16 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
         return rsvld_check_launch();
     }
     if (D == 64) {
-        // 2 query tiles per wave (256 rows per workgroup) once the grid still fills the chip
+        static const bool v1 = getenv("RSVLD_ATTN64_V1") != nullptr;   // A/B switch: the register-staged kernel
+        if (!v1) {
+            dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
+            if (dtype == RSVLD_F16) hipLaunchKernelGGL(attn_d64b_kernel<f16>, grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(attn_d64b_kernel<bf16>, grid, dim3(256), 0, s, a);
+            return rsvld_check_launch();
+        }
+        // measured on MI355X: one query tile per wave (two waves per SIMD) beats two (one wave per SIMD) at every size
         static const char* qt_env = getenv("RSVLD_ATTN64_QT");   // A/B switch: force 1 or 2 query tiles per wave
-        const bool big = qt_env ? qt_env[0] == '2' : (int64_t)((Nq + 255) / 256) * heads * B >= 512;
+        const bool big = qt_env ? qt_env[0] == '2' : false;
         const int rows = big ? 256 : 128;
         dim3 grid((unsigned)((Nq + rows - 1) / rows), (unsigned)heads, (unsigned)B);
         if (dtype == RSVLD_F16) {
