@@ -294,6 +294,103 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Small tensors (deep UNet levels: 32x32 / 64x64 maps): the three launches above are latency-bound (3 x ~7 us for
+// 4 MB).  One workgroup per (image, group) instead: the group's HW x (C/groups) slab is read ONCE into registers
+// (<= 32 sixteen-byte vectors per thread), reduced in fp64 through LDS in a fixed order, and either normalised and
+// written (APPLY) or turned into the per-channel (scale, shift) rows of the fused conv prologue (!APPLY).
+// Needs 8 | C/groups (a vector never straddles groups) and, for [x | x2], groups that do not straddle the sources.
+// ---------------------------------------------------------------------------------------
+constexpr int GN_SMALL_MAXV = 32;
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x1, const T* __restrict__ x2, T* __restrict__ y,
+                                                       float* __restrict__ ab, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int HW, int C1, int C2, int groups,
+                                                       float eps, int silu) {
+    __shared__ double red[2][4];
+    __shared__ float mr[2];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int C = C1 + C2, gs = C / groups, gs8 = gs >> 3;   // gs8 is a power of two <= 256
+    const int ch0 = g * gs;
+    const T* src;
+    int cs, coff;
+    if (ch0 < C1) { src = x1 + (int64_t)b * HW * C1; cs = C1; coff = ch0; }
+    else { src = x2 + (int64_t)b * HW * C2; cs = C2; coff = ch0 - C1; }
+    const int chunk = tid & (gs8 - 1);           // fixed per thread: 256 is a multiple of gs8
+    const int row0 = tid / gs8, rstep = 256 / gs8;
+    const int nv = (HW - row0 + rstep - 1) / rstep;   // vectors of this thread (<= GN_SMALL_MAXV, may be <= 0)
+    u32x4 v[GN_SMALL_MAXV];
+#pragma unroll
+    for (int i = 0; i < GN_SMALL_MAXV; ++i)
+        if (i < nv) v[i] = *(const u32x4*)(src + (int64_t)(row0 + i * rstep) * cs + coff + chunk * 8);
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_SMALL_MAXV; ++i)
+        if (i < nv) {
+            float f[8];
+            unpack8<T>(v[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s += f[e]; ss += f[e] * f[e]; }
+        }
+    double ds = (double)s, dss = (double)ss;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dss += __shfl_xor(dss, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = ds; red[1][tid >> 6] = dss; }
+    __syncthreads();
+    if (tid == 0) {
+        ds = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        dss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double inv_count = 1.0 / ((double)HW * (double)gs);
+        const double mean = ds * inv_count;
+        double var = dss * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[0] = (float)mean;
+        mr[1] = (float)var;
+    }
+    __syncthreads();
+    const float mean = mr[0], rstd = 1.0f / sqrtf(mr[1] + eps);
+    if (!APPLY) {
+        if (tid < gs) {
+            const int c = ch0 + tid;
+            const float a = (gamma ? gamma[c] : 1.f) * rstd;
+            ab[((int64_t)b * C + c) * 2] = a;
+            ab[((int64_t)b * C + c) * 2 + 1] = (beta ? beta[c] : 0.f) - mean * a;
+        }
+        return;
+    }
+    float sa[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = ch0 + chunk * 8 + e;
+        sa[e] = (gamma ? gamma[c] : 1.f) * rstd;
+        sb[e] = (beta ? beta[c] : 0.f) - mean * sa[e];
+    }
+    T* dst = y + (int64_t)b * HW * C + ch0 + chunk * 8;
+#pragma unroll
+    for (int i = 0; i < GN_SMALL_MAXV; ++i)
+        if (i < nv) {
+            float f[8];
+            unpack8<T>(v[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = f[e] * sa[e] + sb[e];
+                f[e] = silu ? silu_f(t) : t;
+            }
+            *(u32x4*)(dst + (int64_t)(row0 + i * rstep) * C) = pack8<T>(f);
+        }
+}
+
+bool gn_small_ok(int B, int HW, int C1, int C2, int groups) {
+    const int C = C1 + C2, gs = C / groups;
+    if (gs % 8) return false;
+    const int gs8 = gs / 8;
+    if (gs8 > 256 || (gs8 & (gs8 - 1))) return false;
+    if (C2 > 0 && C1 % gs) return false;
+    if ((int64_t)HW * gs8 > (int64_t)256 * GN_SMALL_MAXV) return false;
+    return B * groups >= 32;   // enough workgroups to be worth one launch
+}
+
 struct GnPlan {
     int nchunks, rows_per_chunk;
 };
@@ -390,6 +487,17 @@ extern "C" int rsvld_groupnorm_nhwc(const void* x, const void* x2, void* y, cons
                                     int C2, int groups, float eps, int silu, int dtype, void* ws, void* stream) {
     if (!ws) return RSVLD_EINVAL;
     if (!gn_shape_ok(B, HW, C1, C2, groups)) return RSVLD_EINVAL;
+    if (mod_scale1p == nullptr && mod_shift == nullptr && x && y && ((C2 > 0) == (x2 != nullptr)) && B <= 65535 &&
+        gn_small_ok(B, HW, C1, C2, groups) && (dtype == RSVLD_F16 || dtype == RSVLD_BF16)) {
+        hipStream_t s = (hipStream_t)stream;
+        if (dtype == RSVLD_F16)
+            hipLaunchKernelGGL((gn_small_kernel<f16, true>), dim3(groups, B), dim3(256), 0, s, (const f16*)x, (const f16*)x2,
+                               (f16*)y, nullptr, gamma, beta, HW, C1, C2, groups, eps, silu);
+        else
+            hipLaunchKernelGGL((gn_small_kernel<bf16, true>), dim3(groups, B), dim3(256), 0, s, (const bf16*)x, (const bf16*)x2,
+                               (bf16*)y, nullptr, gamma, beta, HW, C1, C2, groups, eps, silu);
+        return rsvld_check_launch();
+    }
     const GnPlan pl = gn_plan(B, HW);
     float* stats = (float*)ws + (int64_t)B * pl.nchunks * groups * 2;
     int rc = rsvld_groupnorm_stats(x, x2, stats, B, HW, C1, C2, groups, dtype, ws, stream);
@@ -403,12 +511,21 @@ extern "C" int rsvld_groupnorm_scale_shift(const void* x, const void* x2, const 
                                            int dtype, void* ws, void* stream) {
     if (!x || !ws || !scale_shift || !gn_shape_ok(B, HW, C1, C2, groups) || ((C2 > 0) != (x2 != nullptr))) return RSVLD_EINVAL;
     if (dtype != RSVLD_F16 && dtype != RSVLD_BF16) return RSVLD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 65535 && gn_small_ok(B, HW, C1, C2, groups)) {
+        if (dtype == RSVLD_F16)
+            hipLaunchKernelGGL((gn_small_kernel<f16, false>), dim3(groups, B), dim3(256), 0, s, (const f16*)x, (const f16*)x2,
+                               (f16*)nullptr, scale_shift, gamma, beta, HW, C1, C2, groups, eps, 0);
+        else
+            hipLaunchKernelGGL((gn_small_kernel<bf16, false>), dim3(groups, B), dim3(256), 0, s, (const bf16*)x, (const bf16*)x2,
+                               (bf16*)nullptr, scale_shift, gamma, beta, HW, C1, C2, groups, eps, 0);
+        return rsvld_check_launch();
+    }
     const GnPlan pl = gn_plan(B, HW);
     const int C = C1 + C2, C8 = C / 8;
     const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
     const size_t smem = (size_t)rif * C * 2 * sizeof(float);
     float* part = (float*)ws;
-    hipStream_t s = (hipStream_t)stream;
     if (dtype == RSVLD_F16)
         hipLaunchKernelGGL(gn_partial_kernel<f16>, dim3(pl.nchunks, B), dim3(256), smem, s, (const f16*)x, (const f16*)x2, part, HW, C1, C2, groups, pl.rows_per_chunk, pl.nchunks);
     else

@@ -230,7 +230,10 @@ def test_linear_and_geglu(cuda, dtype):
 
 
 GN_CASES = [(2, 64, 0, 16, 12, 32, True), (1, 320, 0, 9, 7, 32, False), (3, 512, 256, 6, 6, 32, True),
-            (1, 2560, 0, 4, 4, 32, True), (2, 128, 0, 40, 40, 32, True), (1, 960, 0, 5, 5, 32, True)]
+            (1, 2560, 0, 4, 4, 32, True), (2, 128, 0, 40, 40, 32, True), (1, 960, 0, 5, 5, 32, True),
+            # one-launch path for small tensors (one workgroup per image x group, slab held in registers)
+            (4, 512, 0, 32, 32, 32, True), (2, 512, 512, 17, 19, 32, True), (4, 512, 0, 64, 64, 32, False),
+            (1, 1024, 0, 9, 9, 32, True)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
