@@ -17,13 +17,13 @@ import re
 
 
 def short_name(n):
-    m = re.search(r"conv_halo_kernelI(\w+?)Li(\d+)E", n)
+    m = re.search(r"conv_halo(?:32)?_kernelI(\w+?)Li(\d+)E", n)   # conv_halo32 is the Cout > 64 variant: same bench label
     if m:
         return "conv_halo_%s" % m.group(2)
     m = re.search(r"conv_igemm_kernelI\w+?Li(\d+)ELi(\d+)E", n)
     if m:
         return "conv_igemm_%sx%s" % (m.group(1), m.group(2))
-    m = re.search(r"attn_d(\d+)_kernel", n)
+    m = re.search(r"attn_d(\d+)b?_kernel", n)
     if m:
         return "attn_d%s" % m.group(1)
     m = re.search(r"(?:N_1\d+|::)([a-z0-9_]+)_kernel", n)
