@@ -476,6 +476,8 @@ int dispatch_conv(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream);   // gemm.hip: large 1x1 / Linear layers
+
 extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     if (d == nullptr || d->x == nullptr || d->w == nullptr || d->out == nullptr) return RSVLD_EINVAL;
     if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ho <= 0 || d->Wo <= 0) return RSVLD_EINVAL;
@@ -491,6 +493,10 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     {
         const int Hin = d->upsample ? 2 * d->H : d->H, Win = d->upsample ? 2 * d->W : d->W;
         if ((d->Ho - 1) * d->stride - d->pad_t >= Hin || (d->Wo - 1) * d->stride - d->pad_l >= Win) return RSVLD_EINVAL;
+    }
+    {
+        const int rc = rsvld_gemm256_try(d, stream);   // the dedicated GEMM takes the shapes it is built for
+        if (rc != RSVLD_EUNSUPPORTED) return rc;
     }
     ConvArgs a;
     a.x = d->x; a.x2 = d->x2; a.w = d->w; a.bias = d->bias; a.rowvec = d->rowvec;

@@ -1,0 +1,288 @@
+// gemm.hip — out[m][n] = act(alpha * (sum_k X[m][k] W[n][k] + bias[n])) + beta * residual[m][n] for the 1x1 / Linear
+// layers of the Stage-2 transformer blocks (sgm/modules/attention.py:84-110,196-285,533-635): large M (tokens),
+// K = 320 .. 5120, N = 320 .. 10240.  rocprofv3 showed these layers at 420-630 TFLOP/s on conv_igemm's 128x128 tile
+// (64x64 per wave: 1 KiB of LDS fragment reads + 0.5 KiB of LDS-DMA writes per MFMA, 16 MFMAs per barrier), where the
+// library GEMM of the box reaches 750-1200 on the same shapes; they are 58 % of the Stage-2 time at latent 256.
+//
+// Structure (one workgroup per CU, 8 waves = 2 per SIMD, 128 KiB LDS):
+//   * 256 (m) x 256 (n) tile; wave (g, wn) owns rows 128 g .. +128 and columns 64 wn .. +64: 8 accumulators of
+//     32x32, 0.75 KiB of fragment reads and 0.25 KiB of DMA writes per MFMA;
+//   * K runs in 32-deep tiles through a 4-stage LDS ring (32 KiB per stage: X rows | W rows, 64-B rows, XOR swizzle on
+//     the DMA source side), three tiles in flight, counted vmcnt, raw barriers;
+//   * the two waves of a SIMD belong to different groups g and alternate roles every slot: while group 0 issues the
+//     16 MFMAs of tile t, group 1 reads its fragments of tile t and issues the DMAs of tile t+3, then they swap
+//     (cdna_hip_programming.md §5 "8-phase template" reduced to two phases per tile).  Every slot ends with a barrier
+//     that all 8 waves execute; a reader drains its own LDS reads before that barrier, so the ring is race-free by
+//     construction: tile t+3 is written one barrier after the last read of tile t-1 has RETURNED.
+// The MFMA A operand is the weight tile, the B operand the activation tile: a lane owns one output row (token) and,
+// per accumulator quad, four consecutive output channels (8-byte stores; GEGLU pairs are adjacent channels).
+#include <stdlib.h>
+
+#include "rsvld_common.h"
+
+namespace {
+
+struct GemmArgs {
+    const void* x;         // [M][K]
+    const void* w;         // [N][K]
+    const float* bias;     // [N] or nullptr
+    const void* residual;  // [M][N_out] or nullptr
+    void* out;             // [M][N_out]
+    int M, N, K, N_out;
+    int act;
+    float alpha, beta;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
+constexpr int G_NST = 4;
+constexpr int G_SMEM = G_NST * G_STAGE;
+
+// 64-B rows: 16-B slot s of row r sits at s ^ ((r>>2)&3): conflict-free ds_read_b128 (brute-forced, see conv_halo.hip)
+__device__ __forceinline__ int g_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int N> __device__ __forceinline__ void g_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    typedef typename Mfma<T>::v8 v8;
+    typedef typename Mfma<T>::v4 v4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order: each XCD walks a contiguous run of tiles, m fastest (the weight tile stays in that L2)
+    int tile_m, tile_n;
+    {
+        const int nmt = gridDim.x, nwg = gridDim.x * gridDim.y;
+        const int lid = blockIdx.x + blockIdx.y * nmt;
+        const int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, slot = lid >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile_n = t / nmt;
+        tile_m = t - tile_n * nmt;
+    }
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const int nk = p.K >> 5;
+    const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T);
+
+    // ---- DMA roles: wave w fills rows 32w .. 32w+31 of X and of W: two wave-instructions of 16 rows x 64 B each.
+    // lane -> (row = lane>>2, position = lane&3) holds source chunk position ^ ((row>>2)&3); rows past the end of the
+    // tensor re-read its last row (their outputs are never stored)
+    uint32_t xvo[2], wvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 32 * wave + 16 * i + (lane >> 2);
+        const uint32_t ch = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+        xvo[i] = (uint32_t)((int64_t)min(m0 + r, p.M - 1) * rowb) + ch;
+        wvo[i] = (uint32_t)((int64_t)min(n0 + r, p.N - 1) * rowb) + ch;
+    }
+    const char* Xb = (const char*)p.x;
+    const char* Wb = (const char*)p.w;
+    auto dma_piece = [&](int kt, int j) {   // j = 0..3: (X, W) x (rows 0..15, 16..31) of this wave's share of tile kt
+        char* st = smem + (kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024;
+        const char* src = ((j & 1) ? Wb : Xb) + kt * 64;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + ((j & 1) ? wvo[j >> 1] : xvo[j >> 1])), (lptr_t)st, 16, 0, 0);
+    };
+    auto dma_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_piece(kt, j);
+    };
+
+    f32x16 acc[2][4];   // [n tile][m tile]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    int fa_off[2], fb_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        fa_off[ks] = 16384 + g_off(wn * 64 + l31, 2 * ks + lh);     // weights: + ni * 2048
+        fb_off[ks] = g_off(grp * 128 + l31, 2 * ks + lh);           // activations: + mi * 2048
+    }
+
+    v8 fa[2][2], fb[2][4];   // [k-step][tile]
+    auto read_tile = [&](int kt) {
+        const char* st = smem + (kt & (G_NST - 1)) * G_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) fa[ks][ni] = *(const v8*)(st + fa_off[ks] + ni * 2048);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) fb[ks][mi] = *(const v8*)(st + fb_off[ks] + mi * 2048);
+        }
+    };
+    // 16 MFMAs of the fragments in registers; the 4 LDS-DMAs of tile `next` (if >= 0) are issued between them: an
+    // LDS-DMA costs its wave 60-180 issue cycles, which the matrix pipe covers here and which would lengthen the
+    // partner group's critical read slot otherwise
+    auto mma_tile = [&](int next) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], acc[ni][mi]);
+                if (next >= 0) dma_piece(next, 2 * ks + ni);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // own DMAs of tile kt+1 have landed; `ahead` later tiles of this wave may stay in flight (4 instructions per tile)
+    auto wait_ahead = [&](int ahead) {
+        if (ahead >= 2) g_wait_vm<8>();
+        else if (ahead == 1) g_wait_vm<4>();
+        else g_wait_vm<0>();
+    };
+    auto slot_end = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads have returned
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: three tiles in flight, tile 0 landed for everybody
+    dma_tile(0);
+    if (nk > 1) dma_tile(1);
+    if (nk > 2) dma_tile(2);
+    if (nk > 2) g_wait_vm<8>();
+    else if (nk > 1) g_wait_vm<4>();
+    else g_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- 2 nk + 1 slots; group 0 reads in even slots and multiplies in odd ones, group 1 runs one slot behind.
+    // Tile kt+3 is requested in the multiply slot of tile kt (its stage held tile kt-1, whose last reads returned
+    // before the barrier that opened the slot).  Before the barrier that precedes anybody's read of tile kt+1 every
+    // wave has waited for its own pieces of it: group 0 at the end of its multiply slot (tiles kt+2, kt+3 behind it),
+    // group 1 at the end of its read slot (only tile kt+2 behind it: it requests kt+3 one slot later).
+    if (grp == 0) {
+        for (int kt = 0; kt < nk; ++kt) {
+            read_tile(kt);
+            slot_end();
+            mma_tile(kt + 3 < nk ? kt + 3 : -1);
+            wait_ahead(min(nk - 1, kt + 3) - (kt + 1));
+            slot_end();
+        }
+        slot_end();
+    } else {
+        slot_end();
+        for (int kt = 0; kt < nk; ++kt) {
+            read_tile(kt);
+            wait_ahead(min(nk - 1, kt + 2) - (kt + 1));
+            slot_end();
+            mma_tile(kt + 3 < nk ? kt + 3 : -1);
+            slot_end();
+        }
+    }
+
+    // ---- epilogue through LDS (the ring is dead after the last barrier): a lane owns one output row and, per register
+    // quad, four consecutive channels, i.e. 8-byte pieces 512 B apart -- stored like that the 128 KiB tile leaves the
+    // CU in 16-byte fragments (measured: 17 us per tile, more than the K loop of a K = 640 layer).  So: bias / SiLU /
+    // GEGLU / alpha in registers -> 16-bit tile [256 rows][256 (GEGLU: 128) channels] in LDS (16-byte chunks XOR-swizzled
+    // by the row) -> every thread moves whole 16-byte chunks, rows leave as contiguous 512-byte runs; the residual is
+    // added on that side with equally coalesced loads.
+    const bool geglu = p.act == RSVLD_ACT_GEGLU;
+    const int row_chunks = geglu ? 16 : 32;                 // 16-byte chunks per tile row
+    auto c_off = [&](int row, int chunk) { return row * (row_chunks * 16) + ((chunk ^ (row & (row_chunks - 1))) << 4); };
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int row = grp * 128 + mi * 32 + l31;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wn * 64 + ni * 32 + 8 * g + 4 * lh;   // tile column of the quad
+                const int n = n0 + col;
+                float v[4] = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+                if (p.bias != nullptr && n < p.N) {
+                    const f32x4 bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                }
+                if (geglu) {   // channels are (value, gate) interleaved: 2 outputs per quad
+                    T o2[2] = {(T)(p.alpha * v[0] * gelu_erf_f(v[1])), (T)(p.alpha * v[2] * gelu_erf_f(v[3]))};
+                    uint32_t packed;
+                    __builtin_memcpy(&packed, o2, 4);
+                    const int oc = col >> 1;   // output column inside the 128-wide tile
+                    *(uint32_t*)(smem + c_off(row, oc >> 3) + (oc & 7) * 2) = packed;
+                } else {
+                    if (p.act == RSVLD_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    v4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (T)(v[e] * p.alpha);
+                    *(v4*)(smem + c_off(row, col >> 3) + (col & 7) * 2) = o;
+                }
+            }
+    }
+    __syncthreads();
+    {
+        const int n_tile_out = geglu ? 128 : 256;                         // channels of the stored tile
+        const int n_out0 = geglu ? (n0 >> 1) : n0;
+        const int chunk = tid & (row_chunks - 1);
+        const int rows_per_pass = 512 / row_chunks;
+        const int nn = n_out0 + chunk * 8;
+        if (nn < p.N_out) {
+            for (int row = tid / row_chunks; row < 256; row += rows_per_pass) {
+                const int m = m0 + row;
+                if (m >= p.M) break;
+                u32x4 v = *(const u32x4*)(smem + c_off(row, chunk));
+                if (p.residual != nullptr) {
+                    float f[8], rf[8];
+                    unpack8<T>(v, f);
+                    unpack8<T>(*(const u32x4*)((const T*)p.residual + (int64_t)m * p.N_out + nn), rf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
+                    v = pack8<T>(f);
+                }
+                *(u32x4*)((T*)p.out + (int64_t)m * p.N_out + nn) = v;
+            }
+        }
+        (void)n_tile_out;
+    }
+}
+
+}  // namespace
+
+// Eligibility + launch, called from rsvld_conv2d_nhwc for 1x1 / stride-1 / single-source layers.
+// Returns RSVLD_EUNSUPPORTED when the shape should stay on the implicit-GEMM kernel.
+int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
+    static const bool off = getenv("RSVLD_GEMM256_OFF") != nullptr;   // A/B switch
+    if (off) return RSVLD_EUNSUPPORTED;
+    if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad_t != 0 || d->pad_l != 0 || d->upsample) return RSVLD_EUNSUPPORTED;
+    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || d->out_f32) return RSVLD_EUNSUPPORTED;
+    if (d->Cin % 32 != 0 || d->Cout % 8 != 0) return RSVLD_EUNSUPPORTED;
+    const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
+    if (d->H != d->Ho || d->W != d->Wo) return RSVLD_EUNSUPPORTED;
+    if (d->Cout < 256 || M < 4096) return RSVLD_EUNSUPPORTED;
+    const int64_t tiles = ((M + 255) / 256) * ((d->Cout + 255) / 256);
+    if (tiles < 192) return RSVLD_EUNSUPPORTED;                 // one workgroup per CU: the grid must fill the chip
+    if (M * d->Cin * 2 >= ((int64_t)1 << 32) || (int64_t)d->Cout * d->Cin * 2 >= ((int64_t)1 << 32)) return RSVLD_EUNSUPPORTED;
+    if (d->act == RSVLD_ACT_GEGLU && (d->Cout % 16 != 0 || d->residual != nullptr)) return RSVLD_EINVAL;
+    GemmArgs a;
+    a.x = d->x; a.w = d->w; a.bias = d->bias; a.residual = d->residual; a.out = d->out;
+    a.M = (int)M; a.N = d->Cout; a.K = d->Cin;
+    a.N_out = d->act == RSVLD_ACT_GEGLU ? d->Cout / 2 : d->Cout;
+    a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)((d->Cout + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    auto go = [&](auto kern) -> int {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
+                return RSVLD_ELAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(512), G_SMEM, s, a);
+        return rsvld_check_launch();
+    };
+    return d->dtype == RSVLD_F16 ? go(gemm256_kernel<f16>) : go(gemm256_kernel<bf16>);
+}

@@ -54,7 +54,20 @@ template <typename T> __device__ __forceinline__ u32x4 pack8(const float (&f)[8]
 
 // x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp): an IEEE division here made the GroupNorm apply pass VALU-bound
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (sgm/modules/attention.py:84-96 uses F.gelu's default).  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, far below 16-bit output resolution): one v_rcp, one v_exp and a degree-5 Horner chain instead of
+// libm erff's ~100 instructions -- the GEGLU epilogue of the K = 640 feed-forward GEMMs cost as much as their K loop.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = 1.0f - poly * t * __expf(-z * z);   // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

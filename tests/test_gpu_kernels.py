@@ -168,6 +168,41 @@ def test_conv3x3_halo_fused_upsample(cuda, dtype):
     _close(got.permute(0, 3, 1, 2), want, dtype)
 
 
+GEMM_CASES = [
+    # M, K, N, act (0 none, 1 SiLU, 2 GEGLU), residual
+    (4160, 320, 3840, 0, False),    # ragged M tile (64 rows), 10 K tiles, 255 workgroups
+    (4096, 32, 3848, 0, True),      # a single K tile (prologue only), ragged N tile (8 columns), residual
+    (8192, 64, 2560, 1, True),      # two K tiles, SiLU + residual
+    (4224, 1280, 4096, 2, False),   # GEGLU pairs, 40 K tiles
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm256_linear(cuda, dtype, case):
+    """csrc/gemm.hip: the 256x256 ping-pong GEMM that takes the large 1x1 / Linear layers; vs torch fp32 and vs the
+    implicit-GEMM kernel on the same call (RSVLD_GEMM256_OFF is read once per process, so the cross-check is numeric)."""
+    from rsvld_amd import ops, _lib as L
+    M, K, N, act, use_res = case
+    g = torch.Generator().manual_seed(M + K + N)
+    x = _rt(torch.randn(M, K, generator=g), dtype)
+    w = _rt(torch.randn(N, K, generator=g) / math.sqrt(K), dtype)
+    b = torch.randn(N, generator=g) * 0.1
+    res = _rt(torch.randn(M, N, generator=g), dtype) if use_res else None
+    y = x @ w.t() + b
+    if act == 1:
+        y = F.silu(y)
+    if act == 2:
+        val, gate = y.chunk(2, dim=-1)
+        y = val * F.gelu(gate)
+    if use_res:
+        y = y + res
+    pc = ops.pack_conv(w, b, dtype, cuda, geglu=(act == 2))
+    got = ops.linear(x.to(cuda, dtype), pc, residual=None if res is None else res.to(cuda, dtype),
+                     act={0: L.ACT_NONE, 1: L.ACT_SILU, 2: L.ACT_GEGLU}[act])
+    _close(got, y, dtype)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv2d_epilogue_rowvec_residual_concat(cuda, dtype):
     from rsvld_amd import ops
