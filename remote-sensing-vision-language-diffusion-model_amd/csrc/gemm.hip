@@ -121,7 +121,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     };
     // 16 MFMAs of the fragments in registers; the 4 LDS-DMAs of tile `next` (if >= 0) are issued between them: an
     // LDS-DMA costs its wave 60-180 issue cycles, which the matrix pipe covers here and which would lengthen the
-    // partner group's critical read slot otherwise
+    // partner group's critical read slot otherwise (measured: all four in the read slot -4 %, two and two -5 % at
+    // K >= 2560 against this placement)
     auto mma_tile = [&](int next) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -264,7 +265,7 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     if (d->H != d->Ho || d->W != d->Wo) return RSVLD_EUNSUPPORTED;
     if (d->Cout < 256 || M < 4096) return RSVLD_EUNSUPPORTED;
     const int64_t tiles = ((M + 255) / 256) * ((d->Cout + 255) / 256);
-    if (tiles < 192) return RSVLD_EUNSUPPORTED;                 // one workgroup per CU: the grid must fill the chip
+    if (tiles < 128) return RSVLD_EUNSUPPORTED;   // one workgroup per CU; measured: from half the chip up it beats the 128x128 kernel
     if (M * d->Cin * 2 >= ((int64_t)1 << 32) || (int64_t)d->Cout * d->Cin * 2 >= ((int64_t)1 << 32)) return RSVLD_EUNSUPPORTED;
     if (d->act == RSVLD_ACT_GEGLU && (d->Cout % 16 != 0 || d->residual != nullptr)) return RSVLD_EINVAL;
     GemmArgs a;

@@ -232,7 +232,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     M = B * Ho * Wo
     if (pc.kh == 1 and pc.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not upsample and x2 is None and rowvec is None
             and not out_f32 and Cin % 32 == 0 and pc.cout_p >= 256 and M >= 4096
-            and ((M + 255) // 256) * ((pc.cout_p + 255) // 256) >= 192 and M * Cin * 2 < 2 ** 32
+            and ((M + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128 and M * Cin * 2 < 2 ** 32
             and os.environ.get("RSVLD_GEMM256_OFF") is None):   # mirrors rsvld_gemm256_try in csrc/gemm.hip
         variant = "gemm_256x256"
     elif pc.cout_p <= 32:
