@@ -278,12 +278,12 @@ def main():
     net.use_graph = not args.no_graph
     cond = synthetic_batch(args.batch, args.lr_side, args.scale, rank).to(dev)
 
-    def one_pass():
+    def one_pass(gather=True):
         # continous=False returns ret_img[-1], i.e. ONE image (diffusion.py:198-201): take the last
         # B rows of the 11-frame stack instead, as infer.py does for its single image (infer.py:133-135)
         sr = net.super_resolution(cond, continous=True)[-args.batch:]
         u8 = parallel.to_uint8(sr)
-        return parallel.gather_images(u8, world)
+        return parallel.gather_images(u8, world) if gather else u8
 
     def barrier():
         if world > 1:
@@ -313,7 +313,7 @@ def main():
         ops.set_profiler(prof)
         saved = net.use_graph
         net.use_graph = False
-        one_pass()
+        one_pass(gather=False)   # rank 0 only: no collective in here, the other ranks have moved on
         torch.cuda.synchronize()
         net.use_graph = saved
         ops.set_profiler(None)

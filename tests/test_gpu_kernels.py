@@ -447,3 +447,40 @@ def test_errors_are_loud(cuda):
     q = torch.zeros(1, 8, 96, dtype=torch.float16, device=cuda)
     with pytest.raises(L.RsvldError):
         ops.attention(q, q, q, heads=1)  # D = 96 unsupported
+
+
+def test_hand_scheduled_kernels_are_deterministic(cuda):
+    """Race screen for the kernels whose synchronisation is counted by hand (asm loads left in flight over raw barriers,
+    LDS-DMA rings, ping-pong wave groups): the same launch repeated 8 times on a busy chip must give bit-identical
+    output -- a missing wait or barrier shows up as run-to-run differences long before it fails a tolerance test."""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(123)
+    dt = torch.float16
+
+    def repeat(fn, n=8):
+        ref = fn().clone()
+        for _ in range(n - 1):
+            assert torch.equal(fn(), ref)
+
+    # d = 512 attention: split-KV (2048 keys -> 4 ranges) and a long single-range run
+    qkv = (torch.randn(2, 2048, 1536, generator=g) * 0.5).to(cuda, dt)
+    repeat(lambda: ops.attention(qkv[..., :512], qkv[..., 512:1024], qkv[..., 1024:], heads=1))
+    qkv2 = (torch.randn(26, 900, 1536, generator=g) * 0.5).to(cuda, dt)
+    repeat(lambda: ops.attention(qkv2[..., :512], qkv2[..., 512:1024], qkv2[..., 1024:], heads=1))
+    # d = 64 attention, ragged keys
+    q = torch.randn(2, 3000, 640, generator=g).to(cuda, dt)
+    kv = torch.randn(2, 2777, 1280, generator=g).to(cuda, dt)
+    repeat(lambda: ops.attention(q, kv[..., :640], kv[..., 640:], heads=10))
+    # 256x256 GEMM (ping-pong groups), ragged M
+    x = torch.randn(8200, 1280, generator=g).to(cuda, dt)
+    pc = ops.pack_conv(torch.randn(3840, 1280, generator=g) / 36, torch.zeros(3840), dt, cuda)
+    repeat(lambda: ops.linear(x, pc))
+    # double-buffered halo conv with the fused norm prologue, 8 bodies
+    xi = (torch.randn(2, 40, 72, 512, generator=g)).to(cuda, dt)
+    pcc = ops.pack_conv(torch.randn(256, 512, 3, 3, generator=g) / 68, None, dt, cuda)
+    norm = (torch.ones(512, device=cuda), torch.zeros(512, device=cuda), 32, 1e-5, True)
+    ops.HALO_MIN_WGS = 0
+    try:
+        repeat(lambda: ops.conv2d(xi, pcc, pad=1, norm=norm))
+    finally:
+        ops.HALO_MIN_WGS = 256
