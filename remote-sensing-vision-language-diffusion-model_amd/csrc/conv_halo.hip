@@ -35,7 +35,8 @@ struct HaloArgs {
     int out_f32, act, norm_silu;
     float alpha, beta;
     int Ctot, nchunks;   // channels, 64-channel chunks
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y;   // workgroup tiles (tiles_y counts rows of the kernel's own tile height)
+    int tiles_y8;           // rows of the 8x32-pixel grid of the statistics partials
     int rv_stride, Cout_out;
 };
 
@@ -54,17 +55,20 @@ __device__ __forceinline__ int swz_off(int row, int c) { return row * 128 + ((c 
 // immediate offset -- no address arithmetic inside the tap loop.
 __device__ __forceinline__ int patch_off(int py, int px, int c) { return (py * PW + px) * 128 + ((c ^ ((px >> 1) & 7)) << 4); }
 
-// ---- epilogue shared by both halo kernels: accumulators -> LDS (fp32) -> bias / row vector / SiLU / residual ->
-// 16-byte NHWC stores, plus the per-tile per-channel (sum, sumsq) partials for the next GroupNorm.
-// EPI_PASSES passes of EPI_ROWS pixels; the staging tile aliases the (dead) operand buffers.
-template <typename T, int BN, int TM, int TN>
+// ---- epilogue shared by the halo kernels: accumulators -> LDS (fp32) -> bias / row vector / SiLU / residual ->
+// 16-byte NHWC stores, plus the per-channel (sum, sumsq) partials of every 8x32-pixel sub-tile for the next GroupNorm.
+// NW waves own 64*NW pixels (8 rows of 32 per 4 waves); passes of EPI_ROWS pixels; the staging tile aliases the (dead)
+// operand buffers.
+template <typename T, int BN, int TM, int TN, int NW = 4>
 __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32x16 (&acc)[TN][TM], int tid, int wm, int wn,
                                               int l31, int lh, int x0, int y0, int n0, int img, int tx, int ty) {
-    constexpr int EPI_PASSES = BN > 64 ? 2 : 1;
-    constexpr int EPI_ROWS = 256 / EPI_PASSES;
+    constexpr int NT = 64 * NW, PIX = 64 * NW;
+    constexpr int EPI_ROWS = BN > 64 ? 128 : 256;
+    constexpr int EPI_PASSES = PIX / EPI_ROWS;
+    constexpr int SUB = 256 / EPI_ROWS;        // passes per 8x32 sub-tile
     constexpr int CT_STRIDE = BN + 4;
     float* Ct = (float*)smem;
-    constexpr int CPR = BN / 8, RPP = 256 / CPR;
+    constexpr int CPR = BN / 8, RPP = NT / CPR;
     const int cc = tid % CPR, rr = tid / CPR;
     const int n = n0 + cc * 8;
     float bv[8];
@@ -132,23 +136,26 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
                 }
             }
         }
-    }
-    if (p.stats != nullptr) {   // workgroup-uniform
-        __syncthreads();        // Ct is dead: reuse it as [RPP][BN][2]
-        float* red = (float*)smem;
+        if (p.stats != nullptr && (pass % SUB) == SUB - 1) {   // workgroup-uniform: an 8x32 sub-tile is complete
+            __syncthreads();        // Ct is dead: reuse it as [RPP][BN][2]
+            float* red = (float*)smem;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[((rr * BN) + cc * 8 + e) * 2] = st_s[e];
-            red[((rr * BN) + cc * 8 + e) * 2 + 1] = st_q[e];
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.Cout) {
-            float a = 0.f, q = 0.f;
-            for (int r = 0; r < RPP; ++r) { a += red[(r * BN + tid) * 2]; q += red[(r * BN + tid) * 2 + 1]; }
-            const int64_t tile = (int64_t)ty * p.tiles_x + tx;
-            float* o = p.stats + (((int64_t)img * p.tiles_x * p.tiles_y + tile) * p.Cout + n0 + tid) * 2;
-            o[0] = a;
-            o[1] = q;
+            for (int e = 0; e < 8; ++e) {
+                red[((rr * BN) + cc * 8 + e) * 2] = st_s[e];
+                red[((rr * BN) + cc * 8 + e) * 2 + 1] = st_q[e];
+                st_s[e] = 0.f;
+                st_q[e] = 0.f;
+            }
+            __syncthreads();
+            const int ty8 = ty * (PIX / 256) + pass / SUB;   // row of the 8x32 partial grid
+            if (tid < BN && n0 + tid < p.Cout && ty8 < p.tiles_y8) {
+                float a = 0.f, q = 0.f;
+                for (int r = 0; r < RPP; ++r) { a += red[(r * BN + tid) * 2]; q += red[(r * BN + tid) * 2 + 1]; }
+                const int64_t tile = (int64_t)ty8 * p.tiles_x + tx;
+                float* o = p.stats + (((int64_t)img * p.tiles_x * p.tiles_y8 + tile) * p.Cout + n0 + tid) * 2;
+                o[0] = a;
+                o[1] = q;
+            }
         }
     }
 }
@@ -344,8 +351,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
 // issued after the step's DMAs, in flight) and the barrier is raw.  NORM / NEXT are compile-time so that a step is
 // one basic block and the scheduler can place the VALU between the MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int P32_BYTES = PROWS * 64;   // one 32-channel patch buffer
-constexpr int P32_LOADS = 6;            // 340 x 4 sixteen-byte pieces over 256 threads
+#ifndef HALO_ABL
+#define HALO_ABL 0   // diagnostic builds (timing only, results wrong): 1 no weight DMA in the loop, 2 no patch prefetch/normalise, 4 half the fragment reads
+#endif
 constexpr int AB32_BYTES = 1024;        // one LDS-DMA wave-instruction: 512 B of (scale, shift) + 512 B duplicate
 
 // pixel (py, px) owns a 64-B row; 16-B slot s sits at s ^ ((px>>2)&3): conflict-free ds_read_b128 for every tap shift
@@ -358,18 +366,30 @@ template <int N> __device__ __forceinline__ void halo_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <typename T, int BN, int WAVES_M, int NORM>   // NORM: 0 none, 1 scale/shift, 2 scale/shift + SiLU
-__global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
-    constexpr int WAVES_N = 4 / WAVES_M;
-    constexpr int TM = TH / WAVES_M;
+// NORM: 0 none, 1 scale/shift, 2 scale/shift + SiLU.  NW = 4: 8x32-pixel tile, two workgroups per CU.  NW = 8: 16x32-pixel
+// tile, one workgroup per CU (same 8 waves per CU): the per-tap weight slice is staged once per CU instead of twice and
+// the halo overhead of the patch drops (612 instead of 680 patch pixels per 512 outputs).  Ablation builds
+// (tools/ablate_halo.sh) put the issue cost of the weight LDS-DMAs at 25 % of the 4-wave kernel's time and the patch
+// pipeline at 22-36 %, the fragment reads at ~1 %: per-wave DMA / staging instructions are what to cut.
+template <typename T, int BN, int NORM, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
+    constexpr int NT = 64 * NW;
+    constexpr int WAVES_N = 2, WAVES_M = NW / 2;
+    constexpr int TM = 4;                            // 32-pixel rows per wave
+    constexpr int THT = TM * WAVES_M;                // tile rows: 8 or 16
     constexpr int TN = BN / (32 * WAVES_N);
-    constexpr int TAP_BYTES = BN * 64;       // [BN x 32 ch] weight slice of one tap
-    constexpr int W_BYTES = 2 * TAP_BYTES;   // a step stages two taps
-    constexpr int W_LOADS = BN / 64;         // LDS-DMA instructions per thread per tap
+    constexpr int PR = (THT + 2) * PW;               // patch pixels
+    constexpr int PB = PR * 64;                      // one 32-channel patch buffer
+    constexpr int PL = (PR * 4 + NT - 1) / NT;       // 16-byte pieces per thread: 6 (NW = 4) or 5 (NW = 8)
+    constexpr int TAP_BYTES = BN * 64;               // [BN x 32 ch] weight slice of one tap
+    constexpr int W_BYTES = 2 * TAP_BYTES;           // a step stages two taps
+    constexpr int W_LOADS = BN / (16 * NW);          // LDS-DMA instructions per thread per tap
+    static_assert(PL == 5 || PL == 6, "wait_patch names PL register quads");
+    static_assert(BN % (16 * NW) == 0, "whole wave-instructions per tap");
     typedef typename Mfma<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* patch = smem;                      // [2][P32_BYTES]
-    char* wbuf = smem + 2 * P32_BYTES;       // [2][W_BYTES]
+    char* patch = smem;                      // [2][PB]
+    char* wbuf = smem + 2 * PB;              // [2][W_BYTES]
     char* abuf = wbuf + 2 * W_BYTES;         // [2][AB32_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -387,40 +407,43 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
         img = t % p.B;
         tile_n = t / p.B;
     }
-    const int x0 = tx * TW, y0 = ty * TH, n0 = tile_n * BN;
+    const int x0 = tx * TW, y0 = ty * THT, n0 = tile_n * BN;
 
-    // ---- patch roles: piece i of this thread = patch pixel (tid>>2) + 64 i, 16-byte slot c4 = tid & 3
+    // ---- patch roles: piece i of this thread = patch pixel (tid>>2) + 16 NW i, 16-byte slot c4 = tid & 3
     const int c4 = tid & 3;
-    int poff[P32_LOADS];   // source pixel offset, -1 = zero padding / past the patch
-    int pdst[P32_LOADS];   // LDS byte offset inside a patch buffer; pieces past the patch write a dead LDS word
+    int poff[PL];   // source pixel offset, -1 = zero padding / past the patch
+    int pdst[PL];   // LDS byte offset inside a patch buffer; pieces past the patch write a dead LDS word
 #pragma unroll
-    for (int i = 0; i < P32_LOADS; ++i) {
-        const int pp = (tid >> 2) + 64 * i;
+    for (int i = 0; i < PL; ++i) {
+        const int pp = (tid >> 2) + 16 * NW * i;
         const int py = pp / PW, px = pp - py * PW;
         const int y = y0 - 1 + py, x = x0 - 1 + px;
-        poff[i] = (pp < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y >> p.ush) * p.Ws + (x >> p.ush) : -1;
+        poff[i] = (pp < PR && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y >> p.ush) * p.Ws + (x >> p.ush) : -1;
         // dead target: the duplicate half of (scale, shift) buffer 0, never read
-        pdst[i] = pp < PROWS ? p32_off(py, px, c4) : (int)(abuf - patch) + 512 + (tid & 31) * 16;
+        pdst[i] = pp < PR ? p32_off(py, px, c4) : (int)(abuf - patch) + 512 + (tid & 31) * 16;
     }
     const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * p.Cin;
     const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * p.Cin2 : nullptr;
     const T* __restrict__ Wp = (const T*)p.w;
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
-    u32x4 rp[P32_LOADS];
-    auto issue_patch = [&](int k32, u32x4 (&r)[P32_LOADS]) {
+    u32x4 rp[PL];
+    auto issue_patch = [&](int k32, u32x4 (&r)[PL]) {
         const int ch0 = k32 * 32;
         const T* src;
         int Cs, coff;
         if (ch0 < p.Cin) { src = X1; Cs = p.Cin; coff = ch0 + c4 * 8; } else { src = X2; Cs = p.Cin2; coff = ch0 - p.Cin + c4 * 8; }
 #pragma unroll
-        for (int i = 0; i < P32_LOADS; ++i) {
+        for (int i = 0; i < PL; ++i) {
             const T* ptr = src + (int64_t)(poff[i] < 0 ? 0 : poff[i]) * Cs + coff;   // padding reads a valid dummy, zeroed later
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[i]) : "v"(ptr) : "memory");
         }
     };
-    auto wait_patch = [&](u32x4 (&r)[P32_LOADS]) {   // names every destination: no consumer is scheduled above it
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : : "memory");
+    auto wait_patch = [&](u32x4 (&r)[PL]) {   // names every destination: no consumer is scheduled above it
+        if constexpr (PL == 6)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[PL - 1]) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : : "memory");
     };
     // normalise piece i and write it into patch buffer P; ab16 = (scale, shift) of this thread's 8 channels.  Branch-free.
     auto norm_write = [&](u32x4 v, int i, const float (&ab16)[16], char* P) {
@@ -449,14 +472,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
         }
     };
     // weights of flat tap g (0..17) of body b: chunk 2b + (g >= 9), tap g % 9; lane-linear LDS image, source-side swizzle.
-    // Address = uniform base (SGPR pair: tap, chunk) + 32-bit per-lane offset (row, swizzled slot): two VGPRs in all --
+    // Address = uniform base (SGPR pair: tap, chunk) + 32-bit per-lane offset (row, swizzled slot): W_LOADS VGPRs in all --
     // with 64-bit per-lane pointers hipcc hoists one pointer per (tap, row group) out of the loop and spills them.
     const int wr0 = tid >> 2;
     const int wsl = (tid & 3) ^ ((wr0 >> 2) & 3);
     uint32_t wvoff[W_LOADS];
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i)   // rows past Cout re-read the last row; their accumulators are never stored
-        wvoff[i] = (uint32_t)(((int64_t)min(n0 + wr0 + 64 * i, p.Cout - 1) * Kel + wsl * 8) * (int64_t)sizeof(T));
+        wvoff[i] = (uint32_t)(((int64_t)min(n0 + wr0 + 16 * NW * i, p.Cout - 1) * Kel + wsl * 8) * (int64_t)sizeof(T));
     auto dma_w = [&](int b, int st, int buf) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
             const char* base = (const char*)(Wp + (int64_t)tap * p.Ctot + k32 * 32);   // wave-uniform
 #pragma unroll
             for (int i = 0; i < W_LOADS; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + wvoff[i]), (lptr_t)(dst + (wave * 16 + 64 * i) * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + wvoff[i]), (lptr_t)(dst + (wave * 16 + 16 * NW * i) * 64), 16, 0, 0);
         }
     };
     auto dma_ab = [&](int b, int buf) {   // (scale, shift) of the 64 channels of body b: 512 B, lanes 32..63 duplicate it
@@ -497,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
     dma_w(0, 0, 0);
     dma_ab(0, 0);
     {
-        u32x4 ra[P32_LOADS];
+        u32x4 ra[PL];
         issue_patch(0, ra);
         issue_patch(1, rp);
         float ab16[16];
@@ -506,13 +529,20 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) ab16[e] = ab[e];
         }
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(rp[0]), "+v"(rp[1]),
-                       "+v"(rp[2]), "+v"(rp[3]), "+v"(rp[4]), "+v"(rp[5])
-                     :
-                     : "memory");
+        if constexpr (PL == 6)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[PL - 1]), "+v"(rp[0]), "+v"(rp[1]),
+                           "+v"(rp[2]), "+v"(rp[3]), "+v"(rp[4]), "+v"(rp[PL - 1])
+                         :
+                         : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(rp[0]), "+v"(rp[1]), "+v"(rp[2]),
+                           "+v"(rp[3]), "+v"(rp[4])
+                         :
+                         : "memory");
 #pragma unroll
-        for (int i = 0; i < P32_LOADS; ++i) norm_write(ra[i], i, ab16, patch);
+        for (int i = 0; i < PL; ++i) norm_write(ra[i], i, ab16, patch);
     }
     halo_wait_barrier<0>();
 
@@ -521,32 +551,34 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
         constexpr bool NEXT = decltype(next_c)::value;
 #pragma unroll
         for (int st = 0; st < 9; ++st, ++s) {
-            if (st < 8) dma_w(b, st + 1, (s + 1) & 1);
-            else if (NEXT) dma_w(b + 1, 0, (s + 1) & 1);
-            if (st == 4 && NEXT) {
+            if (!(HALO_ABL & 1)) {
+                if (st < 8) dma_w(b, st + 1, (s + 1) & 1);
+                else if (NEXT) dma_w(b + 1, 0, (s + 1) & 1);
+            }
+            if (st == 4 && NEXT && !(HALO_ABL & 2)) {
                 dma_ab(b + 1, (b + 1) & 1);
                 issue_patch(2 * b + 2, rp);
             }
-            if (st >= 1 && st <= 3) {          // B of this body -> buffer 1
+            if (st >= 1 && st <= 3 && !(HALO_ABL & 2)) {          // B of this body -> buffer 1
                 float ab16[16];
                 lds_ab(abuf + (b & 1) * AB32_BYTES + 256 + c4 * 64, ab16);
-                norm_write(rp[2 * (st - 1)], 2 * (st - 1), ab16, patch + P32_BYTES);
-                norm_write(rp[2 * (st - 1) + 1], 2 * (st - 1) + 1, ab16, patch + P32_BYTES);
+                norm_write(rp[2 * (st - 1)], 2 * (st - 1), ab16, patch + PB);
+                if (2 * (st - 1) + 1 < PL) norm_write(rp[2 * (st - 1) + 1 < PL ? 2 * (st - 1) + 1 : 0], 2 * (st - 1) + 1 < PL ? 2 * (st - 1) + 1 : 0, ab16, patch + PB);
             }
-            if (st >= 6 && NEXT) {             // A' of the next body -> buffer 0
+            if (st >= 6 && NEXT && !(HALO_ABL & 2)) {             // A' of the next body -> buffer 0
                 float ab16[16];
                 lds_ab(abuf + ((b + 1) & 1) * AB32_BYTES + c4 * 64, ab16);
                 norm_write(rp[2 * (st - 6)], 2 * (st - 6), ab16, patch);
-                norm_write(rp[2 * (st - 6) + 1], 2 * (st - 6) + 1, ab16, patch);
+                if (2 * (st - 6) + 1 < PL) norm_write(rp[2 * (st - 6) + 1 < PL ? 2 * (st - 6) + 1 : 0], 2 * (st - 6) + 1 < PL ? 2 * (st - 6) + 1 : 0, ab16, patch);
             }
-            if (st == 8 && NEXT) issue_patch(2 * b + 3, rp);
+            if (st == 8 && NEXT && !(HALO_ABL & 2)) issue_patch(2 * b + 3, rp);
             const char* w_st = wbuf + (s & 1) * W_BYTES;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int g = 2 * st + j;
                 const int par = g >= 9 ? 1 : 0, tap = g >= 9 ? g - 9 : g;
                 const int ky = tap / 3, kx = tap - ky * 3;
-                const char* P = patch + par * P32_BYTES;
+                const char* P = patch + par * PB;
                 const char* w_s = w_st + j * TAP_BYTES;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -554,7 +586,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_s + fa_off[ks] + ni * (32 * 64));
 #pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) fb[mi] = *(const v8*)(P + fb_off[kx][ks] + (mi + ky) * (PW * 64));
+                    for (int mi = 0; mi < TM; ++mi) {
+                        if ((HALO_ABL & 4) && (mi & 1)) fb[mi] = fb[mi - 1];
+                        else fb[mi] = *(const v8*)(P + fb_off[kx][ks] + (mi + ky) * (PW * 64));
+                    }
 #pragma unroll
                     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -564,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
             // end of step: the DMAs of this step (weights of the next step, (scale, shift) rows) must have landed; patch
             // loads issued in this step (after those DMAs) stay in flight
             if ((st == 4 || st == 8) && NEXT) {
-                halo_wait_barrier<P32_LOADS>();
+                halo_wait_barrier<PL>();
             } else {
                 if ((st == 5 || st == 0)) wait_patch(rp);
                 halo_wait_barrier<0>();
@@ -574,15 +609,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo32_kernel(HaloArgs p) {
     for (int b = 0; b + 1 < nb; ++b) body(b, std::true_type{});
     body(nb - 1, std::false_type{});
 
-    halo_epilogue<T, BN, TM, TN>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
+    halo_epilogue<T, BN, TM, TN, NW>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
 }
 
-template <typename T, int BN, int WAVES_M>
-int launch_halo32(const HaloArgs& a, hipStream_t s) {
-    constexpr int stage = 2 * P32_BYTES + 2 * (2 * BN * 64) + 2 * AB32_BYTES;
-    constexpr int epi = (256 / (BN > 64 ? 2 : 1)) * (BN + 4) * 4;
-    constexpr int smem = stage > epi ? stage : epi;
+template <typename T, int BN, int NW>
+int launch_halo32(HaloArgs a, hipStream_t s) {
+    constexpr int THT = 2 * NW;
+    constexpr int stage = 2 * ((THT + 2) * PW * 64) + 2 * (2 * BN * 64) + 2 * AB32_BYTES;
+    constexpr int epi = (BN > 64 ? 128 : 256) * (BN + 4) * 4;
+    constexpr int red = (64 * NW / (BN / 8)) * BN * 2 * 4;
+    constexpr int smem = stage > epi ? (stage > red ? stage : red) : (epi > red ? epi : red);
     const int norm = a.ab == nullptr ? 0 : (a.norm_silu ? 2 : 1);
+    a.tiles_y = (a.H + THT - 1) / THT;
     const int64_t nwg = (int64_t)a.tiles_x * a.tiles_y * a.B * ((a.Cout + BN - 1) / BN);
     if (nwg >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
     auto go = [&](auto kern) -> int {
@@ -593,12 +631,12 @@ int launch_halo32(const HaloArgs& a, hipStream_t s) {
                 return RSVLD_ELAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), smem, s, a);
         return rsvld_check_launch();
     };
-    if (norm == 0) return go(conv_halo32_kernel<T, BN, WAVES_M, 0>);
-    if (norm == 1) return go(conv_halo32_kernel<T, BN, WAVES_M, 1>);
-    return go(conv_halo32_kernel<T, BN, WAVES_M, 2>);
+    if (norm == 0) return go(conv_halo32_kernel<T, BN, 0, NW>);
+    if (norm == 1) return go(conv_halo32_kernel<T, BN, 1, NW>);
+    return go(conv_halo32_kernel<T, BN, 2, NW>);
 }
 
 template <typename T, int BN, int WAVES_M, int TPS>
@@ -624,7 +662,12 @@ int dispatch_halo(const HaloArgs& a, hipStream_t s) {
     if (a.Cout <= 64) return launch_halo<T, 64, 4, 2>(a, s);
     static const bool old128 = getenv("RSVLD_HALO_OLD128") != nullptr;   // A/B switch: the single-buffered 64-channel kernel
     if (old128) return launch_halo<T, 128, 2, 1>(a, s);
-    return launch_halo32<T, 128, 2>(a, s);
+    // 16x32-pixel tiles (one 8-wave workgroup per CU) once that grid still covers most of the chip
+    static const char* nw_env = getenv("RSVLD_HALO_NW");   // A/B switch: 4 or 8
+    const int64_t wg16 = (int64_t)a.tiles_x * ((a.H + 15) / 16) * a.B * ((a.Cout + 127) / 128);
+    const bool use8 = nw_env ? nw_env[0] == '8' : wg16 >= 192;
+    if (use8) return launch_halo32<T, 128, 8>(a, s);
+    return launch_halo32<T, 128, 4>(a, s);
 }
 
 }  // namespace
@@ -663,6 +706,7 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     a.nchunks = a.Ctot / 64;
     a.tiles_x = (d->Wo + TW - 1) / TW;
     a.tiles_y = (d->Ho + TH - 1) / TH;
+    a.tiles_y8 = a.tiles_y;
     a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
     a.Cout_out = d->Cout;
     hipStream_t s = (hipStream_t)stream;

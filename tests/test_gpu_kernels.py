@@ -78,6 +78,9 @@ HALO_CASES = [
     (2, 192, 0, 128, 10, 35, False),    # no norm, BN = 128 (double-buffered 32-channel patch pipeline), 3 bodies, batch 2
     (2, 512, 512, 128, 8, 32, True),    # 16 bodies across two sources: every steady-state prefetch slot is exercised
     (3, 64, 0, 128, 9, 31, True),       # single body (no prefetch beyond the prologue), batch 3
+    (2, 64, 0, 512, 96, 128, True),     # >= 192 workgroups of 16x32 pixels: the 8-wave variant, exact tiles
+    (1, 128, 64, 1024, 88, 100, True),  # 8-wave variant, ragged H (half a tile) and W, two sources, 3 bodies
+    (1, 64, 0, 1024, 90, 97, False),    # 8-wave variant without a fused norm
 ]
 
 
@@ -146,6 +149,33 @@ def test_groupnorm_statistics_from_conv_epilogue(cuda, dtype):
         ops.HALO_MIN_WGS = 256
     cat = torch.cat([ya.float().cpu().permute(0, 3, 1, 2), yb.float().cpu().permute(0, 3, 1, 2)], 1)
     want = F.conv2d(F.silu(F.group_norm(cat, 32, gamma, beta, eps=1e-5)), wc, None, padding=1)
+    _close(got.permute(0, 3, 1, 2), want, dtype)
+    _close(got.float(), ref.float().cpu(), dtype, scale=float(want.abs().max()))
+
+
+def test_groupnorm_statistics_from_8wave_conv_epilogue(cuda):
+    """The 16x32-pixel (8-wave) halo variant writes its statistics on the same 8x32 partial grid as the 4-wave one
+    (two sub-tiles per workgroup, the second one absent on a ragged last tile row): a consumer conv fed by it must
+    agree with the statistics pass over the tensor."""
+    from rsvld_amd import ops
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(33)
+    B, H, W = 2, 88, 100
+    xa = _rt(torch.randn(B, 64, H, W, generator=g), dtype)
+    wa = _rt(torch.randn(512, 64, 3, 3, generator=g) / 24, dtype)      # 192 workgroups of 16x32 -> 8-wave kernel
+    wc = _rt(torch.randn(128, 512, 3, 3, generator=g) / 68, dtype)
+    gamma, beta = 1 + 0.1 * torch.randn(512, generator=g), 0.1 * torch.randn(512, generator=g)
+    ops.HALO_MIN_WGS = 0
+    try:
+        ya = ops.conv2d(_nhwc(xa, dtype, cuda), ops.pack_conv(wa, None, dtype, cuda), pad=1, stats=True)
+        assert hasattr(ya, "_gn_part")
+        norm = (gamma.to(cuda), beta.to(cuda), 32, 1e-5, True)
+        pcc = ops.pack_conv(wc, None, dtype, cuda)
+        got = ops.conv2d(ya, pcc, pad=1, norm=norm)            # statistics from the producer's epilogue
+        ref = ops.conv2d(ya.clone(), pcc, pad=1, norm=norm)    # statistics pass over the tensor
+    finally:
+        ops.HALO_MIN_WGS = 256
+    want = F.conv2d(F.silu(F.group_norm(ya.float().cpu().permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-5)), wc, None, padding=1)
     _close(got.permute(0, 3, 1, 2), want, dtype)
     _close(got.float(), ref.float().cpu(), dtype, scale=float(want.abs().max()))
 
