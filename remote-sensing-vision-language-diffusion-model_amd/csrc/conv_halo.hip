@@ -17,6 +17,7 @@
 #include "rsvld_common.h"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -361,6 +362,14 @@ constexpr int AB32_BYTES = 1024;        // one LDS-DMA wave-instruction: 512 B o
 __device__ __forceinline__ int p32_off(int py, int px, int slot) { return (py * PW + px) * 64 + ((slot ^ ((px >> 2) & 3)) << 4); }
 __device__ __forceinline__ int w32_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
+// compile-time loop: f(std::integral_constant<int, i>) for i = 0..N-1
+template <typename F, int... I> __device__ __forceinline__ void halo_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void halo_static_for(F&& f) {
+    halo_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int N> __device__ __forceinline__ void halo_wait_barrier() {
     // DMA pieces older than the N youngest vector-memory operations have landed, this wave's LDS writes are done
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -384,13 +393,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     constexpr int TAP_BYTES = BN * 64;               // [BN x 32 ch] weight slice of one tap
     constexpr int W_BYTES = 2 * TAP_BYTES;           // a step stages two taps
     constexpr int W_LOADS = BN / (16 * NW);          // LDS-DMA instructions per thread per tap
+    // weight stages: the 4-wave kernel has LDS for two (the slice of step s+1 is requested in step s and must land within
+    // it); the 8-wave kernel has room for three and requests two steps ahead -- the ablation builds charge most of the
+    // "weight DMA" cost to exactly that wait
+    constexpr int WST = NW == 8 ? 3 : 2, AHEAD = WST - 1;
     static_assert(PL == 5 || PL == 6, "wait_patch names PL register quads");
     static_assert(BN % (16 * NW) == 0, "whole wave-instructions per tap");
     typedef typename Mfma<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;                      // [2][PB]
-    char* wbuf = smem + 2 * PB;              // [2][W_BYTES]
-    char* abuf = wbuf + 2 * W_BYTES;         // [2][AB32_BYTES]
+    char* wbuf = smem + 2 * PB;              // [WST][W_BYTES]
+    char* abuf = wbuf + WST * W_BYTES;       // [2][AB32_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -439,11 +452,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[i]) : "v"(ptr) : "memory");
         }
     };
-    auto wait_patch = [&](u32x4 (&r)[PL]) {   // names every destination: no consumer is scheduled above it
+    // names every destination: no consumer is scheduled above it; the weight DMAs issued after the patch loads (the
+    // N youngest operations) may stay in flight
+    auto wait_patch = [&](u32x4 (&r)[PL], auto n_c) {
+        constexpr int N = decltype(n_c)::value;
         if constexpr (PL == 6)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[PL - 1]) : : "memory");
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[PL - 1]) : "n"(N) : "memory");
         else
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : : "memory");
+            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "n"(N) : "memory");
     };
     // normalise piece i and write it into patch buffer P; ab16 = (scale, shift) of this thread's 8 channels.  Branch-free.
     auto norm_write = [&](u32x4 v, int i, const float (&ab16)[16], char* P) {
@@ -517,7 +533,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
 
     // ---- prologue: chunk 0 is the one exposed load -> normalise -> write; chunk 1 is requested with it
     const int nb = p.nchunks;   // bodies = 64-channel pairs of 32-channel chunks
-    dma_w(0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) dma_w(0, a, a);   // steps 0 .. AHEAD-1 of body 0 (every body has 9 steps)
     dma_ab(0, 0);
     {
         u32x4 ra[PL];
@@ -549,30 +566,31 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     int s = 0;   // global step: weight stage parity
     auto body = [&](int b, auto next_c) {
         constexpr bool NEXT = decltype(next_c)::value;
-#pragma unroll
-        for (int st = 0; st < 9; ++st, ++s) {
-            if (!(HALO_ABL & 1)) {
-                if (st < 8) dma_w(b, st + 1, (s + 1) & 1);
-                else if (NEXT) dma_w(b + 1, 0, (s + 1) & 1);
+        halo_static_for<9>([&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;   // compile-time: taps, wait counts and piece indices depend on it
+            constexpr bool w_issue = (st + AHEAD < 9) || NEXT;   // the slice of step s + AHEAD exists
+            if constexpr (w_issue && !(HALO_ABL & 1)) {
+                if constexpr (st + AHEAD < 9) dma_w(b, st + AHEAD, (s + AHEAD) % WST);
+                else dma_w(b + 1, st + AHEAD - 9, (s + AHEAD) % WST);
             }
-            if (st == 4 && NEXT && !(HALO_ABL & 2)) {
+            if constexpr (st == 4 && NEXT && !(HALO_ABL & 2)) {
                 dma_ab(b + 1, (b + 1) & 1);
                 issue_patch(2 * b + 2, rp);
             }
-            if (st >= 1 && st <= 3 && !(HALO_ABL & 2)) {          // B of this body -> buffer 1
+            if constexpr (st >= 1 && st <= 3 && !(HALO_ABL & 2)) {          // B of this body -> buffer 1
                 float ab16[16];
                 lds_ab(abuf + (b & 1) * AB32_BYTES + 256 + c4 * 64, ab16);
                 norm_write(rp[2 * (st - 1)], 2 * (st - 1), ab16, patch + PB);
-                if (2 * (st - 1) + 1 < PL) norm_write(rp[2 * (st - 1) + 1 < PL ? 2 * (st - 1) + 1 : 0], 2 * (st - 1) + 1 < PL ? 2 * (st - 1) + 1 : 0, ab16, patch + PB);
+                if constexpr (2 * (st - 1) + 1 < PL) norm_write(rp[2 * (st - 1) + 1], 2 * (st - 1) + 1, ab16, patch + PB);
             }
-            if (st >= 6 && NEXT && !(HALO_ABL & 2)) {             // A' of the next body -> buffer 0
+            if constexpr (st >= 6 && NEXT && !(HALO_ABL & 2)) {             // A' of the next body -> buffer 0
                 float ab16[16];
                 lds_ab(abuf + ((b + 1) & 1) * AB32_BYTES + c4 * 64, ab16);
                 norm_write(rp[2 * (st - 6)], 2 * (st - 6), ab16, patch);
-                if (2 * (st - 6) + 1 < PL) norm_write(rp[2 * (st - 6) + 1 < PL ? 2 * (st - 6) + 1 : 0], 2 * (st - 6) + 1 < PL ? 2 * (st - 6) + 1 : 0, ab16, patch);
+                if constexpr (2 * (st - 6) + 1 < PL) norm_write(rp[2 * (st - 6) + 1], 2 * (st - 6) + 1, ab16, patch);
             }
-            if (st == 8 && NEXT && !(HALO_ABL & 2)) issue_patch(2 * b + 3, rp);
-            const char* w_st = wbuf + (s & 1) * W_BYTES;
+            if constexpr (st == 8 && NEXT && !(HALO_ABL & 2)) issue_patch(2 * b + 3, rp);
+            const char* w_st = wbuf + (s % WST) * W_BYTES;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int g = 2 * st + j;
@@ -596,15 +614,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
                         for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
                 }
             }
-            // end of step: the DMAs of this step (weights of the next step, (scale, shift) rows) must have landed; patch
-            // loads issued in this step (after those DMAs) stay in flight
-            if ((st == 4 || st == 8) && NEXT) {
-                halo_wait_barrier<PL>();
-            } else {
-                if ((st == 5 || st == 0)) wait_patch(rp);
-                halo_wait_barrier<0>();
-            }
-        }
+            // end of step: the weight slice of the NEXT step must have landed (with three stages it was requested a step
+            // ago: everything issued in this step may stay in flight); patch loads requested in this step always stay in
+            // flight, those requested in the previous step (st 5, st 0) are waited for here
+            constexpr int n_w = (w_issue && !(HALO_ABL & 1)) ? 2 * W_LOADS : 0;
+            constexpr int n_ab = (st == 4 && NEXT && NORM != 0 && !(HALO_ABL & 2)) ? 1 : 0;
+            constexpr int n_p = ((st == 4 || st == 8) && NEXT && !(HALO_ABL & 2)) ? PL : 0;
+            constexpr int keep = (AHEAD == 2 ? n_w + n_ab : 0) + n_p;
+            if constexpr (st == 5 || st == 0) wait_patch(rp, std::integral_constant<int, (AHEAD == 2 ? n_w : 0)>{});
+            halo_wait_barrier<keep>();
+            ++s;
+        });
     };
     for (int b = 0; b + 1 < nb; ++b) body(b, std::true_type{});
     body(nb - 1, std::false_type{});
@@ -615,7 +635,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
 template <typename T, int BN, int NW>
 int launch_halo32(HaloArgs a, hipStream_t s) {
     constexpr int THT = 2 * NW;
-    constexpr int stage = 2 * ((THT + 2) * PW * 64) + 2 * (2 * BN * 64) + 2 * AB32_BYTES;
+    constexpr int stage = 2 * ((THT + 2) * PW * 64) + (NW == 8 ? 3 : 2) * (2 * BN * 64) + 2 * AB32_BYTES;
     constexpr int epi = (BN > 64 ? 128 : 256) * (BN + 4) * 4;
     constexpr int red = (64 * NW / (BN / 8)) * BN * 2 * 4;
     constexpr int smem = stage > epi ? (stage > red ? stage : red) : (epi > red ? epi : red);
@@ -665,7 +685,8 @@ int dispatch_halo(const HaloArgs& a, hipStream_t s) {
     // 16x32-pixel tiles (one 8-wave workgroup per CU) once that grid still covers most of the chip
     static const char* nw_env = getenv("RSVLD_HALO_NW");   // A/B switch: 4 or 8
     const int64_t wg16 = (int64_t)a.tiles_x * ((a.H + 15) / 16) * a.B * ((a.Cout + 127) / 128);
-    const bool use8 = nw_env ? nw_env[0] == '8' : wg16 >= 192;
+    // measured (tools/bench_halo.py, one box): +3..13 % from 192 channels of K up, -3 % at 128 (longer pipeline fill)
+    const bool use8 = nw_env ? nw_env[0] == '8' : (wg16 >= 192 && a.Ctot >= 192);
     if (use8) return launch_halo32<T, 128, 8>(a, s);
     return launch_halo32<T, 128, 4>(a, s);
 }

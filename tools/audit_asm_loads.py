@@ -17,8 +17,15 @@ def regs(code):
     return out
 
 
+VM_PREFIXES = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic",
+               "scratch_load", "scratch_store", "flat_load", "flat_store")
+
+
 def audit(lines, name):
-    pending, lds_pending, bad, in_asm, n_loads = [], [], 0, False, 0
+    """Linear model of the vector-memory queue: every VM instruction is appended in program order; `s_waitcnt vmcnt(N)`
+    (inside or outside asm) retires all but the N youngest.  An asm load with a VGPR destination stays `pending` until
+    retired; touching a pending destination is a violation.  Asm LDS reads stay pending until an asm MFMA consumes them."""
+    vm, lds_pending, bad, in_asm, n_loads = [], [], 0, False, 0   # vm: list of (dest range or None)
     for ln, line in enumerate(lines, 1):
         t = line.strip()
         if t.startswith(';;#ASMSTART'):
@@ -27,21 +34,29 @@ def audit(lines, name):
         if t.startswith(';;#ASMEND'):
             in_asm = False
             continue
-        code = t.split(';')[0]
+        code = t.split(';')[0].strip()
         if not code or code.endswith(':') or code.startswith('.'):
             continue
-        if in_asm and code.startswith('global_load') and '_lds_' not in code:   # LDS-DMA has no VGPR destination
-            r = regs(code)
-            pending.append(r[0])
-            n_loads += 1
-            for a, b in r[1:]:   # address registers of this load must not be an in-flight destination
-                for lo, hi in pending[:-1]:
-                    if a <= hi and b >= lo:
-                        print(f"{name}:{ln}: address reads in-flight destination: {t}")
-                        bad += 1
+        if code.startswith(VM_PREFIXES):
+            if in_asm and code.startswith('global_load') and '_lds_' not in code:   # LDS-DMA has no VGPR destination
+                r = regs(code)
+                for a, b in r[1:]:   # address registers must not be an in-flight destination
+                    for d in vm:
+                        if d is not None and a <= d[1] and b >= d[0]:
+                            print(f"{name}:{ln}: address reads in-flight destination: {t}")
+                            bad += 1
+                vm.append(r[0])
+                n_loads += 1
+            else:
+                vm.append(None)
             continue
-        if in_asm and code.startswith('s_waitcnt') and 'vmcnt(0)' in code:
-            pending = []
+        m = re.search(r'vmcnt\((\d+)\)', code) if code.startswith('s_waitcnt') else None
+        if m:
+            keep = int(m.group(1))
+            vm = vm[len(vm) - keep:] if keep > 0 else []
+            if 'lgkmcnt' not in code and not in_asm:
+                continue
+        if code.startswith('s_waitcnt'):
             continue
         if in_asm and code.startswith('ds_read'):      # asm LDS read: pending until an asm MFMA consumes it
             lds_pending.append(regs(code)[0])
@@ -54,14 +69,13 @@ def audit(lines, name):
         if in_asm:
             continue
         for a, b in regs(code):
+            for d in vm:
+                if d is not None and a <= d[1] and b >= d[0]:
+                    print(f"{name}:{ln}: touches in-flight v[{d[0]}:{d[1]}]: {t}")
+                    bad += 1
             for lo, hi in lds_pending:
                 if a <= hi and b >= lo:
                     print(f"{name}:{ln}: touches in-flight LDS destination v[{lo}:{hi}]: {t}")
-                    bad += 1
-        for a, b in regs(code):
-            for lo, hi in pending:
-                if a <= hi and b >= lo:
-                    print(f"{name}:{ln}: touches in-flight v[{lo}:{hi}]: {t}")
                     bad += 1
     return n_loads, bad
 
