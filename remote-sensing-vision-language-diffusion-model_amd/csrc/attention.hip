@@ -322,8 +322,10 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     // destination) is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md §5.7).
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    bool abl_dma_on = true;   // ablation 4: the prologue fills BOTH buffers of K and V, the loop issues no DMA (operands stay
+                              // real data: zero-filled operands would raise the clock and overstate the saving)
     auto dma_one = [&](const char* base, uint32_t voff, uint32_t dst) {
-        if (A5B_ABL & 4) return;
+        if ((A5B_ABL & 4) && !abl_dma_on) return;
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
@@ -369,6 +371,13 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     if (nt > 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) dma_k(1, i);
+    }
+    if (A5B_ABL & 4) {
+        if (nt > 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dma_v(1, i);
+        }
+        abl_dma_on = false;
     }
 
     // ---- Q fragments (B operand: col = query row on the lane, k = d)

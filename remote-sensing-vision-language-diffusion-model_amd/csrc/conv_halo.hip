@@ -353,7 +353,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
 // one basic block and the scheduler can place the VALU between the MFMAs.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef HALO_ABL
-#define HALO_ABL 0   // diagnostic builds (timing only, results wrong): 1 no weight DMA in the loop, 2 no patch prefetch/normalise, 4 half the fragment reads
+#define HALO_ABL 0   // diagnostic builds (timing only, results wrong; every buffer is filled once so that operands stay real data):
+                     // 1 no weight DMA in the loop, 2 no patch prefetch/normalise in the loop, 4 half the fragment reads
 #endif
 constexpr int AB32_BYTES = 1024;        // one LDS-DMA wave-instruction: 512 B of (scale, shift) + 512 B duplicate
 
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     // ---- prologue: chunk 0 is the one exposed load -> normalise -> write; chunk 1 is requested with it
     const int nb = p.nchunks;   // bodies = 64-channel pairs of 32-channel chunks
 #pragma unroll
-    for (int a = 0; a < AHEAD; ++a) dma_w(0, a, a);   // steps 0 .. AHEAD-1 of body 0 (every body has 9 steps)
+    for (int a = 0; a < ((HALO_ABL & 1) ? WST : AHEAD); ++a) dma_w(0, a, a);   // steps 0 .. AHEAD-1 of body 0 (every body has 9 steps); ablation 1: every stage once, so that the operands stay real data
     dma_ab(0, 0);
     {
         u32x4 ra[PL];
@@ -560,6 +561,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
                          : "memory");
 #pragma unroll
         for (int i = 0; i < PL; ++i) norm_write(ra[i], i, ab16, patch);
+        if (HALO_ABL & 2) {   // ablation 2: buffer 1 is filled once (real data), the loop never refreshes the patch
+#pragma unroll
+            for (int i = 0; i < PL; ++i) norm_write(rp[i], i, ab16, patch + PB);
+        }
     }
     halo_wait_barrier<0>();
 

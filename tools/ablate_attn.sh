@@ -5,8 +5,8 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/remote-sensing-vision-language-diffusion-model_amd/csrc
 mkdir -p $ROOT/tools/ablate
-for N in 1 2 4 8 3 15; do
+for N in 1 4 5; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -DA5B_ABL=$N -I$SRC -I$ROOT/include -c $SRC/attention.hip -o /tmp/attn_abl$N.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ablate/librsvld_abl$N.so /tmp/attn_abl$N.o $SRC/build/conv_igemm.o $SRC/build/conv_halo.o $SRC/build/norm.o $SRC/build/elementwise.o $SRC/build/sampler.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ablate/librsvld_abl$N.so /tmp/attn_abl$N.o $SRC/build/conv_igemm.o $SRC/build/conv_halo.o $SRC/build/gemm.o $SRC/build/norm.o $SRC/build/elementwise.o $SRC/build/sampler.o
 done
 ls -la $ROOT/tools/ablate
