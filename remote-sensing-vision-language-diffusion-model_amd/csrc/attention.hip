@@ -885,6 +885,10 @@ namespace {
 //     other's MFMAs on every SIMD.
 // ---------------------------------------------------------------------------------------
 constexpr int A6B_TILE = 64 * 128;            // 64 keys x 64 d, 16-bit
+#ifndef A6B_ABL
+#define A6B_ABL 0   // diagnostic builds (tools/ablate_attn.sh; results WRONG, timing only): 1 no exp, 2 no in-loop DMA / barrier,
+                    // 8 no running max / row sum
+#endif
 constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
 
 template <typename T>
@@ -978,12 +982,21 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
             voff[dt] = 2 * A6B_TILE + row * 128 + (((4 * dt + 2 * g1 + (pp >> 1)) ^ (((row >> 1) & 1) << 2)) << 4) + ((pp & 1) << 3);
     }
 
+    // The Q fragments are consumed here, before the loop: hipcc then puts its own vmcnt wait for their loads here and
+    // not in front of the loop's first MFMA, where it would also wait for the tile requested at the top of every iteration.
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // tile 0 landed
 
+    if (A6B_ABL & 2) {   // both buffers hold real tiles; the loop then neither requests nor waits
+        if (nt > 1) dma_tile(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) dma_tile(t + 1);   // the other buffers were last read in tile t-1, before the barrier
+        if (!(A6B_ABL & 2) && t + 1 < nt) dma_tile(t + 1);   // the other buffers were last read in tile t-1, before the barrier
         const char* Ks = smem + buf * A6B_TILE;
         const int vb = buf * A6B_TILE;
 
@@ -1034,6 +1047,8 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
                 }
         }
         float mx = -INFINITY;
+        if (A6B_ABL & 8) mx = sacc[0][0];
+        else
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -1051,9 +1066,10 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][r], p.scale_log2e, nm));
+                float pv = __builtin_fmaf(sacc[kt][r], p.scale_log2e, nm);
+                if (!(A6B_ABL & 1)) pv = __builtin_amdgcn_exp2f(pv);
                 sacc[kt][r] = pv;
-                rs += pv;
+                if (!(A6B_ABL & 8) || r == 0) rs += pv;
             }
         l_run = l_run * alpha + rs;
         if (__any(need)) {
@@ -1079,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
                     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
             }
         asm volatile("s_nop 15\n\ts_nop 3\n\ts_waitcnt vmcnt(0)" : "+v"(oacc[0]), "+v"(oacc[1]) : : "memory");   // O readable by VALU; next tile landed
-        __syncthreads();   // everyone done with this tile's buffers
+        if (!(A6B_ABL & 2)) __syncthreads();   // everyone done with this tile's buffers
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);

@@ -81,6 +81,8 @@ HALO_CASES = [
     (2, 64, 0, 512, 96, 128, True),     # >= 192 workgroups of 16x32 pixels: the 8-wave variant, exact tiles
     (1, 128, 64, 1024, 88, 100, True),  # 8-wave variant, ragged H (half a tile) and W, two sources, 3 bodies
     (1, 64, 0, 1024, 90, 97, False),    # 8-wave variant without a fused norm
+    (2, 64, 64, 64, 17, 40, True),      # BN = 64, skip concat 128 -> 64 (Stage-1 level 0), 2 chunks
+    (1, 256, 0, 48, 9, 70, True),       # BN = 64, Cout 48 (clamped weight rows), 4 chunks, three tile columns
 ]
 
 

@@ -1,12 +1,15 @@
 #!/bin/bash
-# Diagnostic builds of the library with parts of attn_d512b_kernel removed (results are WRONG by construction; timing only).
+# Diagnostic builds of the library with parts of attn_d512b_kernel / attn_d64b_kernel removed (results are WRONG by construction; timing only).
 # usage: tools/ablate_attn.sh  -> tools/ablate/librsvld_abl<N>.so for N in the list below
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/remote-sensing-vision-language-diffusion-model_amd/csrc
 mkdir -p $ROOT/tools/ablate
-for N in 1 4 5; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -DA5B_ABL=$N -I$SRC -I$ROOT/include -c $SRC/attention.hip -o /tmp/attn_abl$N.o
+# MACRO=A5B_ABL (d = 512 kernel; list 1 4 5) or MACRO=A6B_ABL (d = 64 kernel; list 1 2 8 9 11)
+MACRO=${MACRO:-A5B_ABL}
+LIST=${LIST:-"1 4 5"}
+for N in $LIST; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -D$MACRO=$N -I$SRC -I$ROOT/include -c $SRC/attention.hip -o /tmp/attn_abl$N.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ablate/librsvld_abl$N.so /tmp/attn_abl$N.o $SRC/build/conv_igemm.o $SRC/build/conv_halo.o $SRC/build/gemm.o $SRC/build/norm.o $SRC/build/elementwise.o $SRC/build/sampler.o
 done
 ls -la $ROOT/tools/ablate
