@@ -67,3 +67,4 @@ def test_stage1_loader_contract(tmp_path):
     # a square input is only resized
     sq2 = resize_and_convert(Image.fromarray(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)), 2)
     assert sq2.size == (32, 32)
+

@@ -121,3 +121,47 @@ def test_oracle_pipeline(model, golden_dir, tag):
     assert len(trace) == len(want)
     for (a, b, h), w in zip(trace, want):
         assert bool(w[2]) == h and abs(a - w[0]) < 1e-4 and abs(b - w[1]) < 1e-3
+
+
+def test_create_sr_model_loads_both_checkpoints_in_reference_order(model, tmp_path, monkeypatch):
+    """models/util.py:73-108: yaml -> instantiate, then SR_CKPT (.safetensors) and SR_CKPT_Q (.ckpt holding
+    {'state_dict': ...}) with strict=False, the second overriding the first where both carry a key; default_setting is
+    returned on request.  The (30 s) network build is replaced by the fixture's instance; everything else is the function's own."""
+    import safetensors.torch
+    import yaml
+    import rsvld_amd.models.util as U
+    m, sd = model
+    keys = [k for k in sd if sd[k].numel() < 4096 and sd[k].dtype == torch.float32]
+    base_keys = [k for k in keys if k.startswith("model.diffusion_model.")][:6] + [k for k in keys if k.startswith("first_stage_model.")][:3]
+    adapter_keys = [k for k in keys if k.startswith("model.control_model.")][:6]
+    shared = base_keys[0]
+    base = {k: (sd[k] + 0.5).contiguous() for k in base_keys}
+    adapter = {k: (sd[k] - 0.25).contiguous() for k in adapter_keys + [shared]}
+    safetensors.torch.save_file(base, str(tmp_path / "base.safetensors"))
+    torch.save({"state_dict": adapter}, str(tmp_path / "adapter.ckpt"))
+    assert set(U.load_state_dict(str(tmp_path / "adapter.ckpt"))) == set(adapter)
+    assert set(U.load_state_dict(str(tmp_path / "base.safetensors"))) == set(base)
+    cfg = yaml.safe_load(open(S.YAML))
+    cfg["SR_CKPT"], cfg["SR_CKPT_Q"] = str(tmp_path / "base.safetensors"), str(tmp_path / "adapter.ckpt")
+    with open(tmp_path / "m.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    seen = {}
+
+    def fake_instantiate(c):
+        seen["target"] = c["target"]
+        return m
+    monkeypatch.setattr(U, "instantiate_from_config", fake_instantiate)
+    try:
+        got, default_setting = U.create_SR_model(str(tmp_path / "m.yaml"), load_default_setting=True)
+        assert got is m and seen["target"] == "rsvld_amd.models.SR_model.SR_backbone"
+        now = m.state_dict()
+        for k in sd:
+            want = sd[k] - 0.25 if k in adapter else (sd[k] + 0.5 if k in base else sd[k])
+            assert torch.equal(now[k], want), k
+        assert default_setting["s_cfg_Quality"] == 7.5
+        cfg["SR_CKPT"] = str(tmp_path / "missing.safetensors")     # an absent file is skipped (random-init runs, DESIGN.md)
+        with open(tmp_path / "m2.yaml", "w") as f:
+            yaml.safe_dump(cfg, f)
+        assert U.create_SR_model(str(tmp_path / "m2.yaml")) is m
+    finally:
+        m.load_state_dict(sd)
