@@ -219,6 +219,12 @@ int rsvld_axpy_f32(const float* x, const float* y, float* out, int64_t n, float 
  * (x_hat - dn)/sigma_hat * dt.   Replaces sampling.py:614-620. */
 int rsvld_euler_step(const float* x_hat, const float* denoised, const float* x_center, float* x_out,
                      int64_t n, float restore_w, float sigma_hat, float dt, void* stream);
+/* Latent-tile blending of TiledRestoreEDMSampler: fp32 NCHW acc / cnt [B,C,H,W]; tile [B,C,th,tw] is the sampler step's
+ * result for the window (y0, x0); weights [th,tw] the Gaussian tile mask.  acc[window] += tile * weights,
+ * cnt[window] += weights (sampling.py:733-734); finish: out = acc / cnt (:735). */
+int rsvld_tile_blend_accumulate(float* acc, float* cnt, const float* tile, const float* weights,
+                                int B, int C, int H, int W, int y0, int x0, int th, int tw, void* stream);
+int rsvld_tile_blend_finish(const float* acc, const float* cnt, float* out, int64_t n, void* stream);
 /* First-block-cache similarity (models/modules/DFBCache.py:98-112): out[row] = (sum|a-b|, sum|a|) per
  * row of two 16-bit [rows, n_per_row] tensors; fp32 partials, fp64 merge, deterministic. */
 int64_t rsvld_absdiff_ws_bytes(int rows, int64_t n_per_row);

@@ -292,6 +292,62 @@ def restore_edm_step(sd, table, cache, x, i, sigmas, c, uc, x_center, opt, thres
     return x + dd * (nxt - sigma_hat)[:, None, None, None], threshold
 
 
+# ---- latent-tile sampling (sampling.py:697-757, 830-863).  The reference's TiledRestoreEDMSampler.__call__ cannot run as
+# shipped (its tile loop multiplies the (x, threshold) tuple that sampler_step now returns, :719-733, and sampler_step's
+# default threshold 0.1 enters the feature cache without a cache context): this restatement follows the source line by
+# line with the one evident repair -- every tile takes an UN-cached step and the tensor is blended.  PARITY UNPINNED for
+# the loop (no reference output exists); sliding_windows is pinned (tests/golden/tiled_sampler_windows.json).
+def sliding_windows(h, w, tile_size, tile_stride):  # :850-863
+    hi_list = list(range(0, h - tile_size + 1, tile_stride))
+    if (h - tile_size) % tile_stride != 0:
+        hi_list.append(h - tile_size)
+    wi_list = list(range(0, w - tile_size + 1, tile_stride))
+    if (w - tile_size) % tile_stride != 0:
+        wi_list.append(w - tile_size)
+    return [(hi, hi + tile_size, wi, wi + tile_size) for hi in hi_list for wi in wi_list]
+
+
+def gaussian_weights(tile_width, tile_height):  # :830-847 -> float64 [tile_height, tile_width] (the reference tiles it to [nb,4,h,w])
+    import math
+    var = 0.01
+    midpoint = (tile_width - 1) / 2
+    x_probs = [math.exp(-(x - midpoint) * (x - midpoint) / (tile_width * tile_width) / (2 * var)) / math.sqrt(2 * math.pi * var)
+               for x in range(tile_width)]
+    midpoint = tile_height / 2          # sic: no "- 1" for the rows
+    y_probs = [math.exp(-(y - midpoint) * (y - midpoint) / (tile_height * tile_height) / (2 * var)) / math.sqrt(2 * math.pi * var)
+               for y in range(tile_height)]
+    return torch.tensor(y_probs, dtype=torch.float64)[:, None] * torch.tensor(x_probs, dtype=torch.float64)[None, :]
+
+
+def tiled_restore_edm(sd, table, x, sigmas, c, uc, x_center, opt, randn, tile_size, tile_stride):
+    """:704-757.  x: the initial noise (scaled here by sqrt(1 + sigma_0^2), :44-55); opt as restore_edm_step."""
+    B, _, h, w = x.shape
+    tiles = sliding_windows(h, w, tile_size, tile_stride)
+    tw = gaussian_weights(tile_size, tile_size)[None, None].repeat(B, 4, 1, 1)
+    lq = c["control"]
+    x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    for i in range(len(sigmas) - 1):
+        gamma = min(opt["s_churn"] / (len(sigmas) - 1), 2 ** 0.5 - 1)
+        x_next, count = torch.zeros_like(x), torch.zeros_like(x)
+        eps_noise = randn(x.shape)
+        sigma, nxt = torch.ones(B) * sigmas[i], torch.ones(B) * sigmas[i + 1]
+        sigma_hat = sigma * (gamma + 1.0)
+        for hi, he, wi, we in tiles:
+            xt = x[:, :, hi:he, wi:we]
+            cj, ucj = dict(c, control=lq[:, :, hi:he, wi:we]), dict(uc, control=lq[:, :, hi:he, wi:we])
+            if gamma > 0:
+                xt = xt + eps_noise[:, :, hi:he, wi:we] * opt["s_noise"] * ((sigma_hat ** 2 - sigma ** 2)[:, None, None, None]) ** 0.5
+            d, _ = restore_edm_denoise(sd, table, None, xt, sigma_hat, cj, ucj, opt["scale"], opt["scale_min"], opt["control_scale"], 0.0)
+            if nxt[0] > 0.05 and opt["restore_cfg"] > 0:
+                d = d - (d - x_center[:, :, hi:he, wi:we]) * ((sigma.view(-1, 1, 1, 1) / 14.6146) ** opt["restore_cfg"])
+            xo = xt + (xt - d) / sigma_hat[:, None, None, None] * (nxt - sigma_hat)[:, None, None, None]
+            x_next[:, :, hi:he, wi:we] += xo * tw          # fp32 += float64 product, as in the reference (:733)
+            count[:, :, hi:he, wi:we] += tw
+        x_next /= count
+        x = x_next
+    return x
+
+
 # ------------------------------------------------------------------------------ VAE (model.py)
 def vae_resblock(sd, p, x):  # model.py:91-148, temb = None
     h = conv(sd, p + ".conv1", F.silu(gn(sd, p + ".norm1", x, 1e-6)), padding=1)

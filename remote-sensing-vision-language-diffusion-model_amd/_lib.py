@@ -63,6 +63,8 @@ SIGNATURES = {
     "rsvld_lerp_f32": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
     "rsvld_axpy_f32": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
     "rsvld_euler_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _vp]),
+    "rsvld_tile_blend_accumulate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsvld_tile_blend_finish": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "rsvld_absdiff_ws_bytes": (_i64, [_i, _i64]),
     "rsvld_absdiff_sums": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
     "rsvld_gaussian_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),

@@ -217,6 +217,44 @@ extern "C" int rsvld_euler_step(const float* x_hat, const float* denoised, const
     return rsvld_check_launch();
 }
 
+// ---- latent-tile blending of TiledRestoreEDMSampler (sampling.py:733-736): acc[tile window] += tile * w, cnt += w; out = acc / cnt
+__global__ __launch_bounds__(256) void tile_blend_accumulate_kernel(float* __restrict__ acc, float* __restrict__ cnt,
+                                                                    const float* __restrict__ tile, const float* __restrict__ w,
+                                                                    int planes, int H, int W, int y0, int x0, int th, int tw) {
+    const int64_t n = (int64_t)planes * th * tw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % tw);
+        const int64_t r = i / tw;
+        const int y = (int)(r % th);
+        const int64_t pl = r / th;
+        const float wv = w[y * tw + x];
+        const int64_t o = (pl * H + y0 + y) * W + x0 + x;
+        acc[o] = fmaf(tile[i], wv, acc[o]);
+        cnt[o] += wv;
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_blend_finish_kernel(const float* __restrict__ acc, const float* __restrict__ cnt,
+                                                                float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = acc[i] / cnt[i];
+}
+
+extern "C" int rsvld_tile_blend_accumulate(float* acc, float* cnt, const float* tile, const float* weights, int B, int C, int H,
+                                           int W, int y0, int x0, int th, int tw, void* stream) {
+    if (!acc || !cnt || !tile || !weights || B <= 0 || C <= 0 || th <= 0 || tw <= 0) return RSVLD_EINVAL;
+    if (y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W) return RSVLD_EINVAL;   // the window must lie inside the latent
+    const int64_t n = (int64_t)B * C * th * tw;
+    hipLaunchKernelGGL(tile_blend_accumulate_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, acc, cnt, tile, weights,
+                       B * C, H, W, y0, x0, th, tw);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_tile_blend_finish(const float* acc, const float* cnt, float* out, int64_t n, void* stream) {
+    if (!acc || !cnt || !out || n <= 0) return RSVLD_EINVAL;
+    hipLaunchKernelGGL(tile_blend_finish_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, acc, cnt, out, n);
+    return rsvld_check_launch();
+}
+
 extern "C" int64_t rsvld_absdiff_ws_bytes(int rows, int64_t n_per_row) {
     if (rows <= 0 || n_per_row <= 0) return 0;
     return (int64_t)rows * 256 * 2 * sizeof(float);

@@ -454,6 +454,26 @@ def euler_step(x_hat, denoised, x_center, restore_w, sigma_hat, dt):
     return out
 
 
+def tile_blend_accumulate(acc, cnt, tile, weights, y0, x0):
+    """In place: ``acc[:, :, y0:y0+th, x0:x0+tw] += tile * weights``, ``cnt[...] += weights`` (fp32 NCHW; sampling.py:733-734)."""
+    _need_gpu(acc, cnt, tile, weights)
+    B, Cc, H, W = acc.shape
+    th, tw = tile.shape[-2:]
+    if (tuple(cnt.shape) != tuple(acc.shape) or tuple(tile.shape[:2]) != (B, Cc) or tuple(weights.shape) != (th, tw)
+            or any(t.dtype != torch.float32 or not t.is_contiguous() for t in (acc, cnt, tile, weights))):
+        raise L.RsvldError("tile_blend_accumulate: fp32 contiguous acc/cnt [B,C,H,W], tile [B,C,th,tw], weights [th,tw]")
+    L.check(L.load().rsvld_tile_blend_accumulate(_ptr(acc), _ptr(cnt), _ptr(tile), _ptr(weights), B, Cc, H, W, int(y0), int(x0),
+                                                 th, tw, _stream()), "rsvld_tile_blend_accumulate")
+
+
+def tile_blend_finish(acc, cnt):
+    """-> ``acc / cnt`` (sampling.py:735)."""
+    _need_gpu(acc, cnt)
+    out = torch.empty_like(acc)
+    L.check(L.load().rsvld_tile_blend_finish(_ptr(acc), _ptr(cnt), _ptr(out), acc.numel(), _stream()), "rsvld_tile_blend_finish")
+    return out
+
+
 def absdiff_sums(a, b):
     """Per batch row: fp32 ``[rows, 2]`` = (sum|a-b|, sum|a|)  (DFBCache.py:98-112)."""
     _need_gpu(a, b)

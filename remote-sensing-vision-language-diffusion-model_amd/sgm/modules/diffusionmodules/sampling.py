@@ -14,6 +14,7 @@ similarity is one deterministic reduction kernel + one device->host copy per ste
 """
 from typing import Dict, Union
 
+import numpy as np
 import torch
 
 from .... import ops
@@ -114,3 +115,75 @@ class RestoreEDMSampler(BaseDiffusionSampler):
             x, th = self.step(x, i, s_in, sigmas, denoiser, cond, uc, x_center, control_scale,
                               use_linear_control_scale, control_scale_start, th)
         return x, th
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Latent-tile sampling (sampling.py:697-757, 830-863).  NOTE on the reference: as shipped, TiledRestoreEDMSampler.__call__
+# cannot run -- RestoreEDMSampler.sampler_step was changed to return ``(x, threshold)`` and to default ``threshold=0.1``
+# (the feature cache, which needs a cache context), while the tile loop still multiplies its return value by the tile
+# mask (:733) and opens no cache context; ``gaussian_weights`` hard-codes ``device='cuda'``.  Nothing in the reference
+# selects the class.  It is provided here with the evident intent: every tile takes one un-cached step (threshold 0) and
+# the tensor part of the result is blended.  ``_sliding_windows`` is pinned to the reference's function
+# (tests/golden/tiled_sampler_windows.json); the mask and the loop follow the source line by line (oracle/s2_oracle.py).
+def gaussian_weights(tile_width, tile_height, nbatches, device=None):
+    """sampling.py:830-847 -> float64 ``[nbatches, 4, tile_height, tile_width]``.  var = 0.01; note the reference's
+    asymmetry: the x midpoint is (w-1)/2, the y midpoint h/2."""
+    var = 0.01
+    mx, my = (tile_width - 1) / 2, tile_height / 2
+    xs = np.arange(tile_width, dtype=np.float64)
+    ys = np.arange(tile_height, dtype=np.float64)
+    x_probs = np.exp(-(xs - mx) * (xs - mx) / (tile_width * tile_width) / (2 * var)) / np.sqrt(2 * np.pi * var)
+    y_probs = np.exp(-(ys - my) * (ys - my) / (tile_height * tile_height) / (2 * var)) / np.sqrt(2 * np.pi * var)
+    w = torch.tensor(np.outer(y_probs, x_probs), device=device)
+    return torch.tile(w, (nbatches, 4, 1, 1))
+
+
+def _sliding_windows(h, w, tile_size, tile_stride):
+    """sampling.py:850-863: (hi, hi_end, wi, wi_end) row-major; a last window flush with the border when the stride does
+    not land on it."""
+    hi_list = list(range(0, h - tile_size + 1, tile_stride))
+    if (h - tile_size) % tile_stride != 0:
+        hi_list.append(h - tile_size)
+    wi_list = list(range(0, w - tile_size + 1, tile_stride))
+    if (w - tile_size) % tile_stride != 0:
+        wi_list.append(w - tile_size)
+    return [(hi, hi + tile_size, wi, wi + tile_size) for hi in hi_list for wi in wi_list]
+
+
+class TiledRestoreEDMSampler(RestoreEDMSampler):
+    def __init__(self, tile_size=128, tile_stride=64, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tile_size, self.tile_stride = tile_size, tile_stride
+        self.tile_weights = gaussian_weights(tile_size, tile_size, 1)   # float64, host; one fp32 [th, tw] plane goes to the device
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, x_center=None, control_scale=1.0,
+                 use_linear_control_scale=False, control_scale_start=0.0):
+        use_local_prompt = isinstance(cond, list)
+        b, _, h, w = x.shape
+        if h < self.tile_size or w < self.tile_size:
+            raise ValueError(f"latent {h}x{w} is smaller than the tile ({self.tile_size})")
+        tiles = _sliding_windows(h, w, self.tile_size, self.tile_stride)
+        if use_local_prompt and len(cond) != len(tiles):
+            raise ValueError("Number of local prompts should be equal to number of tiles")
+        lq = (cond[0] if use_local_prompt else cond)["control"]
+        weights = self.tile_weights[0, 0].to(device=x.device, dtype=torch.float32).contiguous()
+        x, s_in, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        s_in = s_in.cpu()
+        for i in range(num_sigmas - 1):
+            gamma = self._gamma(sigmas, i)
+            x_next, count = torch.zeros_like(x), torch.zeros_like(x)
+            eps_noise = self.noise_fn(x)                      # one draw per step over the whole latent, sliced per tile (:723)
+            for j, (hi, hi_end, wi, wi_end) in enumerate(tiles):
+                sl = (slice(None), slice(None), slice(hi, hi_end), slice(wi, wi_end))
+                ctl = lq[sl].contiguous()
+                c_j = dict(cond[j] if use_local_prompt else cond, control=ctl)
+                uc_j = dict(uc, control=ctl)
+                x_tile, _ = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x[sl].contiguous(), c_j, uc_j,
+                                              gamma, None if x_center is None else x_center[sl].contiguous(),
+                                              eps_noise=eps_noise[sl].contiguous(), control_scale=control_scale,
+                                              use_linear_control_scale=use_linear_control_scale,
+                                              control_scale_start=control_scale_start, threshold=0.0)
+                ops.tile_blend_accumulate(x_next, count, x_tile.contiguous(), weights, hi, wi)
+            x = ops.tile_blend_finish(x_next, count)
+        return x
+

@@ -204,3 +204,55 @@ def test_batched_sampling_is_per_image(model, cuda):
     d = float((both - one).abs().max())
     print("batch-of-2 vs 2 x batch-of-1: max|d| =", d)
     assert d < 2e-2
+
+
+def test_tile_blend_kernels(cuda):
+    from rsvld_amd import ops
+    from rsvld_amd._lib import RsvldError
+    g = torch.Generator().manual_seed(5)
+    acc, cnt = torch.randn(2, 4, 24, 40, generator=g), torch.rand(2, 4, 24, 40, generator=g) + 0.5
+    tile, w = torch.randn(2, 4, 16, 16, generator=g), torch.rand(16, 16, generator=g)
+    want_a, want_c = acc.clone(), cnt.clone()
+    want_a[:, :, 8:24, 17:33] += tile * w
+    want_c[:, :, 8:24, 17:33] += w
+    a, c = acc.to(cuda), cnt.to(cuda)
+    ops.tile_blend_accumulate(a, c, tile.to(cuda), w.to(cuda), 8, 17)
+    assert torch.allclose(a.cpu(), want_a, atol=1e-6) and torch.allclose(c.cpu(), want_c, atol=1e-6)
+    assert torch.allclose(ops.tile_blend_finish(a, c).cpu(), want_a / want_c, rtol=1e-6, atol=1e-6)
+    with pytest.raises(RsvldError):
+        ops.tile_blend_accumulate(a, c, tile.to(cuda), w.to(cuda), 9, 17)      # window past the bottom edge
+
+
+def test_tiled_restore_edm_sampler_vs_oracle(model, cuda):
+    """TiledRestoreEDMSampler (latent 24x24, tile 16, stride 8 -> 4 overlapping tiles, 2 steps, churn + restore pull +
+    linear CFG) against the CPU restatement with the same draws.  2e-2 x range: fp16 UNet/ControlNet vs fp32 oracle."""
+    from oracle import s2_oracle as O
+    from rsvld_amd.sgm.util import instantiate_from_config
+    m, sd = model
+    table = O.legacy_ddpm_sigmas(1000, append_zero=False, flip=True)
+    cd, ucd = S.cond_dicts()
+    zc, x0, xc = S.rnd((1, 4, 24, 24), 301, 0.5), S.rnd((1, 4, 24, 24), 302), S.rnd((1, 4, 24, 24), 303, 0.5)
+    sigmas = O.legacy_ddpm_sigmas(2)
+    opt = dict(s_churn=5, s_noise=1.003, restore_cfg=2.0, scale=4.0, scale_min=7.5, control_scale=1.0)
+    draws = [S.rnd((1, 4, 24, 24), 310 + i) for i in range(2)]
+    it = iter(draws)
+    want = O.tiled_restore_edm(sd, table, x0, sigmas, {**cd, "control": zc}, {**ucd, "control": zc}, xc, opt,
+                               lambda shape: next(it), 16, 8)
+    cfg = {"target": "rsvld_amd.sgm.modules.diffusionmodules.sampling.TiledRestoreEDMSampler",
+           "params": {"tile_size": 16, "tile_stride": 8, "num_steps": 2, "restore_cfg": 2.0, "s_churn": 5, "s_noise": 1.003,
+                      "discretization_config": {"target": "rsvld_amd.sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+                      "guider_config": {"target": "rsvld_amd.sgm.modules.diffusionmodules.guiders.LinearCFG",
+                                        "params": {"scale": 4.0, "scale_min": 7.5}}}}
+    sampler = instantiate_from_config(cfg)
+    it2 = iter(draws)
+    sampler.noise_fn = lambda t: next(it2).to(t.device)
+    dev = lambda d: {k: v.to(cuda) for k, v in d.items()}
+
+    def denoiser(inp, sigma, c, *a, **kw):
+        return m.denoiser(m.model, inp, sigma, c, *a, **kw)
+
+    got = sampler(denoiser, x0.to(cuda), dev({**cd, "control": zc}), uc=dev({**ucd, "control": zc}), x_center=xc.to(cuda))
+    assert got.shape == (1, 4, 24, 24)
+    _cmp(got, want, 2e-2, "tiled sampler, 2 steps x 4 tiles")
+    with pytest.raises(ValueError):
+        sampler(denoiser, x0[:, :, :8, :8].to(cuda), dev({**cd, "control": zc[:, :, :8, :8]}), uc=dev({**ucd, "control": zc[:, :, :8, :8]}))

@@ -165,3 +165,49 @@ def test_create_sr_model_loads_both_checkpoints_in_reference_order(model, tmp_pa
         assert U.create_SR_model(str(tmp_path / "m2.yaml")) is m
     finally:
         m.load_state_dict(sd)
+
+
+def test_tiled_sampler_windows_and_weights(golden_dir):
+    """sampling.py:830-863: window lists against the reference's own `_sliding_windows` (golden), the Gaussian tile mask
+    of the product against the line-by-line restatement (the reference builds it on device='cuda': not runnable here)."""
+    from rsvld_amd.sgm.modules.diffusionmodules.sampling import _sliding_windows, gaussian_weights
+    for case in json.load(open(os.path.join(golden_dir, "tiled_sampler_windows.json"))):
+        want = [tuple(t) for t in case["windows"]]
+        assert O.sliding_windows(*case["args"]) == want
+        assert _sliding_windows(*case["args"]) == want
+        h, w, ts, _ = case["args"]
+        cover = torch.zeros(h, w)
+        for hi, he, wi, we in want:
+            assert he - hi == ts and we - wi == ts and 0 <= hi and he <= h and 0 <= wi and we <= w
+            cover[hi:he, wi:we] += 1
+        assert float(cover.min()) >= 1          # every latent pixel is inside some tile
+    for tw, th in ((16, 16), (128, 128), (9, 16)):
+        got = gaussian_weights(tw, th, 2)
+        want = O.gaussian_weights(tw, th)
+        assert got.dtype == torch.float64 and got.shape == (2, 4, th, tw)
+        assert torch.allclose(got[1, 3], want, rtol=1e-14, atol=0)
+        assert torch.equal(got[0, 0], got[1, 2])
+        assert torch.allclose(want[:, 0], want[:, -1], rtol=1e-14)        # columns: symmetric about (w-1)/2
+        assert torch.allclose(want[1], want[-1], rtol=1e-14)              # rows: about h/2 (the reference's asymmetry)
+        assert float(want[0, tw // 2]) < float(want[-1, tw // 2])
+
+
+def test_tiled_sampler_oracle_single_tile_equals_untiled(model):
+    """A latent of exactly one tile: the blend is (x*w)/w, so the tiled loop reduces to the un-cached RestoreEDMSampler
+    step with the same draws and a FIXED x_center (the tiled sampler never updates it, sampling.py:714,726)."""
+    _, sd = model
+    table = O.legacy_ddpm_sigmas(1000, append_zero=False, flip=True)
+    cd, ucd = S.cond_dicts()
+    zc, x0, xc = S.rnd((1, 4, 16, 16), 201, 0.5), S.rnd((1, 4, 16, 16), 202), S.rnd((1, 4, 16, 16), 203, 0.5)
+    c, uc = {**cd, "control": zc}, {**ucd, "control": zc}
+    sigmas = O.legacy_ddpm_sigmas(2)
+    opt = dict(s_churn=5, s_noise=1.003, restore_cfg=2.0, scale=4.0, scale_min=7.5, control_scale=1.0)
+    draws = [S.rnd((1, 4, 16, 16), 210 + i) for i in range(2)]
+    it = iter(draws)
+    tiled = O.tiled_restore_edm(sd, table, x0, sigmas, c, uc, xc, opt, lambda shape: next(it), 16, 8)
+    it = iter(draws)
+    x = x0 * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+    for i in range(len(sigmas) - 1):
+        x, _ = O.restore_edm_step(sd, table, None, x, i, sigmas, c, uc, xc, opt, 0.0, lambda shape: next(it))
+    assert torch.isfinite(tiled).all()
+    assert _d(tiled, x) < 1e-5 * max(1.0, float(x.abs().max()))
