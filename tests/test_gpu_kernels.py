@@ -371,7 +371,7 @@ def test_attention_d512(cuda, dtype, shape):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 10, 256, 256), (1, 20, 64, 77), (2, 5, 100, 333), (1, 10, 4096, 4096), (3, 2, 1, 1)])
 def test_attention_d64_multihead(cuda, dtype, shape):
-    """SDXL self / cross attention and ZeroCrossAttn: heads x d=64, keys 77 (text), ragged, 4096 tokens (QT=2 path)."""
+    """SDXL self / cross attention and ZeroCrossAttn: heads x d=64, keys 77 (text), ragged, 4096 tokens."""
     from rsvld_amd import ops
     B, heads, Nq, Nk = shape
     D = 64

@@ -1,5 +1,5 @@
 """Times rsvld_attention on the Stage-1 (d = 512, one head) and Stage-2 (d = 64, multi-head) shapes.
-RSVLD_ATTN512_V1=1 selects the first-generation d = 512 kernel for A/B runs."""
+RSVLD_LIB=<another build of librsvld_hip.so> selects a different library for A/B runs (ONLY512 / ONLY64 filter the list)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +14,7 @@ if os.environ.get("ONLY512"):
     CASES = [c for c in CASES if c[3] == 512]
 if os.environ.get("ONLY64"):
     CASES = [c for c in CASES if c[3] == 64]
-print("d512 kernel:", "v1" if os.environ.get("RSVLD_ATTN512_V1") else "v2", " d64 query tiles per wave:", os.environ.get("RSVLD_ATTN64_QT", "auto"))
+print("library:", os.environ.get("RSVLD_LIB", "in-tree build"))
 for (B, heads, N, D) in CASES:
     qkv = torch.randn(B, N, 3 * heads * D, device=dev, dtype=torch.float16)
     q, k, v = qkv[..., :heads * D], qkv[..., heads * D:2 * heads * D], qkv[..., 2 * heads * D:]
