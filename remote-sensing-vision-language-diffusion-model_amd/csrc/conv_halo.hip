@@ -685,8 +685,6 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
 template <typename T>
 int dispatch_halo(const HaloArgs& a, hipStream_t s) {
     if (a.Cout <= 64) return launch_halo<T, 64, 4, 2>(a, s);
-    static const bool old128 = getenv("RSVLD_HALO_OLD128") != nullptr;   // A/B switch: the single-buffered 64-channel kernel
-    if (old128) return launch_halo<T, 128, 2, 1>(a, s);
     // 16x32-pixel tiles (one 8-wave workgroup per CU) once that grid still covers most of the chip
     static const char* nw_env = getenv("RSVLD_HALO_NW");   // A/B switch: 4 or 8
     const int64_t wg16 = (int64_t)a.tiles_x * ((a.H + 15) / 16) * a.B * ((a.Cout + 127) / 128);

@@ -1,6 +1,6 @@
 """Times the 3x3 halo convolution on the Stage-1 (BASELINE configs[1]) layer shapes, with and without the fused
-GroupNorm+SiLU prologue.  RSVLD_HALO_OLD128=1 selects the single-buffered 64-channel kernel for A/B runs; ONLY64=1
-restricts the list to the Cout = 64 layers (always the single-buffered kernel)."""
+GroupNorm+SiLU prologue.  RSVLD_LIB=<another build of librsvld_hip.so> selects a different library for A/B runs; ONLY64=1
+restricts the list to the Cout = 64 layers (the single-buffered 64-channel kernel)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,7 +17,7 @@ SHAPES = [  # B, H, W, Cin, Cin2, Cout
 if os.environ.get("ONLY64"):
     SHAPES = [s for s in SHAPES if s[5] <= 64] + [(4, 512, 512, 64, 64, 64), (1, 2048, 2048, 64, 0, 64)]
 reps = int(os.environ.get("REPS", 20))
-print("kernel:", "old64" if os.environ.get("RSVLD_HALO_OLD128") else "halo32")
+print("library:", os.environ.get("RSVLD_LIB", "in-tree build"))
 for (B, H, W, C1, C2, Co) in SHAPES:
     x = torch.randn(B, H, W, C1, device=dev, dtype=torch.float16)
     x2 = torch.randn(B, H, W, C2, device=dev, dtype=torch.float16) if C2 else None
