@@ -32,5 +32,5 @@ for k, f, e0, e1 in recs:
     a = agg.setdefault(k, [0.0, 0.0, 0]); a[0] += e0.elapsed_time(e1); a[1] += f; a[2] += 1
 tot = sum(a[0] for a in agg.values())
 print(f"conv/linear total: {tot:.1f} ms over {steps} steps")
-for k, (ms, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+for k, (ms, f, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("TOP", 40))]:
     print(f"{ms:9.2f} ms  n={n:4d}  {f/ms/1e9:7.1f} TF/s  {k}")
