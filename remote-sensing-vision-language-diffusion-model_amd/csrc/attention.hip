@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const v8*)(Ks + kt * 4096 + koff[ks]);
         f32x16 sacc[2];
+        asm volatile("s_setprio 1");   // the wave that feeds the matrix pipe issues ahead of its SIMD's softmax waves (+0.6 %)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             if constexpr (__is_same(T, f16)) {
@@ -576,6 +577,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][3]), "v"(qf[3]));
             }
         }
+        asm volatile("s_setprio 0");
         // V fragments of this tile: in flight behind the softmax.  A operand (row = d, k = key in P's register order):
         // elements 0..3 = keys 16 s4 + 4 lh + 0..3, elements 4..7 = keys 16 s4 + 8 + 4 lh + 0..3
         v8 vf[2][4];
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
             for (int j = 0; j < 8; ++j) pf[s4][j] = (T)sacc[s4 >> 1][8 * (s4 & 1) + j];
 
         // ---- O^T[d][q] += V^T P^T, VGPR form
+        asm volatile("s_setprio 1");
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -649,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
                 else
                     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
             }
+        asm volatile("s_setprio 0");
         asm volatile("s_nop 15\n\ts_nop 3\n\ts_waitcnt vmcnt(0)" : "+v"(oacc[0]), "+v"(oacc[1]) : : "memory");   // O readable by VALU; next tile landed
         if (!(A6B_ABL & 2)) __syncthreads();   // everyone done with this tile's buffers
     }
