@@ -436,8 +436,8 @@ namespace {
 //   * exp2(scale * s - m) is ONE fma + exp2 per element (the max is taken on raw scores, scale > 0);
 //   * K and V tiles are filled by LDS-DMA (asm, one scalar base per tensor per tile, no staging registers), V is
 //     read through ds_read_b64_tr_b16, so no transpose pass exists;
-//   * 4 waves x 32 query rows, ~170 registers -> two workgroups per CU: one wave's softmax runs beside the
-//     other's MFMAs on every SIMD.
+//   * 4 waves x 32 query rows, 128 registers -> four workgroups per CU: the other waves' softmax runs beside one
+//     wave's MFMAs on every SIMD.
 // ---------------------------------------------------------------------------------------
 constexpr int A6B_TILE = 64 * 128;            // 64 keys x 64 d, 16-bit
 #ifndef A6B_ABL
@@ -446,8 +446,16 @@ constexpr int A6B_TILE = 64 * 128;            // 64 keys x 64 d, 16-bit
 #endif
 constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
 
+// A6B_OCC4 = 1 (default): 128 registers, FOUR workgroups per CU.  The K fragments are read one 32-key half at a time and
+// the V fragments after the softmax instead of behind it, so that no 32-register fragment set is live across another
+// phase; the exposed LDS latency is covered by the fourth wave of the SIMD (measured +2.3-2.9 % at 16k-32k tokens against
+// the 153-register, three-workgroup form, which -DA6B_OCC4=0 still builds for A/B runs).  Reading the V fragments (or half
+// of them) behind the exponentials at four waves per SIMD spills.
+#ifndef A6B_OCC4
+#define A6B_OCC4 1
+#endif
 template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(AttnArgs p) {
     constexpr int D = 64;
     typedef typename Mfma<T>::v8 v8;
     typedef typename Mfma<T>::v4 v4;
@@ -557,14 +565,20 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
 
         // ---- S^T[key][q]: two 32-key halves x 4 k-steps, VGPR-form MFMAs
         v8 kf[2][4];
+        if (!A6B_OCC4) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const v8*)(Ks + kt * 4096 + koff[ks]);
+                for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const v8*)(Ks + kt * 4096 + koff[ks]);
+        }
         f32x16 sacc[2];
         asm volatile("s_setprio 1");   // the wave that feeds the matrix pipe issues ahead of its SIMD's softmax waves (+0.6 %)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+            if (A6B_OCC4) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const v8*)(Ks + kt * 4096 + koff[ks]);
+            }
             if constexpr (__is_same(T, f16)) {
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sacc[kt]) : "v"(kf[kt][0]), "v"(qf[0]));
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][1]), "v"(qf[1]));
@@ -578,19 +592,22 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
             }
         }
         asm volatile("s_setprio 0");
-        // V fragments of this tile: in flight behind the softmax.  A operand (row = d, k = key in P's register order):
-        // elements 0..3 = keys 16 s4 + 4 lh + 0..3, elements 4..7 = keys 16 s4 + 8 + 4 lh + 0..3
         v8 vf[2][4];
+        auto read_v = [&]() {
+            // V fragments of this tile: in flight behind the softmax.  A operand (row = d, k = key in P's register order):
+            // elements 0..3 = keys 16 s4 + 4 lh + 0..3, elements 4..7 = keys 16 s4 + 8 + 4 lh + 0..3
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int off = vb + voff[dt] + s4 * 2048;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off + 1024));
-                typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
-                vf[dt][s4] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int off = vb + voff[dt] + s4 * 2048;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off + 1024));
+                    typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+                    vf[dt][s4] = __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+        };
+        if (!A6B_OCC4) read_v();
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));   // MFMA D -> VALU reader (§5.7 item 2)
 
         // ---- online softmax, register-local (this lane: 32 of its query's 64 scores, lane^32 the rest)
@@ -640,18 +657,18 @@ __global__ __launch_bounds__(256, 2) void attn_d64b_kernel(AttnArgs p) {
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[s4][j] = (T)sacc[s4 >> 1][8 * (s4 & 1) + j];
+        if (A6B_OCC4) read_v();   // four waves per SIMD: the fragments may not be live across the softmax
 
         // ---- O^T[d][q] += V^T P^T, VGPR form
         asm volatile("s_setprio 1");
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                if constexpr (__is_same(T, f16))
-                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
-                else
-                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int s4 = i >> 1, dt = i & 1;
+            if constexpr (__is_same(T, f16))
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
+            else
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
+        }
         asm volatile("s_setprio 0");
         asm volatile("s_nop 15\n\ts_nop 3\n\ts_waitcnt vmcnt(0)" : "+v"(oacc[0]), "+v"(oacc[1]) : : "memory");   // O readable by VALU; next tile landed
         if (!(A6B_ABL & 2)) __syncthreads();   // everyone done with this tile's buffers
