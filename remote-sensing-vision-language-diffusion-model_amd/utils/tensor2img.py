@@ -4,15 +4,14 @@ import numpy as np
 
 
 def tensor2img(tensor, out_type=np.uint8, min_max=(-1, 1)):
-    tensor = tensor.squeeze().float().cpu().clamp_(*min_max)
-    tensor = (tensor - min_max[0]) / (min_max[1] - min_max[0])
-    if tensor.dim() == 3:
-        img_np = np.transpose(tensor.numpy(), (1, 2, 0))
-    elif tensor.dim() == 2:
-        img_np = tensor.numpy()
-    else:
+    """``[3,H,W]`` / ``[1,3,H,W]`` -> HWC, ``[H,W]`` -> HW; uint8 output is rounded, any other dtype keeps [0, 1] values."""
+    lo, hi = min_max
+    unit = (tensor.squeeze().float().cpu().clamp_(lo, hi) - lo) / (hi - lo)
+    rank = unit.dim()
+    if rank not in (2, 3):
         raise TypeError(f"Only 3D and 2D tensors are supported here (the reference's 4-D branch calls an "
-                        f"unimported make_grid). Got {tensor.dim()}D")
+                        f"unimported make_grid). Got {rank}D")
+    arr = unit.numpy() if rank == 2 else unit.numpy().transpose(1, 2, 0)
     if out_type == np.uint8:
-        img_np = (img_np * 255.0).round()
-    return img_np.astype(out_type)
+        arr = np.round(arr * 255.0)
+    return arr.astype(out_type)
