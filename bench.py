@@ -4,21 +4,38 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the Stage-1 sampler over one batch: BASELINE.json configs[1]
-(Stage-1 only, 128 -> 512 x4 SR, batch 4 per GPU, 50 ancestral DDPM steps, synthetic inputs and
-seeded random-init weights of the shipped architecture).  value = images / second over the whole
-job (all ranks), inputs resident in HBM when the timed region starts.  Weak scaling: every rank
-processes its own 4 images; the only collective is the all-gather of finished uint8 images.
+Default workload = the configuration BASELINE.json's metric is quoted on (``--workload c4``):
+512x512 -> 4096x4096 x8 SR, Stage 1 (SR3, 50 ancestral DDPM steps at 4096^2) -> 8-bit hand-off ->
+Stage 2 (50 EDM steps at latent 512, ControlNet, tiled VAE 512/64, Wavelet colour fix), one image
+per GPU per pass, synthetic inputs, seeded random-init weights of the shipped architectures.
 
-Besides the contract fields the JSON line carries
-  roofline     : the dominant kernel (implicit-GEMM conv, MFMA-bound): algorithmic FLOPs of its
-                 launches / their summed HIP-event durations, from one extra instrumented pass;
-  cpu_baseline : the CPU oracle (oracle/sr3_oracle.py, a port) timed on this host's cores on a
-                 bounded sample and extrapolated linearly in step count.
+A whole image is ~70 s of GPU work, so one bench "step" is ONE sampler iteration of EACH stage at
+the real shapes (the work of every iteration is identical: the feature cache is OFF for the headline,
+because its hit rate on random weights means nothing).  After W untimed iterations of each stage the
+timed region runs, bracketed by barrier + synchronize: the per-image fixed part (2 tiled encodes +
+2 tiled decodes, hand-off, conditioner, colour fix, uint8 all-gather) ONCE and exactly K iterations
+of each stage.  With the phase times taken at device-synchronised stamps inside that region
+(max over ranks each):
+
+    value = n_gpus / (50 * t_S1_iter + 50 * t_S2_iter + t_fixed)          [images / s, whole job]
+
+``--workload c4full`` times complete images instead (one image per step) and is how the
+per-iteration figure was validated.  Other workloads: ``c2`` (BASELINE configs[1],
+Stage 1 only 128->512 batch 4), ``c3`` (configs[2], Stage 2 at 2048^2 batch 8 with the per-image
+feature cache), ``s2`` (Stage 2 only, any size).
+
+The JSON line also carries
+  roofline     : the dominant kernel of the workload: algorithmic FLOPs of its launches / their summed
+                 HIP-event durations (events on the launch stream, one extra instrumented pass), and the
+                 HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same workload;
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference's CPU path) timed on this host's
+                 cores on a bounded sample and extrapolated as stated in ``sample``.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,78 +44,64 @@ sys.path.insert(0, ROOT)
 
 import torch
 
-METRIC = "512px x8 SR images/sec @50 steps"
+METRIC = "512px x8 SR images/sec @50 steps"              # BASELINE.json metric (the c4 / c4full workloads only)
 PEAK_TFLOPS_F16 = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
-UNET_TF_PER_IMAGE_STEP = {256: 0.262, 512: 1.126, 1024: 5.77, 2048: 43.3, 4096: 496.3}
+S1_TF_PER_IMAGE_STEP = {256: 0.262, 512: 1.126, 1024: 5.77, 2048: 43.3, 4096: 496.3}   # BASELINE.md section 2 / SURVEY 8(d)
+S2_TF_PER_IMAGE_STEP = {64: 4.76, 128: 20.3, 256: 107.8, 512: 865.9}                  # by latent side, CFG pair + ControlNet
+PKG = os.path.join(ROOT, "remote-sensing-vision-language-diffusion-model_amd")
+
+S2_KW = dict(p_p="", n_p="", dec_img=1.0, restoration_scale=-1, s_churn=5, s_noise=1.003, cfg_scale=7.5, control_scale=1.0,
+             color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=4.0)     # infer.py:44-62 defaults
 
 
-def build_model(dev, T):
-    from oracle import sr3_oracle as O
-    from rsvld_amd.sr3_model.sr3_modules.diffusion import GaussianDiffusion
-    from rsvld_amd.sr3_model.sr3_modules.unet import UNet
-    c = O.SR3_CFG
-    torch.manual_seed(0)
-    unet = UNet(in_channel=c["in_channel"], out_channel=c["out_channel"], inner_channel=c["inner_channel"],
-                norm_groups=c["norm_groups"], channel_mults=c["channel_mults"], attn_res=list(c["attn_res"]),
-                res_blocks=c["res_blocks"], dropout=0.2, image_size=c["image_size"])
-    net = GaussianDiffusion(unet, image_size=c["image_size"], channels=3, conditional=True)
-    net.to(dev).eval()
-    net.set_new_noise_schedule(dict(schedule="linear", n_timestep=T, linear_start=1e-6, linear_end=1e-2), dev)
-    return net
+# --------------------------------------------------------------------------------------------- synthetic inputs / models
+def synthetic_image(shape, seed, smooth=4):
+    """Image-like fp32 tensor in [-1, 1]: seeded uniform noise, box low-pass, min-max normalised."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(shape, generator=g)
+    if smooth > 1:
+        x = torch.nn.functional.avg_pool2d(x, smooth, stride=1, padding=smooth // 2)[..., :shape[-2], :shape[-1]]
+    lo, hi = x.amin(dim=(-3, -2, -1), keepdim=True), x.amax(dim=(-3, -2, -1), keepdim=True)
+    return ((x - lo) / (hi - lo) * 2 - 1).contiguous()
 
 
-def synthetic_batch(batch, lr_side, scale, rank):
+def stage1_input(image_ids, lr_side, scale):
     """LR images -> the Stage-1 input contract (data/dataset.py:16-21,30-42): bicubic x scale, [-1,1]."""
-    from oracle import seeded
-    lr = torch.cat([seeded.synthetic_image((1, 3, lr_side, lr_side), seed=1234 + rank * batch + i, smooth=4)
-                    for i in range(batch)], 0)
+    lr = torch.cat([synthetic_image((1, 3, lr_side, lr_side), seed=1234 + i, smooth=4) for i in image_ids], 0)
     return torch.nn.functional.interpolate(lr, scale_factor=scale, mode="bicubic", align_corners=False).clamp(-1, 1)
 
 
-def cpu_baseline(side, T, steps_sampled=2):
-    """Time the CPU oracle on `steps_sampled` ancestral steps of ONE image at the real size."""
-    from oracle import seeded, sr3_oracle as O
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    ncores = max(1, min(avail, 32))   # beyond ~32 threads the fp32 conv/GEMM oracle stops scaling (NUMA, sync)
-    torch.set_num_threads(ncores)
-    c = O.SR3_CFG
-    names = []
+def build_stage1(T):
+    """The shipped Stage-1 option file (configs/sr_sr3.json) through the product's own factory
+    (sr3_model.create_model, infer.py:96-103), seeded default init, ``T``-step 'val' schedule."""
+    from rsvld_amd.configs import sr3 as SR3
+    from rsvld_amd.sr3_model import create_model
+    from rsvld_amd.utils import logger as Logger
+    opt = Logger.parse(SR3.SR3_Config())
+    opt["path"]["resume_state"] = None          # no checkpoints offline
     torch.manual_seed(0)
-    from rsvld_amd.sr3_model.sr3_modules.unet import UNet
-    unet = UNet(in_channel=c["in_channel"], out_channel=c["out_channel"], inner_channel=c["inner_channel"],
-                norm_groups=c["norm_groups"], channel_mults=c["channel_mults"], attn_res=list(c["attn_res"]),
-                res_blocks=c["res_blocks"], dropout=0.2, image_size=c["image_size"])
-    sd = {"denoise_fn." + k: v.detach() for k, v in unet.state_dict().items()}
-    sch = O.schedule(dict(schedule="linear", n_timestep=T, linear_start=1e-6, linear_end=1e-2))
-    cond = seeded.synthetic_image((1, 3, side, side), seed=1, smooth=4)
-    x = torch.randn(1, 3, side, side)
-    with torch.no_grad():
-        O.p_sample(sd, c, sch, x, T - 1, cond, torch.randn_like(x))  # warm-up (thread pool, allocator)
-        t0 = time.perf_counter()
-        for i in range(steps_sampled):
-            x = O.p_sample(sd, c, sch, x, T - 1 - i, cond, torch.randn_like(x))
-        dt = (time.perf_counter() - t0) / steps_sampled
-    return {"value": 1.0 / (dt * T), "unit": "img/s", "cores": ncores, "kind": "port",
-            "sample": f"{steps_sampled} ancestral steps of 1 image at {side}x{side} on the fp32 CPU oracle "
-                      f"({dt:.2f} s/step, {ncores} threads of {avail} schedulable cores), extrapolated linearly to {T} steps"}
+    model = create_model(opt)
+    sched = dict(opt["model"]["beta_schedule"]["val"], n_timestep=T)
+    model.set_new_noise_schedule(sched, schedule_phase="val")
+    return model.netG, opt
+
+
+def stage2_params():
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(PKG, "model_configs", "juggernautXL.yaml")))["model"]["params"]
+    g2, g3 = torch.Generator().manual_seed(2), torch.Generator().manual_seed(3)
+    cfg["conditioner_config"] = {"target": "rsvld_amd.sgm.modules.PreparedConditioner", "params": {
+        "cond_pth": {"crossattn": torch.randn(1, 77, 2048, generator=g2), "vector": torch.randn(1, 2816, generator=g2)},
+        "un_cond_pth": {"crossattn": torch.randn(1, 77, 2048, generator=g3), "vector": torch.randn(1, 2816, generator=g3)}}}
+    return cfg
 
 
 def build_stage2(dev, tile_vae):
     """Full juggernautXL.yaml networks (UNet 2.6 B + ControlNet 1.2 B params, seeded random init with the
-    zero-initialised tensors re-drawn), cached text embeddings (PreparedConditioner)."""
-    import yaml
+    zero-initialised tensors re-drawn), cached text embeddings (the reference's PreparedConditioner)."""
     from rsvld_amd.sgm.util import instantiate_from_config
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "remote-sensing-vision-language-diffusion-model_amd", "model_configs",
-                                           "juggernautXL.yaml")))["model"]["params"]
-    g2, g3 = torch.Generator().manual_seed(2), torch.Generator().manual_seed(3)
-    cfg["conditioner_config"]["params"] = {
-        "cond_pth": {"crossattn": torch.randn(1, 77, 2048, generator=g2), "vector": torch.randn(1, 2816, generator=g2)},
-        "un_cond_pth": {"crossattn": torch.randn(1, 77, 2048, generator=g3), "vector": torch.randn(1, 2816, generator=g3)}}
     torch.manual_seed(0)
-    m = instantiate_from_config({"target": "rsvld_amd.models.SR_model.SR_backbone", "params": cfg})
+    m = instantiate_from_config({"target": "rsvld_amd.models.SR_model.SR_backbone", "params": stage2_params()})
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for p_ in m.parameters():                  # zero_module() outputs would make the network output 0
@@ -110,173 +113,347 @@ def build_stage2(dev, tile_vae):
     return m
 
 
-S2_KW = dict(p_p="", n_p="", dec_img=1.0, restoration_scale=-1, s_churn=5, s_noise=1.003, cfg_scale=7.5, control_scale=1.0,
-             color_fix_type="Wavelet", use_linear_CFG=True, cfg_scale_start=4.0)
+# --------------------------------------------------------------------------------------------- helpers
+def schedulable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
+class Phases:
+    """Device-synchronised wall-clock stamps: ``stamp(name)`` closes the phase ``name``."""
+
+    def __init__(self):
+        self.t, self.acc = None, {}
+
+    def start(self):
+        torch.cuda.synchronize()
+        self.t = time.perf_counter()
+
+    def __call__(self, name):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.acc[name] = self.acc.get(name, 0.0) + now - self.t
+        self.t = now
+
+
+def dist_max(vals, dev, world):
+    if world == 1:
+        return [float(v) for v in vals]
+    on_host = torch.distributed.get_backend() == "gloo"
+    t = torch.tensor(vals, device="cpu" if on_host else dev, dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
+def barrier(world):
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def kernel_table(summ):
+    return {k: {"ms": round(v["ms"], 2), "n": v["n"],
+                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
+                "GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and not v["flops"] else None}
+            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def roofline_of(summ, pmc_file):
+    """The dominant kernel = the group with the largest time share of the instrumented pass."""
+    dom = max(summ.values(), key=lambda r: r["ms"])
+    tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    traffic, src = None, None
+    path = os.path.join(ROOT, "profiles", pmc_file)
+    if os.path.exists(path):
+        k = json.load(open(path)).get("kernels", {}).get(dom["name"])
+        if k is not None:
+            traffic, src = round(k["hbm_bytes_per_launch"]), f"profiles/{pmc_file}"
+    return {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
+            "algorithmic_flops_per_launch": round(dom["flops"] / dom["n"]),
+            "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 2),
+            "kernel_time_share": round(dom["ms"] / sum(r["ms"] for r in summ.values()), 3),
+            "by_kernel": kernel_table(summ)}
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+def _time_threads(fn, counts):
+    """Run ``fn`` once per thread count; -> (best seconds, best count, {count: seconds})."""
+    res = {}
+    for n in counts:
+        torch.set_num_threads(n)
+        t0 = time.perf_counter()
+        fn()
+        res[n] = time.perf_counter() - t0
+    best = min(res, key=res.get)
+    torch.set_num_threads(best)
+    return res[best], best, res
+
+
+def cpu_baseline_s1(side, T, steps_sampled=2):
+    """The CPU oracle (oracle/sr3_oracle.py) on ancestral steps of ONE image at ``side``; -> (s/step, threads, note)."""
+    from oracle import sr3_oracle as O
+    from rsvld_amd.sr3_model.sr3_modules.unet import UNet
+    avail = schedulable_cores()
+    c = O.SR3_CFG
+    torch.manual_seed(0)
+    unet = UNet(in_channel=c["in_channel"], out_channel=c["out_channel"], inner_channel=c["inner_channel"],
+                norm_groups=c["norm_groups"], channel_mults=c["channel_mults"], attn_res=list(c["attn_res"]),
+                res_blocks=c["res_blocks"], dropout=0.2, image_size=c["image_size"])
+    sd = {"denoise_fn." + k: v.detach() for k, v in unet.state_dict().items()}
+    sch = O.schedule(dict(schedule="linear", n_timestep=T, linear_start=1e-6, linear_end=1e-2))
+    cond = synthetic_image((1, 3, side, side), seed=1, smooth=4)
+    x = torch.randn(1, 3, side, side)
+    with torch.no_grad():
+        def one():
+            O.p_sample(sd, c, sch, x, T - 1, cond, torch.randn_like(x))
+        one()                                                     # warm-up (thread pool, allocator)
+        cands = sorted({min(avail, n) for n in (16, 32, 64, avail)})
+        _, best, sweep = _time_threads(one, cands)                # which thread count is fastest on this host
+        t0 = time.perf_counter()
+        for i in range(steps_sampled):
+            O.p_sample(sd, c, sch, x, T - 1 - i, cond, torch.randn_like(x))
+        dt = (time.perf_counter() - t0) / steps_sampled
+    return dt, best, {str(k): round(v, 2) for k, v in sweep.items()}
+
+
+def cpu_baseline_s2(m_state, params, latent, threads, steps_sampled=1):
+    """The CPU oracle (oracle/s2_oracle.py) on un-cached EDM sampler steps of ONE image at latent side ``latent``
+    with the FULL-size networks (the fp32 state dict of the benchmarked model); -> s/step."""
+    from oracle import s2_oracle as O
+    torch.set_num_threads(threads)
+    cp = params["conditioner_config"]["params"]
+    z = torch.randn(1, 4, latent, latent)
+    c = {"crossattn": cp["cond_pth"]["crossattn"], "vector": cp["cond_pth"]["vector"], "control": z}
+    uc = {"crossattn": cp["un_cond_pth"]["crossattn"], "vector": cp["un_cond_pth"]["vector"], "control": z}
+    table = O.legacy_ddpm_sigmas(1000, append_zero=False, flip=True)
+    sigmas = O.legacy_ddpm_sigmas(50)
+    sopt = dict(s_churn=5, s_noise=1.003, restore_cfg=-1, scale=4.0, scale_min=7.5, control_scale=1.0)
+    x = torch.randn(1, 4, latent, latent) * float(sigmas[0])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for i in range(steps_sampled):
+            x, _ = O.restore_edm_step(m_state, table, O.Cache(), x, i, sigmas, c, uc, x, sopt, 0.0, torch.randn)
+        dt = (time.perf_counter() - t0) / steps_sampled
+    return dt
+
+
+def cpu_baseline_headline(m, params, T, side, latent):
+    """Both stages on the host cores.  A 4096^2 Stage-1 step is ~500 TFLOP (hundreds of seconds on a CPU), so each
+    stage is timed at the largest size that keeps the sample within ~30 s and scaled by the algorithmic-FLOP ratio
+    of BASELINE.md section 2 (which under-states the CPU time: its attention share grows with size)."""
+    avail = schedulable_cores()
+    s1_side, s2_lat = 512, 64
+    dt1, thr, sweep = cpu_baseline_s1(s1_side, T, steps_sampled=2)
+    state = {k: v.detach().to("cpu", torch.float32) for k, v in m.state_dict().items()}
+    dt2 = cpu_baseline_s2(state, params, s2_lat, thr, steps_sampled=1)
+    del state
+    s1_full = dt1 * S1_TF_PER_IMAGE_STEP[side] / S1_TF_PER_IMAGE_STEP[s1_side]
+    s2_full = dt2 * S2_TF_PER_IMAGE_STEP[latent] / S2_TF_PER_IMAGE_STEP[s2_lat]
+    per_image = T * (s1_full + s2_full)
+    return {"value": 1.0 / per_image, "unit": "img/s", "cores": thr, "kind": "port",
+            "sample": f"fp32 CPU oracle: 2 Stage-1 ancestral steps of 1 image at {s1_side}^2 ({dt1:.2f} s/step) and 1 un-cached "
+                      f"Stage-2 EDM step (ControlNet + UNet, CFG pair, full-size networks) at latent {s2_lat} ({dt2:.2f} s/step), "
+                      f"{thr} threads = the fastest of the sweep {sweep} s/step on {avail} schedulable cores; scaled by the "
+                      f"algorithmic-FLOP ratios {side}^2/{s1_side}^2 = {S1_TF_PER_IMAGE_STEP[side] / S1_TF_PER_IMAGE_STEP[s1_side]:.0f}x and "
+                      f"latent {latent}/{s2_lat} = {S2_TF_PER_IMAGE_STEP[latent] / S2_TF_PER_IMAGE_STEP[s2_lat]:.0f}x, times {T} steps per "
+                      f"stage; VAE and colour fix not counted (an upper bound on the CPU rate)",
+            "s1_s_per_step_extrapolated": round(s1_full, 1), "s2_s_per_step_extrapolated": round(s2_full, 1)}
+
+
+# --------------------------------------------------------------------------------------------- headline: c4 / c4full
+def bench_headline(args, dev, rank, world):
+    from rsvld_amd import ops, parallel
+    T, K, W = args.ddpm_steps, args.steps, args.warmup
+    full = args.workload == "c4full"
+    side = args.lr_side * args.scale
+    latent = side // 8
+    t0 = time.perf_counter()
+    net, _ = build_stage1(T)
+    net.use_graph = False            # launches are ms-long at 4096^2; eager keeps the per-launch HIP events usable
+    params = stage2_params()
+    m = build_stage2(dev, True)
+    build_s = time.perf_counter() - t0
+    thr = args.s2_threshold
+
+    def image_inputs(img_id):
+        return stage1_input([img_id], args.lr_side, args.scale).to(dev)
+
+    def one_image(img_id, cond, n_iter, ph):
+        """Stage 1 -> hand-off -> Stage 2 -> uint8 -> all-gather; ``n_iter`` sampler iterations per stage (None = all)."""
+        torch.manual_seed(42 + img_id)                      # per-image RNG streams: results do not depend on the GPU count
+        ph.start()
+        sr = net.super_resolution(cond, continous=True, _max_steps=n_iter, _stamp=ph)[-1:]
+        u8 = parallel.to_uint8(sr)                          # utils/tensor2img.py:4-21: the 8-bit hand-off
+        lq = u8.float() / 127.5 - 1.0                       # models/util.py:132-156 (4096 is a multiple of 64)
+        ph("handoff")
+        out = m.just_sampling(lq, [""], **dict(S2_KW, img_threshold=thr, num_steps=T), _max_steps=n_iter, _stamp=ph)
+        gathered = parallel.gather_images(parallel.to_uint8(out), world)   # one RCCL all-gather of finished uint8 images
+        ph("gather")
+        return gathered
+
+    cond = image_inputs(rank)
+    if not args.pmc_pass:
+        # one-time work out of the timed region: lazy 16-bit weight packing of the Stage-2 networks (a tiny image, one step)
+        small = synthetic_image((1, 3, 512, 512), seed=7, smooth=4).to(dev)
+        m.just_sampling(small, [""], **dict(S2_KW, img_threshold=0.0, num_steps=1))
+        del small
+    torch.cuda.synchronize()
+
+    if args.pmc_pass:            # under rocprofv3 --pmc: exactly ONE iteration of each stage + the fixed part, nothing else
+        one_image(rank, cond, 1, Phases())
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(json.dumps({"pmc_pass": True, "workload": args.workload}), flush=True)
+        return
+
+    n_timed = None if full else K
+    if full:
+        for w in range(W):
+            one_image(rank + world * w, cond, None, Phases())
+    elif W > 0:
+        one_image(rank, cond, W, Phases())                  # W untimed iterations of each stage (+ the fixed part once)
+    ph = Phases()
+    barrier(world)
+    t0 = time.perf_counter()
+    if full:
+        for k in range(K):
+            out = one_image(rank + world * (W + k), cond, None, ph)
+    else:
+        out = one_image(rank, cond, n_timed, ph)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    a = ph.acc
+    s1_loop, s2_loop = a["s1_loop"], a["edm_sampler_loop"]
+    fixed = sum(v for k, v in a.items() if k not in ("s1_loop", "edm_sampler_loop"))
+    dt, s1_loop, s2_loop, fixed = dist_max([dt, s1_loop, s2_loop, fixed], dev, world)
+    if full:
+        value = world * K / dt
+        it1, it2, fx = s1_loop / (K * T), s2_loop / (K * T), fixed / K
+    else:
+        it1, it2, fx = s1_loop / K, s2_loop / K, fixed
+        value = world / (T * it1 + T * it2 + fx)
+    finite = bool(torch.isfinite(out.float()).all())
+
+    line = None
+    if rank == 0:
+        # ---- roofline: one extra instrumented pass (2 iterations per stage + the fixed part), not part of `value`
+        prof = ops.LaunchProfiler()
+        ops.set_profiler(prof)
+        _local_pass(net, m, cond, T, thr, 2)
+        torch.cuda.synchronize()
+        ops.set_profiler(None)
+        summ = prof.summary()
+        roof = roofline_of(summ, "r02_c4_pmc_traffic.json")
+        tf_img = (S1_TF_PER_IMAGE_STEP.get(side, 0) + S2_TF_PER_IMAGE_STEP.get(latent, 0)) * T
+        line = {
+            "metric": METRIC, "value": round(value, 6), "unit": "img/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 (UNets, fp32 accumulate), bf16 (VAE)", "data": "synthetic",
+            "config": {
+                "workload": (f"BASELINE configs[3]/[4] shape = the metric's configuration: {args.lr_side}x{args.lr_side} -> {side}x{side} "
+                             f"x{args.scale} SR, one image per GPU per pass: Stage 1 SR3 {T} ancestral DDPM steps at {side}^2 + 8-bit "
+                             f"hand-off + Stage 2 {T} EDM steps at latent {latent} (ControlNet + UNet, CFG pair, feature cache "
+                             f"{'OFF (threshold 0): uniform work per iteration' if thr <= 0 else thr}), tiled VAE 512/64, Wavelet colour "
+                             f"fix, uint8 all-gather; cached text embeddings (PreparedConditioner) instead of the live LLaVA prompt; "
+                             f"seeded random-init weights"),
+                "step_definition": ("one complete image per step" if full else
+                                    f"one sampler iteration of EACH stage at the real shapes; the timed region = the per-image fixed "
+                                    f"part once + exactly {K} iterations per stage; value = n_gpus / ({T}*t_S1_iter + {T}*t_S2_iter + "
+                                    f"t_fixed)"),
+                "global_batch": world, "parallelism": f"dp{world}",
+                "t_s1_iter_ms": round(it1 * 1e3, 1), "t_s2_iter_ms": round(it2 * 1e3, 1), "t_fixed_ms": round(fx * 1e3, 1),
+                "seconds_per_image": round(T * it1 + T * it2 + fx, 2),
+                "phases_ms": {k: round(v * 1e3, 1) for k, v in a.items()},
+                "timed_region_s": round(dt, 2), "model_build_s": round(build_s, 1), "finite": finite,
+                "algorithmic_tflops_whole_image": round(tf_img / (T * it1 + T * it2 + fx), 1),
+                "feature_cache": "off" if thr <= 0 else thr},
+            "roofline": roof}
+    if rank == 0:
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_headline(m, params, T, side, latent)
+        print(json.dumps(line), flush=True)
+
+
+def _local_pass(net, m, cond, T, thr, n_iter):
+    """Collective-free pass on the calling rank (the instrumented roofline pass)."""
+    from rsvld_amd import parallel
+    sr = net.super_resolution(cond, continous=True, _max_steps=n_iter)[-1:]
+    lq = parallel.to_uint8(sr).float() / 127.5 - 1.0
+    return parallel.to_uint8(m.just_sampling(lq, [""], **dict(S2_KW, img_threshold=thr, num_steps=T), _max_steps=n_iter))
+
+
+# --------------------------------------------------------------------------------------------- Stage 2 only: s2 / c3
 def bench_stage2(args, dev, rank, world):
-    """Secondary workload (not the contract line): Stage 2 only — BASELINE configs[2] shape family:
-    50 EDM steps, CFG 4.0->7.5 linear, s_churn 5, feature cache threshold 0.3, Wavelet colour fix."""
-    from oracle import seeded
+    """Secondary workloads (not the contract line).  ``c3`` = BASELINE configs[2]: Stage 2 on 2048^2 inputs (latent 256),
+    batch 8 per GPU, 50 EDM steps, per-image feature cache 0.3, Wavelet, tiled VAE.  ``s2``: any size / batch."""
+    from rsvld_amd import ops
+    if args.workload == "c3":
+        args.s2_side, args.batch, args.tile_vae = 2048, (8 if "--batch" not in sys.argv else args.batch), True
+        if "--s2-threshold" not in sys.argv:
+            args.s2_threshold = 0.3
     t0 = time.perf_counter()
     m = build_stage2(dev, args.tile_vae)
     side = args.s2_side
-    img = torch.cat([seeded.synthetic_image((1, 3, side, side), seed=1234 + rank * args.batch + i, smooth=4)
+    img = torch.cat([synthetic_image((1, 3, side, side), seed=1234 + rank * args.batch + i, smooth=4)
                      for i in range(args.batch)]).to(dev)
-    thr = args.s2_threshold if args.batch == 1 else 0.0
+    thr = args.s2_threshold
     kw = dict(S2_KW, img_threshold=thr, num_steps=args.ddpm_steps)
     build_s = time.perf_counter() - t0
 
     def one_pass():
+        torch.manual_seed(42 + rank)
         return m.just_sampling(img, [""] * args.batch, **kw)
 
     for _ in range(args.warmup):
         one_pass()
-    torch.cuda.synchronize()
+    barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_pass()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    from rsvld_amd import ops
+    barrier(world)
+    dt = dist_max([time.perf_counter() - t0], dev, world)[0]
+    trace = getattr(m, "cache_trace", None)
+    hits = None
+    if trace:
+        flat = [h for step in trace for (_, _, h) in step]
+        hits = round(sum(flat) / max(len(flat), 1), 3)
+    if rank != 0:
+        return
     prof = ops.LaunchProfiler()
     ops.set_profiler(prof)
-    one_pass()
+    m.just_sampling(img, [""] * args.batch, **dict(kw, _max_steps=2))
     torch.cuda.synchronize()
     ops.set_profiler(None)
     summ = prof.summary()
     L = side // 8
-    tf_step = {64: 4.76, 128: 20.3, 256: 107.8, 512: 865.9}.get(L)
-    line = {"metric": "Stage-2 images/sec (secondary workload)", "value": round(args.batch * args.steps / dt, 4), "unit": "img/s",
-            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 1),
+    tf_step = S2_TF_PER_IMAGE_STEP.get(L)
+    line = {"metric": "Stage-2 images/sec (secondary workload)", "value": round(args.batch * world * args.steps / dt, 4),
+            "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 (UNet/ControlNet), bf16 (VAE)", "data": "synthetic",
-            "config": {"workload": f"Stage 2 only, {side}x{side} input (latent {L}), batch {args.batch}, {args.ddpm_steps} EDM steps, "
-                                   f"cache threshold {thr}, Wavelet, {'tiled VAE (512 / 64)' if args.tile_vae else 'untiled VAE'}, "
-                                   f"full juggernautXL.yaml sizes",
+            "config": {"workload": f"Stage 2 only, {side}x{side} input (latent {L}), batch {args.batch}/GPU, {args.ddpm_steps} EDM steps, "
+                                   f"per-image feature-cache threshold {thr}, Wavelet, "
+                                   f"{'tiled VAE (512 / 64)' if args.tile_vae else 'untiled VAE'}, full juggernautXL.yaml sizes",
                        "model_build_s": round(build_s, 1), "finite": bool(torch.isfinite(out).all()),
+                       "cache_hit_rate": hits,
                        "algorithmic_tflops_no_cache": None if tf_step is None else round(
-                           tf_step * args.ddpm_steps * args.batch * args.steps / dt, 1)},
-            "by_kernel": {k: {"ms": round(v["ms"], 1), "n": v["n"],
-                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
-                          for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
+                           tf_step * args.ddpm_steps * args.batch * world * args.steps / dt, 1)},
+            "roofline": roofline_of(summ, f"r02_{args.workload}_pmc_traffic.json"), "cpu_baseline": None}
     print(json.dumps(line), flush=True)
 
 
-def bench_pipeline(args, dev, rank, world):
-    """The headline shape (BASELINE configs[3], one image per pass): 512 -> 4096 x8, Stage 1 (SR3, --ddpm-steps
-    ancestral steps at 4096^2) -> 8-bit hand-off -> Stage 2 (--ddpm-steps EDM steps, ControlNet, feature cache 0.3,
-    tiled VAE 512 / 64, Wavelet colour fix).  The caption comes from cached text embeddings (the LLaVA pass needs
-    checkpoints that are not available offline and stays on PyTorch-ROCm by north_star).  Kernel statistics are taken
-    in the timed pass itself (two HIP events per launch)."""
-    from oracle import seeded
+# --------------------------------------------------------------------------------------------- Stage 1 only: c2
+def bench_stage1(args, dev, rank, world):
+    """BASELINE configs[1]: Stage 1 only, 128 -> 512 x4, batch 4 per GPU, 50 ancestral steps (hipGraph replay)."""
     from rsvld_amd import ops, parallel
-    T = args.ddpm_steps
-    t0 = time.perf_counter()
-    net = build_model(dev, T)
-    net.use_graph = False   # per-launch HIP events cannot be recorded inside a graph capture; launches are ms-long here
-    m = build_stage2(dev, True)
-    build_s = time.perf_counter() - t0
-    cond = synthetic_batch(1, args.lr_side, args.scale, rank).to(dev)
-    side = args.lr_side * args.scale
-    # one-time work out of the timed region: lazy 16-bit weight packing of the Stage-2 networks (a tiny image, one step)
-    small = seeded.synthetic_image((1, 3, 512, 512), seed=7, smooth=4).to(dev)
-    m.just_sampling(small, [""], **dict(S2_KW, img_threshold=0.0, num_steps=1))
-    torch.cuda.synchronize()
-    stage = {}
-
-    def one_pass():
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        sr = net.super_resolution(cond, continous=True)[-1:]
-        u8 = parallel.to_uint8(sr)                                   # utils/tensor2img.py:4-21: the 8-bit hand-off
-        torch.cuda.synchronize()
-        b = time.perf_counter()
-        lq = u8.float() / 127.5 - 1.0                                # models/util.py:132-156 (4096 is a multiple of 64)
-        out = m.just_sampling(lq, [""], **dict(S2_KW, img_threshold=args.s2_threshold, num_steps=T))
-        torch.cuda.synchronize()
-        c = time.perf_counter()
-        stage["stage1_s"], stage["stage2_s"] = round(b - a, 2), round(c - b, 2)
-        print(f"pipeline pass: stage 1 {b - a:.2f} s, stage 2 {c - b:.2f} s", flush=True)
-        return out
-
-    for _ in range(args.warmup):
-        one_pass()
-    prof = ops.LaunchProfiler()
-    ops.set_profiler(prof)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_pass()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ops.set_profiler(None)
-    summ = prof.summary()
-    tf_img = UNET_TF_PER_IMAGE_STEP[side] * T + 865.9 * T   # BASELINE.md section 2, VAE and cache hits not counted
-    dom = max(summ.values(), key=lambda r: r["ms"])
-    tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    line = {"metric": METRIC, "value": round(args.steps / dt, 5), "unit": "img/s", "n_gpus": 1, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 (UNets), bf16 (VAE)", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[3] shape, one image per pass: {args.lr_side}->{side} x{args.scale}, Stage 1 {T} DDPM "
-                                   f"steps + Stage 2 {T} EDM steps (ControlNet, cache {args.s2_threshold}, tiled VAE 512/64, Wavelet), "
-                                   f"cached text embeddings instead of the live LLaVA prompt, seeded random-init weights",
-                       "global_batch": 1, "parallelism": "dp1", "model_build_s": round(build_s, 1),
-                       "finite": bool(torch.isfinite(out).all()), "out_shape": list(out.shape), **stage,
-                       "algorithmic_tflops_no_cache": round(tf_img * args.steps / dt, 1),
-                       "stage2_trace": getattr(m, "last_trace", None)},
-            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK_TFLOPS_F16,
-                         "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": None,
-                         "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 2),
-                         "kernel_time_share": round(dom["ms"] / sum(r["ms"] for r in summ.values()), 3),
-                         "by_kernel": {k: {"ms": round(v["ms"], 1), "n": v["n"],
-                                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None}
-                                       for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}},
-            "cpu_baseline": None}
-    print(json.dumps(line), flush=True)
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="c2", choices=["c2", "s2", "c4"],
-                    help="c2 = the contract line (default); s2 = Stage 2 only; c4 = the 512->4096 two-stage pipeline, one image")
-    ap.add_argument("--s2-side", type=int, default=1024)
-    ap.add_argument("--s2-threshold", type=float, default=0.3)
-    ap.add_argument("--tile-vae", action="store_true", help="Stage 2: VAEHook tiling (needed from 2048x2048 up: the VAE's "
-                                                               "single-head attention is quadratic in the pixel count)")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
-    ap.add_argument("--lr-side", type=int, default=128)
-    ap.add_argument("--scale", type=int, default=4)
-    ap.add_argument("--ddpm-steps", type=int, default=50)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
-    args = ap.parse_args()
-
-    from rsvld_amd import ops, parallel
-    rank, world, local = parallel.init_from_env()
-    if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}`")
-    if os.environ.get("RSVLD_DEVICE_OVERRIDE") is not None:   # debugging aid: several ranks on one GPU (with gloo)
-        local = int(os.environ["RSVLD_DEVICE_OVERRIDE"])
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if args.workload == "c4":
-        if "--lr-side" not in " ".join(sys.argv):
-            args.lr_side, args.scale = 512, 8
-        return bench_pipeline(args, dev, rank, world)
-    if args.workload == "s2":
-        if args.batch == 4 and "--batch" not in " ".join(sys.argv):
-            args.batch = 1
-        return bench_stage2(args, dev, rank, world)
-    side = args.lr_side * args.scale
-    T = args.ddpm_steps
-
-    net = build_model(dev, T)
+    side, T = args.lr_side * args.scale, args.ddpm_steps
+    net, _ = build_stage1(T)
     net.use_graph = not args.no_graph
-    cond = synthetic_batch(args.batch, args.lr_side, args.scale, rank).to(dev)
+    ids = [rank * args.batch + i for i in range(args.batch)]
+    cond = stage1_input(ids, args.lr_side, args.scale).to(dev)
 
     def one_pass(gather=True):
         # continous=False returns ret_img[-1], i.e. ONE image (diffusion.py:198-201): take the last
@@ -285,75 +462,113 @@ def main():
         u8 = parallel.to_uint8(sr)
         return parallel.gather_images(u8, world) if gather else u8
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         one_pass()
-    barrier()
+    barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = one_pass()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        on_host = torch.distributed.get_backend() == "gloo"
-        tmax = torch.tensor([dt], device="cpu" if on_host else dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
-    n_img = args.batch * world * args.steps
-    value = n_img / dt
-
-    # ---- roofline of the dominant kernel: one extra, instrumented pass (not part of `value`)
-    roof = None
-    if rank == 0:
-        prof = ops.LaunchProfiler()
-        ops.set_profiler(prof)
-        saved = net.use_graph
-        net.use_graph = False
-        one_pass(gather=False)   # rank 0 only: no collective in here, the other ranks have moved on
-        torch.cuda.synchronize()
-        net.use_graph = saved
-        ops.set_profiler(None)
-        summ = prof.summary()
-        dom = max(summ.values(), key=lambda r: r["ms"])
-        tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        traffic = None   # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this workload
-        pmc = os.path.join(ROOT, "profiles", "r01_c2_pmc_traffic.json")
-        if os.path.exists(pmc) and side == 512 and args.batch == 4:
-            k = json.load(open(pmc))["kernels"].get(dom["name"])
-            traffic = None if k is None else round(k["hbm_bytes_per_launch"])
-        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK_TFLOPS_F16,
-                "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
-                "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 2),
-                "kernel_time_share": round(dom["ms"] / sum(r["ms"] for r in summ.values()), 3),
-                "by_kernel": {k: {"ms": round(v["ms"], 3), "n": v["n"],
-                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None}
-                              for k, v in summ.items()}}
-
-    if rank == 0:
-        step_tf = UNET_TF_PER_IMAGE_STEP.get(side)
-        line = {
-            "metric": METRIC, "value": round(value, 4), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+        one_pass()
+    barrier(world)
+    dt = dist_max([time.perf_counter() - t0], dev, world)[0]
+    if rank != 0:
+        return
+    prof = ops.LaunchProfiler()
+    ops.set_profiler(prof)
+    saved, net.use_graph = net.use_graph, False
+    one_pass(gather=False)   # rank 0 only: no collective in here, the other ranks have moved on
+    torch.cuda.synchronize()
+    net.use_graph = saved
+    ops.set_profiler(None)
+    step_tf = S1_TF_PER_IMAGE_STEP.get(side)
+    line = {"metric": f"Stage-1 (SR3) {args.lr_side}->{side} x{args.scale} images/sec @{T} steps (BASELINE configs[1], secondary workload)",
+            "value": round(args.batch * world * args.steps / dt, 4), "unit": "img/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: Stage-1 (SR3) only, {args.lr_side}->{side} x{args.scale} SR, "
                                    f"batch {args.batch}/GPU, {T} ancestral DDPM steps, seeded random-init weights",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "hipgraph": bool(net.use_graph),
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(net.use_graph),
                        "algorithmic_tflops_whole_step": None if step_tf is None else round(
                            step_tf * T * args.batch * world * args.steps / dt, 2)},
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(side, T)
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+            "roofline": roofline_of(prof.summary(), "r01_c2_pmc_traffic.json")}
+    if not args.no_cpu_baseline and world == 1:
+        dt1, thr, sweep = cpu_baseline_s1(side, T)
+        line["cpu_baseline"] = {"value": 1.0 / (dt1 * T), "unit": "img/s", "cores": thr, "kind": "port",
+                                "sample": f"2 ancestral steps of 1 image at {side}x{side} on the fp32 CPU oracle ({dt1:.2f} s/step, "
+                                          f"{thr} threads: fastest of {sweep} on {schedulable_cores()} schedulable cores), "
+                                          f"extrapolated linearly to {T} steps"}
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line), flush=True)
+
+
+# --------------------------------------------------------------------------------------------- launcher
+def self_launch(n):
+    """``bench.py --gpus N`` started as a plain process: spawn N fresh ranks through torch.distributed.run as a CHILD
+    process (this parent has not touched the GPU and never does) and exit with its code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c4", choices=["c4", "c4full", "c2", "c3", "s2"],
+                    help="c4 = the metric's configuration, timed per sampler iteration (default); c4full = the same, whole images; "
+                         "c2 = Stage 1 only (BASELINE configs[1]); c3 = Stage 2 at 2048^2 batch 8 (configs[2]); s2 = Stage 2 only")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (c2: 4, s2: 1, c3: 8)")
+    ap.add_argument("--lr-side", type=int, default=None)
+    ap.add_argument("--scale", type=int, default=None)
+    ap.add_argument("--ddpm-steps", type=int, default=50)
+    ap.add_argument("--s2-side", type=int, default=1024)
+    ap.add_argument("--s2-threshold", type=float, default=None, help="feature-cache threshold (headline: 0 = off; c3/s2: 0.3)")
+    ap.add_argument("--tile-vae", action="store_true", help="s2: VAEHook tiling (needed from 2048x2048 up)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="c2: launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--pmc-pass", action="store_true", help="c4: one iteration of each stage + the fixed part and nothing "
+                                                             "else (the process rocprofv3 --pmc counts)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
+    headline = args.workload in ("c4", "c4full")
+    dflt = {"c4": (20, 5), "c4full": (1, 0), "c2": (3, 1), "c3": (1, 0), "s2": (1, 1)}[args.workload]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
+    if args.lr_side is None:
+        args.lr_side, args.scale = (512, 8) if headline else (128, 4)
+    elif args.scale is None:
+        args.scale = 8 if headline else 4
+    if args.batch is None:
+        args.batch = {"c2": 4, "c3": 8}.get(args.workload, 1)
+    if args.s2_threshold is None:
+        args.s2_threshold = 0.0 if headline else 0.3
+    if args.workload == "c4" and max(args.steps, args.warmup) > args.ddpm_steps:
+        raise SystemExit("--steps / --warmup must not exceed --ddpm-steps on the per-iteration workload")
+
+    from rsvld_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("RSVLD_DEVICE_OVERRIDE") is not None:   # debugging aid: several ranks on one GPU (with gloo)
+        local = int(os.environ["RSVLD_DEVICE_OVERRIDE"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if headline:
+        bench_headline(args, dev, rank, world)
+    elif args.workload in ("s2", "c3"):
+        bench_stage2(args, dev, rank, world)
+    else:
+        bench_stage1(args, dev, rank, world)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

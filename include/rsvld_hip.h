@@ -14,7 +14,13 @@
  *   - activations are NHWC ("channels last", token-major) with C % 8 == 0;
  *     `dtype` selects the 16-bit storage/MFMA operand type: 0 = fp16, 1 = bf16.
  *     Accumulation, normalisation statistics and softmax are always fp32;
- *   - stateless and re-entrant: one stream per call.
+ *   - stateless and re-entrant: one stream per call; no environment variables are read and no
+ *     mutable global state is kept (the only process-wide objects are one-time, thread-safe
+ *     registrations of kernel attributes, C++11 function-local statics);
+ *   - launch plans are BATCH-INVARIANT on request: the kernel family, tile shape and split plan of a
+ *     call are derived from (batch / plan_div), i.e. from ONE of `plan_div` independent work units
+ *     stacked along the batch, so a unit's result is bit-identical however many units share the
+ *     launch (data-parallel sharding and per-image feature-cache sub-batches rely on it).
  */
 #ifndef RSVLD_HIP_H
 #define RSVLD_HIP_H
@@ -71,7 +77,19 @@ typedef struct rsvld_conv_desc {
     int32_t act;           /* RSVLD_ACT_*                                           */
     float alpha, beta;
     int32_t rowvec_stride; /* elements between rows of rowvec; 0 = Cout                     */
+    int32_t plan_div;      /* independent work units stacked along B (or along the rows of a Linear): the launch
+                              plan is made for B*Ho*Wo / plan_div rows; 0 or 1 = plan for the whole call      */
+    int32_t tune;          /* RSVLD_TUNE_* developer A/B overrides; 0 = the library's own choice             */
 } rsvld_conv_desc;
+
+/* rsvld_conv_desc.tune (benchmarking only; every combination computes the same function) */
+#define RSVLD_TUNE_TILE_MASK 7          /* 1: 256x64, 2: 128x64, 3: 128x128, 4: 64x128 implicit-GEMM tile */
+#define RSVLD_TUNE_STAGES_SHIFT 3       /* bits 3..5: LDS ring depth 2..4 (0 = per-tile default)          */
+#define RSVLD_TUNE_NO_KSPLIT (1 << 6)   /* no intra-workgroup split-K variants                            */
+#define RSVLD_TUNE_REG_STAGING (1 << 7) /* register-staged operands instead of LDS-DMA                    */
+#define RSVLD_TUNE_HALO_NW4 (1 << 8)    /* halo conv: force the 4-wave 8x32 tile                          */
+#define RSVLD_TUNE_HALO_NW8 (1 << 9)    /* halo conv: force the 8-wave 16x32 tile                         */
+#define RSVLD_TUNE_NO_GEMM256 (1 << 10) /* keep large 1x1 / Linear layers on the implicit-GEMM kernel     */
 
 int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
 
@@ -156,10 +174,11 @@ int rsvld_attention(const void* q, const void* k, const void* v, void* out,
                     int64_t k_batch_stride, int64_t k_tok_stride,
                     int64_t v_batch_stride, int64_t v_tok_stride,
                     int64_t o_batch_stride, int64_t o_tok_stride,
-                    float scale, int dtype, void* ws, void* stream);
+                    float scale, int dtype, int plan_div, void* ws, void* stream);
 /* bytes of `ws` the call above needs (0 = none, ws may be NULL): the D = 512 kernel splits the keys over
- * workgroups when the query tiles alone cannot fill the chip and merges the partial results from ws. */
-int64_t rsvld_attention_ws_bytes(int B, int heads, int Nq, int Nk, int D);
+ * workgroups when the query tiles of B / plan_div batch rows alone cannot fill the chip and merges the partial
+ * results from ws (plan_div: independent units stacked along B, see the conventions; 0 or 1 = plan on B). */
+int64_t rsvld_attention_ws_bytes(int B, int heads, int Nq, int Nk, int D, int plan_div);
 
 /* ---------------------------------------------------------------------------------------
  * Small dense layers on embeddings (rows <= 64): y = act_out( W * act_in(x) + b ), fp32.

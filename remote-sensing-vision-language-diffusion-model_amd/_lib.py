@@ -12,6 +12,10 @@ LIB_PATH = os.environ.get("RSVLD_LIB") or os.path.join(_PKG_DIR, "librsvld_hip.s
 
 F16, BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+# rsvld_conv_desc.tune (developer A/B overrides)
+TUNE_TILE = {"256x64": 1, "128x64": 2, "128x128": 3, "64x128": 4}
+TUNE_STAGES_SHIFT, TUNE_NO_KSPLIT, TUNE_REG_STAGING = 3, 1 << 6, 1 << 7
+TUNE_HALO_NW4, TUNE_HALO_NW8, TUNE_NO_GEMM256 = 1 << 8, 1 << 9, 1 << 10
 
 ERRORS = {-1: "RSVLD_EINVAL (bad shape / pointer / combination)",
           -2: "RSVLD_EUNSUPPORTED", -3: "RSVLD_ELAUNCH (HIP launch failed)"}
@@ -31,6 +35,7 @@ class ConvDesc(C.Structure):
         ("pad_l", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
         ("upsample", C.c_int32), ("dtype", C.c_int32), ("out_f32", C.c_int32), ("act", C.c_int32),
         ("alpha", C.c_float), ("beta", C.c_float), ("rowvec_stride", C.c_int32),
+        ("plan_div", C.c_int32), ("tune", C.c_int32),
     ]
 
 
@@ -50,8 +55,8 @@ SIGNATURES = {
     "rsvld_groupnorm_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "rsvld_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
     "rsvld_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
-                             _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _vp, _vp]),
-    "rsvld_attention_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
+                             _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _i, _vp, _vp]),
+    "rsvld_attention_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
     "rsvld_linear_small_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsvld_sinusoidal_embedding": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "rsvld_nchw_f32_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),

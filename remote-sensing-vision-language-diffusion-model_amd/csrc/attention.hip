@@ -706,10 +706,10 @@ static void attn512_plan(int B, int heads, int Nq, int Nk, int* nsplit, int* key
     *nsplit = (Nk + kps - 1) / kps;
 }
 
-extern "C" int64_t rsvld_attention_ws_bytes(int B, int heads, int Nq, int Nk, int D) {
+extern "C" int64_t rsvld_attention_ws_bytes(int B, int heads, int Nq, int Nk, int D, int plan_div) {
     if (D != 512 || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return 0;
     int ns, kps;
-    attn512_plan(B, heads, Nq, Nk, &ns, &kps);
+    attn512_plan(plan_div > 1 ? (B + plan_div - 1) / plan_div : B, heads, Nq, Nk, &ns, &kps);
     if (ns == 1) return 0;
     return (int64_t)ns * B * heads * Nq * (512 + 2) * 4;
 }
@@ -717,8 +717,8 @@ extern "C" int64_t rsvld_attention_ws_bytes(int B, int heads, int Nq, int Nk, in
 extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
                                int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
                                int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride,
-                               int64_t o_batch_stride, int64_t o_tok_stride, float scale, int dtype, void* ws,
-                               void* stream) {
+                               int64_t o_batch_stride, int64_t o_tok_stride, float scale, int dtype, int plan_div,
+                               void* ws, void* stream) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return RSVLD_EINVAL;
     if (dtype != RSVLD_F16 && dtype != RSVLD_BF16) return RSVLD_EINVAL;
     // 16-byte vector access along d: strides must keep rows 8-element aligned
@@ -734,19 +734,15 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
     a.scale_log2e = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     if (D == 512) {
-        int ns, kps;
-        attn512_plan(B, heads, Nq, Nk, &ns, &kps);
+        int ns, kps;   // the key split (an accumulation-order choice) is planned on ONE of the plan_div stacked units
+        attn512_plan(plan_div > 1 ? (B + plan_div - 1) / plan_div : B, heads, Nq, Nk, &ns, &kps);
         if (ns > 1 && ws == nullptr) return RSVLD_EINVAL;
         float* part_o = (float*)ws;
         float* part_ml = ns > 1 ? part_o + (int64_t)ns * B * heads * Nq * 512 : nullptr;
         dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)ns, (unsigned)(B * heads));
         auto go = [&](auto kern, auto comb) -> int {
-            static bool set = false;
-            if (!set) {
-                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, A5B_SMEM) != hipSuccess)
-                    return RSVLD_ELAUNCH;
-                set = true;
-            }
+            static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, A5B_SMEM);
+            if (attr != hipSuccess) return RSVLD_ELAUNCH;
             hipLaunchKernelGGL(kern, grid, dim3(256), A5B_SMEM, s, a, kps, part_o, part_ml);
             if (ns > 1) hipLaunchKernelGGL(comb, dim3((unsigned)Nq, (unsigned)(B * heads)), dim3(128), 0, s, a, ns, part_o, part_ml);
             return rsvld_check_launch();

@@ -39,6 +39,7 @@ struct HaloArgs {
     int tiles_x, tiles_y;   // workgroup tiles (tiles_y counts rows of the kernel's own tile height)
     int tiles_y8;           // rows of the 8x32-pixel grid of the statistics partials
     int rv_stride, Cout_out;
+    int B_plan, tune;       // batch rows the launch plan is made for (B / plan_div); RSVLD_TUNE_*
 };
 
 constexpr int TH = 8, TW = 32, PW = TW + 2, PROWS = (TH + 2) * PW;   // 340 patch pixels
@@ -649,13 +650,9 @@ int launch_halo32(HaloArgs a, hipStream_t s) {
     const int64_t nwg = (int64_t)a.tiles_x * a.tiles_y * a.B * ((a.Cout + BN - 1) / BN);
     if (nwg >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
     auto go = [&](auto kern) -> int {
-        // per-instantiation flag: the lambda is instantiated once per kernel type
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-                return RSVLD_ELAUNCH;
-            attr_set = true;
-        }
+        // one-time, thread-safe; the lambda is instantiated once per kernel type
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (attr != hipSuccess) return RSVLD_ELAUNCH;
         hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), smem, s, a);
         return rsvld_check_launch();
     };
@@ -670,12 +667,8 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
     constexpr int epi = (256 / (BN > 64 ? 2 : 1)) * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
     auto kern = conv_halo_kernel<T, BN, WAVES_M, TPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return RSVLD_ELAUNCH;
-        attr_set = true;
-    }
+    static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr != hipSuccess) return RSVLD_ELAUNCH;
     const int64_t nwg = (int64_t)a.tiles_x * a.tiles_y * a.B * ((a.Cout + BN - 1) / BN);
     if (nwg >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
@@ -686,10 +679,10 @@ template <typename T>
 int dispatch_halo(const HaloArgs& a, hipStream_t s) {
     if (a.Cout <= 64) return launch_halo<T, 64, 4, 2>(a, s);
     // 16x32-pixel tiles (one 8-wave workgroup per CU) once that grid still covers most of the chip
-    static const char* nw_env = getenv("RSVLD_HALO_NW");   // A/B switch: 4 or 8
-    const int64_t wg16 = (int64_t)a.tiles_x * ((a.H + 15) / 16) * a.B * ((a.Cout + 127) / 128);
+    const int64_t wg16 = (int64_t)a.tiles_x * ((a.H + 15) / 16) * a.B_plan * ((a.Cout + 127) / 128);
     // measured (tools/bench_halo.py, one box): +3..13 % from 192 channels of K up, -3 % at 128 (longer pipeline fill)
-    const bool use8 = nw_env ? nw_env[0] == '8' : (wg16 >= 192 && a.Ctot >= 192);
+    const bool use8 = (a.tune & RSVLD_TUNE_HALO_NW8) ? true : (a.tune & RSVLD_TUNE_HALO_NW4) ? false
+                                                             : (wg16 >= 192 && a.Ctot >= 192);
     if (use8) return launch_halo32<T, 128, 8>(a, s);
     return launch_halo32<T, 128, 4>(a, s);
 }
@@ -723,6 +716,8 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     a.ab = norm_scale_shift;
     a.stats = d->out_f32 ? nullptr : out_stats_partials;
     a.B = d->B; a.H = d->Ho; a.W = d->Wo; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
+    a.B_plan = d->plan_div > 1 ? (d->B + d->plan_div - 1) / d->plan_div : d->B;
+    a.tune = d->tune;
     a.Hs = d->H; a.Ws = d->W; a.ush = d->upsample ? 1 : 0;
     a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.norm_silu = norm_silu ? 1 : 0;
     a.alpha = d->alpha; a.beta = d->beta;

@@ -49,6 +49,8 @@ struct ConvArgs {
     int nk;      // K-steps of 64 elements
     int Cout_out;  // channels of the stored tensor (Cout, or Cout/2 for GEGLU)
     int rv_stride; // row stride of rowvec
+    int M_plan;    // rows the launch plan is made for (M / plan_div)
+    int tune;      // RSVLD_TUNE_*
 };
 
 constexpr int BK_BYTES = 128;  // 64 x 16-bit per LDS row
@@ -372,67 +374,25 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int epi = BM * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
     auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-            return RSVLD_ELAUNCH;
-        attr_set = true;
-    }
+    // one-time, thread-safe (C++11 magic static), per instantiation
+    static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr != hipSuccess) return RSVLD_ELAUNCH;
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
     hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, a);
     return rsvld_check_launch();
 }
 
-bool use_glds() {   // RSVLD_CONV_STAGING=reg selects the register-staged variant (A/B on hardware)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("RSVLD_CONV_STAGING");
-        v = (e != nullptr && e[0] == 'r') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-int tile_override() {   // RSVLD_CONV_TILE=256x64|128x64|128x128|64x128 forces a tile (benchmarking only)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("RSVLD_CONV_TILE");
-        v = 0;
-        if (e != nullptr) {
-            if (!strcmp(e, "256x64")) v = 1;
-            else if (!strcmp(e, "128x64")) v = 2;
-            else if (!strcmp(e, "128x128")) v = 3;
-            else if (!strcmp(e, "64x128")) v = 4;
-        }
-    }
-    return v;
-}
-
 // Tile choice.  Cout <= 32: 256x32.  Cout <= 64: 128x64 (48 KiB LDS -> 3 workgroups per CU: these layers
 // have few K-steps per tile, so co-resident workgroups hide each other's prologue / epilogue).  Otherwise
 // 128x128, except when that grid would leave CUs idle (< 256 workgroups): then 64x128 doubles the grid.
-int stages_override() {   // RSVLD_CONV_STAGES=2|3|4 (benchmarking only; default = per-tile choice below)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("RSVLD_CONV_STAGES");
-        v = e != nullptr ? atoi(e) : 0;
-    }
-    return v;
-}
-
-bool ksplit_enabled() {   // RSVLD_CONV_KSPLIT=0 disables the intra-workgroup split-K variants (A/B on hardware)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("RSVLD_CONV_KSPLIT");
-        v = (e != nullptr && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
+// All grid-size tests use M_plan (the rows of ONE of the plan_div stacked units): the plan, and with it the
+// order of every accumulation, does not depend on how many units share the launch.
 template <typename T, bool GLDS>
 int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     if (a.Cout <= 32) return launch_conv<T, 256, 32, 4, 1, GLDS>(a, s);
-    const int ov = tile_override();
-    const int st = GLDS ? stages_override() : 2;
+    const int ov = a.tune & RSVLD_TUNE_TILE_MASK;
+    const int st = GLDS ? ((a.tune >> RSVLD_TUNE_STAGES_SHIFT) & 7) : 2;
+    const bool ksplit = !(a.tune & RSVLD_TUNE_NO_KSPLIT);
     if (a.Cout <= 64) {
         if (ov == 1) return launch_conv<T, 256, 64, 4, 1, GLDS>(a, s);
         if constexpr (GLDS) {   // measured: 3 WGs/CU x 1 tile in flight (48 KiB) beats 2 WGs/CU x 2 tiles (72 KiB)
@@ -441,22 +401,22 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
         }
         return launch_conv<T, 128, 64, 4, 1, GLDS>(a, s);
     }
-    const int64_t wg128 = (int64_t)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-    const int64_t wg64x128 = (int64_t)((a.M + 63) / 64) * ((a.Cout + 127) / 128);
+    const int64_t wg128 = (int64_t)((a.M_plan + 127) / 128) * ((a.Cout + 127) / 128);
+    const int64_t wg64x128 = (int64_t)((a.M_plan + 63) / 64) * ((a.Cout + 127) / 128);
     if constexpr (GLDS) {
         // small-M linears (Stage-2 transformer blocks at 16x16 / 32x32 tokens): even 64x128 leaves most CUs idle and
         // the K loop is a latency-bound weight stream.  64x64 tiles double the grid again; 4 x 16 KiB stages keep
         // 3 tiles in flight per workgroup at 2 workgroups per CU.
         if (ov == 0 && wg64x128 < 256) {
-            const int64_t wg64 = (int64_t)((a.M + 63) / 64) * ((a.Cout + 63) / 64);
-            if (ksplit_enabled() && st == 0 && wg64 <= 256 && a.nk >= 16) return launch_conv<T, 64, 64, 2, 2, true, 4, 2>(a, s);
+            const int64_t wg64 = (int64_t)((a.M_plan + 63) / 64) * ((a.Cout + 63) / 64);
+            if (ksplit && st == 0 && wg64 <= 256 && a.nk >= 16) return launch_conv<T, 64, 64, 2, 2, true, 4, 2>(a, s);
             return launch_conv<T, 64, 64, 2, 2, true, 4>(a, s);
         }
     }
     if (ov == 4 || (ov == 0 && wg128 < 256)) {
         if constexpr (GLDS) {
             // one 64x128 workgroup per CU at most and a long K loop: two K groups (8 waves) per tile
-            if (ksplit_enabled() && st == 0 && wg64x128 <= 256 && a.nk >= 16) return launch_conv<T, 64, 128, 2, 2, true, 3, 2>(a, s);
+            if (ksplit && st == 0 && wg64x128 <= 256 && a.nk >= 16) return launch_conv<T, 64, 128, 2, 2, true, 3, 2>(a, s);
             if (st == 3 || st == 0) return launch_conv<T, 64, 128, 2, 2, true, 3>(a, s);   // 72 KiB: 2 WGs / CU
             if (st == 4) return launch_conv<T, 64, 128, 2, 2, true, 4>(a, s);
         }
@@ -471,7 +431,7 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
 
 template <typename T>
 int dispatch_conv(const ConvArgs& a, hipStream_t s) {
-    return use_glds() ? dispatch_conv2<T, true>(a, s) : dispatch_conv2<T, false>(a, s);
+    return (a.tune & RSVLD_TUNE_REG_STAGING) ? dispatch_conv2<T, false>(a, s) : dispatch_conv2<T, true>(a, s);
 }
 
 }  // namespace
@@ -503,12 +463,11 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     a.residual = d->residual; a.out = d->out;
     {   // the zero page's address is a kernel argument: taking &g_zero16 in device code reloads it through the GOT
         // inside the K loop, and an outstanding scalar load forces every LDS wait there to lgkmcnt(0)
-        static const void* zero = nullptr;
-        if (zero == nullptr) {
+        static const void* const zero = [] {   // one-time, thread-safe
             void* z = nullptr;
-            if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero16)) != hipSuccess || z == nullptr) return RSVLD_ELAUNCH;
-            zero = z;
-        }
+            return hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero16)) == hipSuccess ? (const void*)z : (const void*)nullptr;
+        }();
+        if (zero == nullptr) return RSVLD_ELAUNCH;
         a.zero = zero;
     }
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
@@ -516,6 +475,8 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     a.Ho = d->Ho; a.Wo = d->Wo; a.upsample = d->upsample ? 1 : 0;
     a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
     a.M = d->B * d->Ho * d->Wo;
+    a.M_plan = d->plan_div > 1 ? (a.M + d->plan_div - 1) / d->plan_div : a.M;
+    a.tune = d->tune;
     a.HoWo = d->Ho * d->Wo;
     a.C1_8 = d->Cin / 8;
     a.Ctot8 = (d->Cin + d->Cin2) / 8;

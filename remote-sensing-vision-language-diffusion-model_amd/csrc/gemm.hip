@@ -256,15 +256,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 // Eligibility + launch, called from rsvld_conv2d_nhwc for 1x1 / stride-1 / single-source layers.
 // Returns RSVLD_EUNSUPPORTED when the shape should stay on the implicit-GEMM kernel.
 int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
-    static const bool off = getenv("RSVLD_GEMM256_OFF") != nullptr;   // A/B switch
-    if (off) return RSVLD_EUNSUPPORTED;
+    if (d->tune & RSVLD_TUNE_NO_GEMM256) return RSVLD_EUNSUPPORTED;   // A/B switch
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad_t != 0 || d->pad_l != 0 || d->upsample) return RSVLD_EUNSUPPORTED;
     if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || d->out_f32) return RSVLD_EUNSUPPORTED;
     if (d->Cin % 32 != 0 || d->Cout % 8 != 0) return RSVLD_EUNSUPPORTED;
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     if (d->H != d->Ho || d->W != d->Wo) return RSVLD_EUNSUPPORTED;
-    if (d->Cout < 256 || M < 4096) return RSVLD_EUNSUPPORTED;
-    const int64_t tiles = ((M + 255) / 256) * ((d->Cout + 255) / 256);
+    // eligibility is decided on the rows of ONE of the plan_div stacked units (batch-invariant plan)
+    const int64_t Mp = d->plan_div > 1 ? (M + d->plan_div - 1) / d->plan_div : M;
+    if (d->Cout < 256 || Mp < 4096) return RSVLD_EUNSUPPORTED;
+    const int64_t tiles = ((Mp + 255) / 256) * ((d->Cout + 255) / 256);
     if (tiles < 128) return RSVLD_EUNSUPPORTED;   // one workgroup per CU; measured: from half the chip up it beats the 128x128 kernel
     if (M * d->Cin * 2 >= ((int64_t)1 << 32) || (int64_t)d->Cout * d->Cin * 2 >= ((int64_t)1 << 32)) return RSVLD_EUNSUPPORTED;
     if (d->act == RSVLD_ACT_GEGLU && (d->Cout % 16 != 0 || d->residual != nullptr)) return RSVLD_EINVAL;
@@ -276,12 +277,8 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)((d->Cout + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
     auto go = [&](auto kern) -> int {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM) != hipSuccess)
-                return RSVLD_ELAUNCH;
-            attr_set = true;
-        }
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM);
+        if (attr != hipSuccess) return RSVLD_ELAUNCH;
         hipLaunchKernelGGL(kern, grid, dim3(512), G_SMEM, s, a);
         return rsvld_check_launch();
     };

@@ -106,6 +106,19 @@ class SR_backbone(DiffusionEngine):
                       restoration_scale=4.0, s_churn=0, s_noise=1.003, cfg_scale=4.0, seed=-1, num_samples=1,
                       control_scale=1, color_fix_type="None", use_linear_CFG=False, use_linear_control_scale=False,
                       cfg_scale_start=1.0, control_scale_start=0.0, **kwargs):
+        """Reference signature (:200-223).  Images of a batch are independent units: every kernel launch inside is
+        planned for ONE image (``ops.plan_units``), so image b of a batch is bit-identical to its batch-of-1 run --
+        with the feature cache on as well (per-image decisions, sub-batched second UNet half)."""
+        from .. import ops
+        with ops.plan_units(num_samples if num_samples > 1 else len(x)):
+            return self._just_sampling(x, p, p_p, n_p, img_threshold, dec_img, num_steps, restoration_scale, s_churn, s_noise,
+                                       cfg_scale, seed, num_samples, control_scale, color_fix_type, use_linear_CFG,
+                                       use_linear_control_scale, cfg_scale_start, control_scale_start, **kwargs)
+
+    def _just_sampling(self, x, p, p_p="default", n_p="default", img_threshold=0.1, dec_img=1.0, num_steps=100,
+                       restoration_scale=4.0, s_churn=0, s_noise=1.003, cfg_scale=4.0, seed=-1, num_samples=1,
+                       control_scale=1, color_fix_type="None", use_linear_CFG=False, use_linear_control_scale=False,
+                       cfg_scale_start=1.0, control_scale_start=0.0, **kwargs):
         assert len(x) == len(p)
         assert color_fix_type in ["Wavelet", "AdaIn", "None"]
         N = len(x)
@@ -114,9 +127,6 @@ class SR_backbone(DiffusionEngine):
             N = num_samples
             x = x.repeat(N, 1, 1, 1)
             p = p * N
-        if N > 1 and img_threshold > 0:
-            raise NotImplementedError("the feature cache decides per image; batch > 1 runs with img_threshold <= 0 "
-                                      "(the reference itself only ever samples one image, infer.py:172,199)")
         p_p = self.p_p if p_p == "default" else p_p
         n_p = self.n_p if n_p == "default" else n_p
 
@@ -127,20 +137,14 @@ class SR_backbone(DiffusionEngine):
         sp.restore_cfg, sp.s_churn, sp.s_noise = restoration_scale, s_churn, s_noise
         self.sampler = instantiate_from_config(self.sampler_config)
 
-        # RSVLD_TRACE=1: wall time of every stage (device-synchronised), kept in self.last_trace
-        import os, time
-        trace = [] if os.environ.get("RSVLD_TRACE") else None
+        # measurement hooks (bench.py): ``_stamp(name)`` is called at every phase border, ``_max_steps`` truncates the
+        # sampler loop (the per-image fixed part still runs in full)
+        _stamp, _max_steps = kwargs.get("_stamp"), kwargs.get("_max_steps")
 
-        def stamp(name, _t=[None]):
-            if trace is None:
-                return
-            torch.cuda.synchronize()
-            now = time.perf_counter()
-            if _t[0] is not None:
-                trace.append((name, now - _t[0]))
-            _t[0] = now
+        def stamp(name):
+            if _stamp is not None:
+                _stamp(name)
 
-        stamp(None)
         x = x.float().contiguous()
         _z = self.encode_first_stage_with_denoise(x, use_sample=False)
         stamp("vae_denoise_encode")
@@ -159,14 +163,22 @@ class SR_backbone(DiffusionEngine):
         sampler.noise_fn = self._randn_like   # per-step churn draws follow the same generator choice
         z, s_in, sigmas, num_sigmas, c_img, uc_img = sampler.init_loop(noised_z, c_img, uc=uc_img, num_steps=num_steps)
         x_center_cur = z_stage1
-        with cache_context(MyCacheContext()):
-            for i in range(num_sigmas - 1):
+        if N > 1 and img_threshold > 0:
+            # the cache decides PER IMAGE: one threshold per image; sampler.step then returns a list
+            img_threshold = [float(img_threshold)] * N
+        stamp("sampler_init")
+        self.cache_trace = []
+        n_iter = num_sigmas - 1 if _max_steps is None else min(_max_steps, num_sigmas - 1)
+        with cache_context(MyCacheContext()) as ctx:
+            ctx.trace = self.cache_trace
+            for i in range(n_iter):
                 z, img_threshold = sampler.step(z, i, s_in, sigmas, denoiser, c_img, uc_img, x_center=x_center_cur,
                                                 control_scale=control_scale,
                                                 use_linear_control_scale=use_linear_control_scale,
                                                 control_scale_start=control_scale_start, threshold=img_threshold)
                 x_center_cur = z
-                img_threshold = img_threshold * dec_img
+                img_threshold = [t * dec_img for t in img_threshold] if isinstance(img_threshold, list) \
+                    else img_threshold * dec_img
         stamp("edm_sampler_loop")
 
         samples = self.decode_first_stage(z)
@@ -176,7 +188,4 @@ class SR_backbone(DiffusionEngine):
         elif color_fix_type == "AdaIn":
             samples = adaptive_instance_normalization(samples, x_stage1)
         stamp("colour_fix")
-        if trace is not None:
-            self.last_trace = trace
-            print("just_sampling trace: " + ", ".join(f"{n} {dt:.2f}s" for n, dt in trace), flush=True)
         return samples

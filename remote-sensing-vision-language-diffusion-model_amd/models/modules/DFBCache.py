@@ -29,7 +29,7 @@ def cache_context(cache_context):
     old = _current_cache_context
     _current_cache_context = cache_context
     try:
-        yield
+        yield cache_context
     finally:
         _current_cache_context = old
 
@@ -62,6 +62,33 @@ def relative_l1(t1, t2, images=None):
         cnt = n * per
         out.append((sd / cnt) / (sa / cnt + 1e-6))
     return out
+
+
+class RowSubset:
+    """A row selection of a per-sample tensor that is NOT materialised: consumers that cache work per source tensor
+    (the text-context K/V projections, sgm/modules/attention.py) keep their cache on ``full`` and select ``rows``."""
+
+    def __init__(self, full, rows):
+        self.full, self.rows = full, rows
+
+
+def select_rows(t, rows):
+    """``t[rows]`` for an activation, carrying the producer's GroupNorm partial statistics along (ops.conv2d attaches
+    them as ``_gn_part``), so the sub-batch takes the same statistics path as the full batch."""
+    out = t.index_select(0, rows)
+    part = getattr(t, "_gn_part", None)
+    if part is not None:
+        out._gn_part = (part[0].index_select(0, rows), part[1])
+    return out
+
+
+def select_partial_info(p, rows):
+    """The ``partial_info`` dict of ``input_stage1`` (SR_modules.py:674-683) restricted to batch rows ``rows``."""
+    ctx = p["context"]
+    return dict(p, h=select_rows(p["h"], rows), hs=[select_rows(t, rows) for t in p["hs"]],
+                emb={k: v.index_select(0, rows) for k, v in p["emb"].items()},
+                context=None if ctx is None else RowSubset(ctx, rows),
+                control=None if p["control"] is None else [select_rows(t, rows) for t in p["control"]])
 
 
 def are_two_tensors_similar(t1, t2, *, threshold, parallelized=False):

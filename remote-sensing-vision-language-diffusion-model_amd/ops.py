@@ -5,6 +5,7 @@ current HIP stream; every computation is a kernel of librsvld_hip.so.  Activatio
 16-bit tensors ``[B, H, W, C]`` with ``C % 8 == 0``; tokens ``[B, N, C]`` are the same thing with
 ``H = 1``.  Every function raises if the tensor is not on a GPU: there is no CPU path.
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -39,6 +40,44 @@ def _dt(t):
 
 def pad8(c):
     return (c + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------- launch plans
+# Batch-invariant plans (include/rsvld_hip.h, conventions): inside ``with plan_units(n)`` every launch is planned --
+# kernel family, tile shape, split-K / split-KV -- for ONE of the ``n`` independent work units (images) stacked along its
+# batch, so an image's result is bit-identical however many images share the launch.  Default 1 = plan on the whole call.
+_PLAN_DIV = 1
+
+
+@contextlib.contextmanager
+def plan_units(n):
+    global _PLAN_DIV
+    old, _PLAN_DIV = _PLAN_DIV, max(1, int(n))
+    try:
+        yield
+    finally:
+        _PLAN_DIV = old
+
+
+def _tune_from_env():
+    """Developer A/B switches -> rsvld_conv_desc.tune.  The environment is read HERE, once, by the Python tools layer;
+    the C ABI itself reads no environment (it is stateless)."""
+    e = os.environ
+    t = L.TUNE_TILE.get(e.get("RSVLD_CONV_TILE", ""), 0)
+    if e.get("RSVLD_CONV_STAGES"):
+        t |= (int(e["RSVLD_CONV_STAGES"]) & 7) << L.TUNE_STAGES_SHIFT
+    if e.get("RSVLD_CONV_KSPLIT", "1")[:1] == "0":
+        t |= L.TUNE_NO_KSPLIT
+    if e.get("RSVLD_CONV_STAGING", "")[:1] == "r":
+        t |= L.TUNE_REG_STAGING
+    if e.get("RSVLD_HALO_NW"):
+        t |= L.TUNE_HALO_NW8 if e["RSVLD_HALO_NW"][:1] == "8" else L.TUNE_HALO_NW4
+    if e.get("RSVLD_GEMM256_OFF") is not None:
+        t |= L.TUNE_NO_GEMM256
+    return t
+
+
+TUNE = _tune_from_env()
 
 
 # ----------------------------------------------------------------------------- launch profiling
@@ -185,12 +224,13 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride,
         pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=_dt(x), out_f32=int(out_f32),
-        act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride)
+        act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=_PLAN_DIV, tune=TUNE)
     lib = L.load()
     halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
+    Bp = -(-B // _PLAN_DIV)            # batch rows of one planning unit: every plan decision below uses Bp / Mp
     if halo:
         bn = 64 if pc.cout_p <= 64 else 128
-        halo = B * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= HALO_MIN_WGS and not (upsample and norm is not None)
+        halo = Bp * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= HALO_MIN_WGS and not (upsample and norm is not None)
     if norm is not None and not halo:   # unfused: normalise into a (single) tensor, then convolve it
         gamma, nbeta, groups, eps, silu = norm
         xn = group_norm(x, gamma, nbeta, groups, eps, x2=x2, silu=silu)
@@ -230,18 +270,19 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
             out._gn_part = (part_out, ntiles)
         return out
     M = B * Ho * Wo
+    Mp = -(-M // _PLAN_DIV)
     if (pc.kh == 1 and pc.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not upsample and x2 is None and rowvec is None
-            and not out_f32 and Cin % 32 == 0 and pc.cout_p >= 256 and M >= 4096
-            and ((M + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128 and M * Cin * 2 < 2 ** 32
-            and os.environ.get("RSVLD_GEMM256_OFF") is None):   # mirrors rsvld_gemm256_try in csrc/gemm.hip
+            and not out_f32 and Cin % 32 == 0 and pc.cout_p >= 256 and Mp >= 4096
+            and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128 and M * Cin * 2 < 2 ** 32
+            and not (TUNE & L.TUNE_NO_GEMM256)):   # mirrors rsvld_gemm256_try in csrc/gemm.hip (profiler label only)
         variant = "gemm_256x256"
     elif pc.cout_p <= 32:
         variant = "conv_igemm_256x32"
     elif pc.cout_p <= 64:
         variant = "conv_igemm_128x64"
     else:   # mirrors dispatch_conv2 in csrc/conv_igemm.hip
-        wg128 = ((B * Ho * Wo + 127) // 128) * ((pc.cout_p + 127) // 128)
-        wg64 = ((B * Ho * Wo + 63) // 64) * ((pc.cout_p + 127) // 128)
+        wg128 = ((Mp + 127) // 128) * ((pc.cout_p + 127) // 128)
+        wg64 = ((Mp + 63) // 64) * ((pc.cout_p + 127) // 128)
         variant = "conv_igemm_64x64" if wg64 < 256 else ("conv_igemm_64x128" if wg128 < 256 else "conv_igemm_128x128")
     _launch(variant, flops, nbytes, lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
     return out
@@ -330,12 +371,12 @@ def attention(q, k, v, heads, scale=None):
     lib = L.load()
     flops = 4.0 * B * heads * Nq * Nk * D
     nbytes = (q.shape[0] * Nq * HD * 2 + 2 * B * Nk * HD) * q.element_size()
-    ws_bytes = lib.rsvld_attention_ws_bytes(B, heads, Nq, Nk, D)   # split-KV partials (D = 512, small grids)
+    ws_bytes = lib.rsvld_attention_ws_bytes(B, heads, Nq, Nk, D, _PLAN_DIV)   # split-KV partials (D = 512, small grids)
     ws = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8) if ws_bytes > 0 else None
     _launch(f"attention_d{D}", flops, nbytes, lambda: L.check(
         lib.rsvld_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
                             q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                            out.stride(0), out.stride(1), scale, _dt(q), _ptr(ws), _stream()), "rsvld_attention"))
+                            out.stride(0), out.stride(1), scale, _dt(q), _PLAN_DIV, _ptr(ws), _stream()), "rsvld_attention"))
     return out
 
 

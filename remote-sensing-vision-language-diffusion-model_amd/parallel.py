@@ -53,11 +53,27 @@ def gather_images(local_u8, world):
 
 
 def unshard(gathered, n_images, world):
-    """Invert shard_indices: gathered is rank-major ([rank0's images..., rank1's ...]) -> image order."""
+    """Invert shard_indices: ``gathered`` is rank-major with ``per = ceil(n_images / world)`` rows per rank (short
+    ranks pad their tail, gather_images needs equal shapes) -> the n_images real rows in image order."""
     per = gathered.shape[0] // world
-    order = []
+    if per * world != gathered.shape[0] or per < -(-n_images // world):
+        raise ValueError(f"unshard: {gathered.shape[0]} gathered rows cannot hold {n_images} images over {world} ranks")
+    pos = torch.empty(n_images, dtype=torch.long)
     for r in range(world):
-        order += shard_indices(n_images, r, world)[:per]
-    inv = torch.empty(len(order), dtype=torch.long)
-    inv[torch.tensor(order)] = torch.arange(len(order))
-    return gathered[inv.to(gathered.device)]
+        for j, i in enumerate(shard_indices(n_images, r, world)):
+            pos[i] = r * per + j                     # image i sits in rank r's j-th row; pad rows are never addressed
+    return gathered[pos.to(gathered.device)]
+
+
+def run_sharded(process, n_images, rank, world):
+    """Data-parallel driver of independent images (infer_dir.py:198-200): this rank runs ``process(i) -> uint8 [C,H,W]``
+    for its images i = rank, rank + world, ...; ONE all-gather of the finished uint8 images; -> ``[n_images, C, H, W]``
+    in image order on every rank.  ``process`` must derive all of its randomness from ``i`` (per-image seeds), so the
+    result does not depend on the number of ranks."""
+    mine = [process(i) for i in shard_indices(n_images, rank, world)]
+    per = -(-n_images // world)
+    if not mine:
+        raise ValueError("run_sharded: more ranks than images")
+    while len(mine) < per:                           # equal shapes for the collective: pad with a copy, dropped by unshard
+        mine.append(mine[-1])
+    return unshard(gather_images(torch.stack(mine), world), n_images, world)

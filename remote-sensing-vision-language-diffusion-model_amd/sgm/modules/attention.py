@@ -18,6 +18,7 @@ from torch import nn
 
 from ... import ops
 from ..._lib import ACT_GEGLU
+from ...models.modules.DFBCache import RowSubset
 
 
 def zero_module(module):
@@ -69,6 +70,9 @@ class CrossAttention(nn.Module):
             q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
         else:
             q = ops.linear(x, rt.pk(self.to_q))
+            rows = None
+            if isinstance(context, RowSubset):   # a sub-batch of a cached context: project the full one, pick rows
+                context, rows = context.full, context.rows
             # valid only while the very same tensor object (held alive here) is passed, unmodified
             ent = rt._pk.get(("ctx_kv", id(self))) if rt.cache_context_kv else None
             if ent is not None and ent[0] is context and ent[1] == context._version:
@@ -77,6 +81,8 @@ class CrossAttention(nn.Module):
                 kv = ops.linear(context, rt.pk_cat([self.to_k, self.to_v], "kv"))
                 if rt.cache_context_kv:
                     rt._pk[("ctx_kv", id(self))] = (context, context._version, kv)
+            if rows is not None:
+                kv = kv.index_select(0, rows)
             k, v = kv[..., :inner], kv[..., inner:]
         o = ops.attention(q, k, v, heads=self.heads, scale=self.scale)
         return ops.linear(o, rt.pk(self.to_out[0]), residual=residual, alpha=alpha)

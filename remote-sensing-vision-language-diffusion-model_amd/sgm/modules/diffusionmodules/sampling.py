@@ -18,7 +18,8 @@ import numpy as np
 import torch
 
 from .... import ops
-from ....models.modules.DFBCache import get_can_use_cache_multi, get_current_cache_context
+from ....models.modules.DFBCache import (get_can_use_cache_multi, get_current_cache_context, relative_l1,
+                                         select_partial_info)
 from ...util import default, instantiate_from_config
 
 DEFAULT_GUIDER = {"target": "rsvld_amd.sgm.modules.diffusionmodules.guiders.IdentityGuider"}
@@ -55,6 +56,8 @@ class RestoreEDMSampler(BaseDiffusionSampler):
 
     # ---- sampling.py:548-596
     def denoise(self, x, denoiser, sigma, cond, uc, control_scale=1.0, threshold=0.1):
+        if isinstance(threshold, (list, tuple)):
+            return self._denoise_per_image(x, denoiser, sigma, cond, uc, control_scale, list(threshold))
         if threshold <= 0:
             denoised = denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc), control_scale=control_scale,
                                 fbcache_mode="none", partial_info=None)
@@ -63,7 +66,10 @@ class RestoreEDMSampler(BaseDiffusionSampler):
         context = get_current_cache_context()
         partial_info = denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc), control_scale=control_scale,
                                 fbcache_mode=self.fb_mode + "1", partial_info=None)
+        first = context.prev is None
         can_use_cache, cache_th = get_can_use_cache_multi(partial_info["h"], threshold=threshold, parallelized=False)
+        if getattr(context, "trace", None) is not None:   # [(threshold, measured diff, hit)] per image, one entry per step
+            context.trace.append([(float(threshold), None if first else float(cache_th), bool(can_use_cache))])
         if can_use_cache:
             if context.final_decode is not None:
                 return context.final_decode, threshold
@@ -74,6 +80,49 @@ class RestoreEDMSampler(BaseDiffusionSampler):
         denoised = self.guider(denoised, sigma)
         context.final_decode = denoised
         return denoised, cache_th
+
+    def _denoise_per_image(self, x, denoiser, sigma, cond, uc, control_scale, thresholds):
+        """A batch of B independent images with the feature cache ON: the reference only ever samples
+        one image (infer.py:172,199), so its whole-tensor test (:548-596, DFBCache.py:98-134) IS a per-image test.
+        Here the first UNet half runs on the full CFG batch, every image takes its own hit / miss decision against its
+        own threshold (rows b and B+b of the cache key), the second half runs on the sub-batch that missed, and the
+        guided predictions are scattered into the cached tensor.  Image b sees exactly the control flow, thresholds and
+        (batch-invariant kernels) values of a batch-of-1 run."""
+        B = x.shape[0]
+        context = get_current_cache_context()
+        x2, s2, c2 = self.guider.prepare_inputs(x, sigma, cond, uc)
+        partial_info = denoiser(x2, s2, c2, control_scale=control_scale, fbcache_mode=self.fb_mode + "1", partial_info=None)
+        h = partial_info["h"]
+        if context.prev is None:
+            diffs, hit = [None] * B, [False] * B                      # step 0: nothing to compare with (:123-124)
+        else:
+            diffs = relative_l1(context.prev, h, images=B)
+            hit = [d < t for d, t in zip(diffs, thresholds)]
+        trace = getattr(context, "trace", None)
+        if trace is not None:
+            trace.append([(float(t), None if d is None else float(d), bool(u)) for t, d, u in zip(thresholds, diffs, hit)])
+        miss = [b for b in range(B) if not hit[b]]
+        new_thr = [t if (hit[b] or diffs[b] is None) else diffs[b] for b, t in enumerate(thresholds)]
+        if not miss:
+            return context.final_decode, new_thr
+        if len(miss) == B:
+            context.prev = h
+            denoised = self.guider(denoiser(x2, s2, c2, control_scale=control_scale, fbcache_mode=self.fb_mode + "2",
+                                            partial_info=partial_info), sigma)
+            context.final_decode = denoised
+            return denoised, new_thr
+        idx = torch.tensor(miss, device=x.device)
+        rows = torch.cat([idx, idx + B])                                # [uc rows of the missed images; c rows]
+        context.prev = context.prev.index_copy(0, rows, h.index_select(0, rows))
+        sub = select_partial_info(partial_info, rows)
+        xs = x.index_select(0, idx)
+        ss = sigma[torch.tensor(miss)]
+        with ops.plan_units(len(miss)):                                 # the sub-batch holds len(miss) images
+            den = denoiser(torch.cat([xs] * 2), torch.cat([ss] * 2), c2, control_scale=control_scale,
+                           fbcache_mode=self.fb_mode + "2", partial_info=sub)
+        den = self.guider(den, ss)
+        context.final_decode = context.final_decode.index_copy(0, idx, den)
+        return context.final_decode, new_thr
 
     # ---- sampling.py:598-621
     def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None, gamma=0.0, x_center=None, eps_noise=None,

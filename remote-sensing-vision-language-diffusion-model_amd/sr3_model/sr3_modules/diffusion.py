@@ -168,7 +168,9 @@ class GaussianDiffusion(nn.Module):
         return xin
 
     @torch.no_grad()
-    def p_sample_loop(self, x_in, continous=False):
+    def p_sample_loop(self, x_in, continous=False, _max_steps=None, _stamp=None):
+        """``_max_steps`` / ``_stamp`` are measurement hooks (bench.py): run only the first ``_max_steps`` ancestral
+        steps, and call ``_stamp(name)`` at the phase borders (set-up | loop)."""
         if self._host is None:
             raise RsvldError("call set_new_noise_schedule() first")
         device = self.betas.device
@@ -189,10 +191,15 @@ class GaussianDiffusion(nn.Module):
         xin = self._pack_condition(cond, img)
         # one [T+1, B, 1] device table of noise levels instead of a host->device copy per step
         levels = torch.tensor(self._host["level"], device=device).view(T + 1, 1, 1).expand(T + 1, B, 1).contiguous()
-        for i in reversed(range(T)):
+        if _stamp is not None:
+            _stamp("s1_setup")
+        last = 0 if _max_steps is None else max(T - _max_steps, 0)
+        for i in reversed(range(last, T)):
             img = self.p_sample(img, i, condition_x=cond, _xin=xin, _levels=levels)
-            if i % sample_inter == 0:
+            if i % sample_inter == 0 or i == last:   # (a truncated loop also keeps the frame it stopped at)
                 ret_img = torch.cat([ret_img, img], dim=0)
+        if _stamp is not None:
+            _stamp("s1_loop")
         return ret_img if continous else ret_img[-1]
 
     @torch.no_grad()
@@ -201,8 +208,8 @@ class GaussianDiffusion(nn.Module):
         return self.p_sample_loop((batch_size, self.channels, s, s), continous)
 
     @torch.no_grad()
-    def super_resolution(self, x_in, continous=False):
-        return self.p_sample_loop(x_in, continous)
+    def super_resolution(self, x_in, continous=False, **hooks):
+        return self.p_sample_loop(x_in, continous, **hooks)
 
     def forward(self, x, *args, **kwargs):
         raise NotImplementedError("training (p_losses, diffusion.py:223-250) is outside the inference hot path")

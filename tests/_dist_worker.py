@@ -13,8 +13,8 @@ n_images = int(sys.argv[1])
 rank, world, _ = parallel.init_from_env(backend="gloo")
 idx = parallel.shard_indices(n_images, rank, world)
 # stand-in for the sampler: image i is a deterministic function of i only (per-image seeds)
-local = torch.stack([torch.full((3, 4, 4), float(i) / n_images * 2 - 1) for i in idx])
-allimgs = parallel.unshard(parallel.gather_images(parallel.to_uint8(local), world), n_images, world)
+allimgs = parallel.run_sharded(lambda i: parallel.to_uint8(torch.full((3, 4, 4), float(i) / n_images * 2 - 1)),
+                               n_images, rank, world)
 dist.barrier()
 print("RESULT " + json.dumps({"rank": rank, "idx": idx, "vals": allimgs[:, 0, 0, 0].tolist()}), flush=True)
 dist.destroy_process_group()

@@ -256,3 +256,39 @@ def test_tiled_restore_edm_sampler_vs_oracle(model, cuda):
     _cmp(got, want, 2e-2, "tiled sampler, 2 steps x 4 tiles")
     with pytest.raises(ValueError):
         sampler(denoiser, x0[:, :, :8, :8].to(cuda), dev({**cd, "control": zc[:, :, :8, :8]}), uc=dev({**ucd, "control": zc[:, :, :8, :8]}))
+
+
+def test_batched_cache_is_per_image(model, cuda):
+    """Feature cache ON with a batch (BASELINE configs[2]-[4]): image b of a batch of 4 takes the hit / miss
+    decisions, thresholds and output of its own batch-of-1 run -- traces equal, outputs bit-identical."""
+    from oracle import seeded
+    m, _ = model
+    B, steps = 4, 6
+    imgs = torch.cat([seeded.synthetic_image((1, 3, 64, 64), seed=s, smooth=3) for s in (80, 81, 82, 83)]).to(cuda)
+    kw = dict(p_p="", n_p="", img_threshold=0.3, dec_img=1.0, num_steps=steps, restoration_scale=-1, s_churn=5, s_noise=1.003,
+              cfg_scale=7.5, cfg_scale_start=4.0, use_linear_CFG=True, color_fix_type="Wavelet")
+    n_post, n_xt = S.rnd((B, 4, 8, 8), 95), S.rnd((B, 4, 8, 8), 96)
+    n_step = [S.rnd((B, 4, 8, 8), 100 + i) for i in range(steps)]
+
+    def run(x, sl):
+        draws = iter([n_xt] + n_step)
+        m._posterior_noise = lambda shape: n_post[sl]
+        m._randn_like = lambda t: next(draws)[sl].to(t.device)
+        try:
+            out = m.just_sampling(x, [""] * x.shape[0], **kw)
+            return out, [list(step) for step in m.cache_trace]
+        finally:
+            del m._posterior_noise, m._randn_like
+
+    both, tr_b = run(imgs, slice(0, B))
+    assert len(tr_b) == steps and all(len(step) == B for step in tr_b)
+    any_hit = False
+    for b in range(B):
+        one, tr_1 = run(imgs[b:b + 1], slice(b, b + 1))     # scalar threshold: the reference's own control flow (:548-596)
+        mine = [step[b] for step in tr_b]
+        print(f"image {b}: hits {[h for _, _, h in mine]}  thresholds {[round(t, 4) for t, _, _ in mine]}")
+        assert mine == [step[0] for step in tr_1], f"image {b}: cache trace differs between batched and single runs"
+        any_hit |= any(h for _, _, h in mine)
+        d = float((both[b:b + 1] - one).abs().max())
+        assert d == 0.0, f"image {b}: batched vs single max|d| = {d:.3e}"
+    assert any_hit, "no cache hit in the test: the threshold does not exercise the sub-batch path"

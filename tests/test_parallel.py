@@ -17,7 +17,17 @@ def test_two_rank_shard_and_gather():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    n = 8
+    _two_ranks(8)
+    _two_ranks(5)      # uneven: rank 0 holds 3 images, rank 1 holds 2 and pads
+
+
+def _two_ranks(n):
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
     worker = os.path.join(ROOT, "tests", "_dist_worker.py")
     procs = []
     for r in range(2):
@@ -29,7 +39,7 @@ def test_two_rank_shard_and_gather():
         assert p.returncode == 0, out
         res.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:]))
     res.sort(key=lambda d: d["rank"])
-    assert res[0]["idx"] == [0, 2, 4, 6] and res[1]["idx"] == [1, 3, 5, 7]
+    assert res[0]["idx"] == list(range(0, n, 2)) and res[1]["idx"] == list(range(1, n, 2))
     want = [int(round(((i / n * 2 - 1) + 1) * 0.5 * 255)) for i in range(n)]
     assert res[0]["vals"] == want and res[1]["vals"] == want    # both ranks hold all images, in image order
 
@@ -37,9 +47,12 @@ def test_two_rank_shard_and_gather():
 def test_shard_and_unshard_are_inverse():
     sys.path.insert(0, ROOT)
     from rsvld_amd import parallel
-    for n, world in ((8, 2), (64, 8), (16, 4)):
-        per = n // world
-        gathered = torch.cat([torch.tensor(parallel.shard_indices(n, r, world)[:per]) for r in range(world)])
-        assert parallel.unshard(gathered, n, world).tolist() == list(range(n))
+    for n, world in ((8, 2), (64, 8), (16, 4), (5, 4), (7, 2), (9, 4)):   # incl. uneven shards: short ranks pad their tail
+        per = -(-n // world)
+        rows = []
+        for r in range(world):
+            idx = parallel.shard_indices(n, r, world)
+            rows += idx + [idx[-1]] * (per - len(idx))
+        assert parallel.unshard(torch.tensor(rows), n, world).tolist() == list(range(n))
     x = torch.tensor([-2.0, -1.0, 0.0, 0.999, 1.0, 3.0])
     assert parallel.to_uint8(x).tolist() == [0, 0, 128, 255, 255, 255]
