@@ -167,7 +167,9 @@ def roofline_of(summ, pmc_file):
     traffic, src = None, None
     path = os.path.join(ROOT, "profiles", pmc_file)
     if os.path.exists(path):
-        k = json.load(open(path)).get("kernels", {}).get(dom["name"])
+        alias = {"attention_d64": "attn_d64", "attention_d512": "attn_d512", "gemm_256x256": "gemm256"}
+        kern = json.load(open(path)).get("kernels", {})
+        k = kern.get(dom["name"], kern.get(alias.get(dom["name"], "")))
         if k is not None:
             traffic, src = round(k["hbm_bytes_per_launch"]), f"profiles/{pmc_file}"
     return {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",

@@ -61,6 +61,7 @@ class PipelineConfig:
     encoder_tile_size: int = 512
     decoder_tile_size: int = 64
     sr3_steps: int = 0            # 0 = the option file's 'val' schedule (500 steps, configs/sr_sr3.json)
+    allow_random_init: bool = False   # tests / benchmarks only: run without checkpoints on seeded random weights
 
     def __post_init__(self):
         self.output_dir = Path(self.output_dir)
@@ -86,7 +87,9 @@ class SuperResolutionPipeline:
         self.sr3_model.set_new_noise_schedule(sched, schedule_phase="val")
 
     def _load_refinement_model(self):
-        self.refinement_model = create_SR_model(self.cfg.model_yaml)
+        self.refinement_model = create_SR_model(self.cfg.model_yaml, allow_random_init=self.cfg.allow_random_init)
+        if self.refinement_model is None:
+            raise RuntimeError(f"{self.cfg.model_yaml}: SR_CKPT is null, there are no pretrained weights to refine with")
         self.refinement_model.to(self.cfg.sr_model_device)
         if self.cfg.use_tile_vae:
             self.refinement_model.init_tile_vae(self.cfg.encoder_tile_size, self.cfg.decoder_tile_size)

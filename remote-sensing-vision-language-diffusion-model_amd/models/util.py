@@ -27,15 +27,31 @@ def load_config(path):
         return AttrDict(yaml.safe_load(f))
 
 
-def create_SR_model(config_path, load_default_setting=False):
-    """yaml -> SR_backbone, then the two checkpoints (SDXL base, SR adapter) with strict=False, exactly
-    the order of models/util.py:93-108.  Missing checkpoint files are skipped (random init)."""
+def create_SR_model(config_path, load_default_setting=False, allow_random_init=False):
+    """yaml -> SR_backbone, then the two checkpoints (SDXL base, SR adapter) with strict=False, in the order of
+    models/util.py:93-108.  Like the reference, ``SR_CKPT: null`` means "no pretrained weights" and returns None --
+    unless ``allow_random_init`` (tests, benchmarks) asks for the randomly initialised model.  A CONFIGURED checkpoint
+    path that does not exist raises FileNotFoundError (the reference fails inside torch.load): nothing is skipped
+    silently."""
+    import logging
+    log = logging.getLogger("rsvld_amd")
     config = load_config(config_path)
     model = instantiate_from_config(config.model).cpu()
-    for key in ("SR_CKPT", "SR_CKPT_Q"):
-        path = config.get(key)
-        if path is not None and os.path.exists(path):
-            model.load_state_dict(load_state_dict(path), strict=False)
+    if config.get("SR_CKPT") is None:
+        if not allow_random_init:
+            print("There are no pretrained weights.")
+            return None
+        log.warning("create_SR_model: SR_CKPT is null, returning a RANDOMLY INITIALISED model (allow_random_init=True)")
+    else:
+        for key in ("SR_CKPT", "SR_CKPT_Q"):
+            path = config.get(key)
+            if path is None or not os.path.exists(path):
+                raise FileNotFoundError(f"create_SR_model: {key} = {path!r} (from {config_path}) does not exist")
+            res = model.load_state_dict(load_state_dict(path), strict=False)
+            log.info("create_SR_model: loaded %s (%d missing, %d unexpected keys)", path, len(res.missing_keys),
+                     len(res.unexpected_keys))
+            if res.unexpected_keys:
+                log.warning("create_SR_model: unexpected keys in %s, e.g. %s", path, res.unexpected_keys[:5])
     if load_default_setting:
         return model, config.default_setting
     return model

@@ -39,8 +39,10 @@ class ControlWrapper(nn.Module):
         if not x.is_cuda:
             raise RsvldError("ControlWrapper runs on the GPU only")
         dt = self._compute_dtype()
-        self.diffusion_model.compute_dtype = dt
-        self.control_model.compute_dtype = dt
+        for net in (self.diffusion_model, self.control_model):
+            if net.compute_dtype != dt:          # the packed 16-bit weights are per dtype
+                net.compute_dtype = dt
+                net.invalidate_packed()
         context = c.get("crossattn", None)
         if context is not None and context.dtype != dt:
             cached = getattr(self, "_ctx_cast", None)

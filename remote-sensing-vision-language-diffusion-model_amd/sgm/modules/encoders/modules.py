@@ -293,6 +293,12 @@ class PreparedConditioner(nn.Module):
     @torch.no_grad()
     def forward(self, batch: Dict, return_uc=False) -> Dict:
         n = batch["control"].shape[0]
+        if not getattr(self, "_warned_txt", False) and any(str(t).strip() for t in batch.get("txt", [])):
+            import logging   # same behaviour as the reference class (it never reads batch['txt']) -- but say so once
+            logging.getLogger("rsvld_amd").warning(
+                "PreparedConditioner: the caption / a_prompt / n_prompt text is NOT used; conditioning comes from the cached "
+                "embeddings only (build them for your prompts with tools/build_cached_cond.py, or use juggernautXL.yaml)")
+            self._warned_txt = True
         output = {}
         for k, v in self.state_dict().items():
             if k.endswith("_uc") != return_uc:

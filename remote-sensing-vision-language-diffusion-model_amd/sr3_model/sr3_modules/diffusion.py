@@ -139,9 +139,11 @@ class GaussianDiffusion(nn.Module):
         unet = self.denoise_fn
         if not self.use_graph:
             return unet.forward_nhwc(xin, level)
-        key = (tuple(xin.shape), xin.dtype, xin.device.index)
+        # the graph holds raw pointers into the packed weights: key it on their version and drop stale captures
+        key = (tuple(xin.shape), xin.dtype, xin.device.index, unet.pack_version)
         ent = self._graphs.get(key)
         if ent is None:
+            self._graphs = {k: v for k, v in self._graphs.items() if k[3] == unet.pack_version}
             s_x, s_l = torch.empty_like(xin), torch.empty_like(level)
             s_x.copy_(xin)
             s_l.copy_(level)

@@ -148,15 +148,24 @@ class UNet(nn.Module):
         self._pk = None                      # packed weights, built lazily on the parameters' device
 
     # ------------------------------------------------------------------ weight packing
+    # ``pack_version`` counts invalidations: anything that holds raw pointers into the packed tensors (the sampler's
+    # captured hipGraphs) keys itself on it and is rebuilt after a weight reload / move / dtype change.
+    pack_version = 0
+
     def invalidate_packed(self):
         self._pk = None
+        self.pack_version += 1
 
     def load_state_dict(self, *a, **k):
-        self._pk = None
+        self.invalidate_packed()
         return super().load_state_dict(*a, **k)
 
+    def _load_from_state_dict(self, *a, **k):   # reached when a PARENT module's load_state_dict recurses into this one
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*a, **k)
+
     def _apply(self, fn, *a, **k):  # .to(device) / .half() etc. move the fp32 masters
-        self._pk = None
+        self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 
     def _res_blocks(self):

@@ -27,7 +27,8 @@ def product_params():
     for k in ("control_stage_config", "network_config"):
         cfg[k]["params"].update(copy.deepcopy(SMALL))
     c, uc = cond_dicts()
-    cfg["conditioner_config"]["params"] = {"cond_pth": c, "un_cond_pth": uc}
+    cfg["conditioner_config"] = {"target": "rsvld_amd.sgm.modules.PreparedConditioner",   # the reference's cached-embedding class
+                                 "params": {"cond_pth": c, "un_cond_pth": uc}}
     return cfg
 
 

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def test_pipeline_cli_flow(cuda, tmp_path):
     from PIL import Image
     from rsvld_amd import infer
-    cfg = yaml.safe_load(open(S.YAML))
+    cfg = yaml.safe_load(open(S.YAML.replace("juggernautXL.yaml", "juggernautXL_cached.yaml")))
     for k in ("control_stage_config", "network_config"):
         cfg["model"]["params"][k]["params"].update(S.SMALL)
     c, uc = S.cond_dicts()
@@ -31,6 +31,7 @@ def test_pipeline_cli_flow(cuda, tmp_path):
     lr = Image.fromarray(rng.integers(0, 255, (24, 32, 3), dtype=np.uint8))
     lr.save(tmp_path / "tile.png")
     pc = infer.PipelineConfig(input_img=str(tmp_path / "tile.png"), output_dir=str(tmp_path / "out"), model_yaml=str(ypath),
+                              allow_random_init=True,
                               upscale_factor=2, min_size=128, edm_steps=3, sr3_steps=3, seed=1, img_threshold=0.3)
     pipe = infer.SuperResolutionPipeline(pc)
     # zero-initialised output convs would make Stage 2 a no-op: give them small seeded weights

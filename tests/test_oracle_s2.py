@@ -159,10 +159,16 @@ def test_create_sr_model_loads_both_checkpoints_in_reference_order(model, tmp_pa
             want = sd[k] - 0.25 if k in adapter else (sd[k] + 0.5 if k in base else sd[k])
             assert torch.equal(now[k], want), k
         assert default_setting["s_cfg_Quality"] == 7.5
-        cfg["SR_CKPT"] = str(tmp_path / "missing.safetensors")     # an absent file is skipped (random-init runs)
+        cfg["SR_CKPT"] = str(tmp_path / "missing.safetensors")     # a configured but absent checkpoint is an error, never skipped
         with open(tmp_path / "m2.yaml", "w") as f:
             yaml.safe_dump(cfg, f)
-        assert U.create_SR_model(str(tmp_path / "m2.yaml")) is m
+        with pytest.raises(FileNotFoundError):
+            U.create_SR_model(str(tmp_path / "m2.yaml"))
+        cfg["SR_CKPT"] = None                                       # models/util.py:101-103: "There are no pretrained weights."
+        with open(tmp_path / "m3.yaml", "w") as f:
+            yaml.safe_dump(cfg, f)
+        assert U.create_SR_model(str(tmp_path / "m3.yaml")) is None
+        assert U.create_SR_model(str(tmp_path / "m3.yaml"), allow_random_init=True) is m
     finally:
         m.load_state_dict(sd)
 
