@@ -284,8 +284,11 @@ def restore_edm_step(sd, table, cache, x, i, sigmas, c, uc, x_center, opt, thres
     if gamma > 0:
         eps = randn(x.shape) * opt["s_noise"]
         x = x + eps * ((sigma_hat ** 2 - sigma ** 2)[:, None, None, None]) ** 0.5
+    control_scale = opt["control_scale"]
+    if opt.get("use_linear_control_scale"):   # :608-609
+        control_scale = (float(sigma[0]) / 14.6146) * (opt.get("control_scale_start", 0.0) - control_scale) + control_scale
     d, threshold = restore_edm_denoise(sd, table, cache, x, sigma_hat, c, uc, opt["scale"], opt["scale_min"],
-                                       opt["control_scale"], threshold, trace)
+                                       control_scale, threshold, trace)
     if nxt[0] > 0.05 and opt["restore_cfg"] > 0:
         d = d - (d - x_center) * ((sigma.view(-1, 1, 1, 1) / 14.6146) ** opt["restore_cfg"])
     dd = (x - d) / sigma_hat[:, None, None, None]
@@ -447,6 +450,9 @@ def just_sampling(sd, x, cond, uncond, opt, randn=None, trace=None):
     cfg_scale, cfg_scale_start, use_linear_CFG, restoration_scale, control_scale, img_threshold, dec_img,
     color_fix_type.  ``randn(shape)`` supplies draws in the reference's order."""
     randn = randn or (lambda shape: torch.randn(shape))
+    if opt.get("num_samples", 1) > 1:   # :231-235
+        assert x.shape[0] == 1
+        x = x.repeat(opt["num_samples"], 1, 1, 1)
     N = x.shape[0]
     table = legacy_ddpm_sigmas(1000, append_zero=False, flip=True)   # denoiser buffer (denoiser.py:41-44)
     _z = encode_with_denoise(sd, x)
@@ -460,7 +466,8 @@ def just_sampling(sd, x, cond, uncond, opt, randn=None, trace=None):
     z = z * torch.sqrt(1.0 + sigmas[0] ** 2.0)
     sopt = dict(s_churn=opt["s_churn"], s_noise=opt["s_noise"], restore_cfg=opt["restoration_scale"],
                 scale=opt["cfg_scale_start"] if opt["use_linear_CFG"] else opt["cfg_scale"], scale_min=opt["cfg_scale"],
-                control_scale=opt["control_scale"])
+                control_scale=opt["control_scale"], use_linear_control_scale=opt.get("use_linear_control_scale", False),
+                control_scale_start=opt.get("control_scale_start", 0.0))
     cache, thr, x_center = Cache(), opt["img_threshold"], z_stage1
     for i in range(len(sigmas) - 1):
         z, thr = restore_edm_step(sd, table, cache, z, i, sigmas, c, uc, x_center, sopt, thr, randn, trace)

@@ -38,3 +38,12 @@ def rnd(shape, seed, scale=1.0):
 
 PIPE_OPT = dict(num_steps=6, s_churn=5, s_noise=1.003, cfg_scale=7.5, cfg_scale_start=4.0, use_linear_CFG=True,
                 restoration_scale=-1, control_scale=1.0, img_threshold=0.3, dec_img=1.0, color_fix_type="Wavelet")
+
+# variants of PIPE_OPT pinned by tests/golden/s2_branches.npz (gen_s2_branches_golden.py): branches the default call does not take
+BRANCHES = {
+    "restore": dict(restoration_scale=4.0),                                        # sampling.py:614-616
+    "lincs": dict(use_linear_control_scale=True, control_scale_start=0.3),         # sampling.py:608-609
+    "adain": dict(color_fix_type="AdaIn"),                                         # utils/colorfix.py:44-71
+    "ns2": dict(num_samples=2, img_threshold=0.0),                                 # SR_model.py:231-235
+}
+STEP_OPT = dict(num_steps=50, s_churn=5, s_noise=1.003, restore_cfg=4.0, cfg_scale=7.5, cfg_scale_start=4.0)

@@ -47,7 +47,7 @@ def _n(t, channels=None):
 
 def test_ops_vs_reference_golden(model, cuda, golden_dir):
     """ResBlock / SpatialTransformer / Down / Up / ZeroSFT (3 variants) / ZeroCrossAttn (2) / embedding.
-    Tolerance 6e-3 x range (fp16 operands through 2-20 layers)."""
+    Tolerance 2e-3 x range (fp16 operands through 2-20 layers; measured worst 9.5e-4 x range, st_1280)."""
     from rsvld_amd import ops
     m, _ = model
     unet = m.model.diffusion_model
@@ -57,7 +57,7 @@ def test_ops_vs_reference_golden(model, cuda, golden_dir):
     rows = unet.emb_rows(emb)
     x320, x640, x1280 = S.rnd((2, 320, 8, 8), 52), S.rnd((2, 640, 4, 4), 53), S.rnd((2, 1280, 4, 4), 54)
     pm = unet.project_modules
-    R = 6e-3
+    R = 2e-3
     _cmp(_n(unet.input_blocks[1][0].run(unet, _h(x320, cuda), rows)), z["op.res_320"], R, "res_320")
     _cmp(_n(unet.input_blocks[4][0].run(unet, _h(S.rnd((2, 320, 4, 4), 55), cuda), rows)), z["op.res_320_640"], R, "res_320_640")
     _cmp(_n(unet.input_blocks[4][1].run(unet, _h(x640, cuda), ctx)), z["op.st_640"], R, "st_640")
@@ -85,13 +85,17 @@ def test_networks_vs_reference_golden(model, cuda, golden_dir):
     c = {"crossattn": ctx, "vector": y, "control": xc}
     w = m.model
     part = w(xt, t, c, 1.0, "input_stage1", None)
-    _cmp(_n(part["control"][9]), z["control.9"], 1e-2, "control[9]")
-    _cmp(_n(part["h"]), z["unet.h"], 1e-2, "unet stage-1 h (cache key)")
+    _cmp(_n(part["control"][9]), z["control.9"], 3e-3, "control[9]")              # measured 1.4e-3 x range
+    for i in range(10):   # all 10 ControlNet maps: the golden keeps a 4096-point strided subsample + 3 moments of each
+        f = _n(part["control"][i]).cpu().float()
+        fp = torch.cat([f.flatten()[:: max(1, f.numel() // 4096)], torch.stack([f.mean(), f.abs().mean(), f.std()])])
+        _cmp(fp, z[f"control.{i}.fp"], 3e-3, f"control[{i}] fingerprint")
+    _cmp(_n(part["h"]), z["unet.h"], 3.5e-3, "unet stage-1 h (cache key)")         # measured 1.7e-3 x range
     two = w(xt, t, c, 1.0, "input_stage2", part)
     full = w(xt, t, c, 1.0, "none", None)
     assert torch.equal(full, two), "none != stage1 o stage2 (must be bit-identical, SURVEY.md App. B)"
-    _cmp(_n(full, 4), z["unet.out"], 1.5e-2, "unet eps")
-    _cmp(_n(w(xt, t, c, 0.8, "none", None), 4), z["unet.out_cs08"], 1.5e-2, "unet eps, control_scale 0.8")
+    _cmp(_n(full, 4), z["unet.out"], 2.5e-3, "unet eps")                            # measured 1.0e-3 x range
+    _cmp(_n(w(xt, t, c, 0.8, "none", None), 4), z["unet.out_cs08"], 2.5e-3, "unet eps, control_scale 0.8")
 
 
 def test_denoiser_and_guider_vs_oracle(model, cuda):
@@ -110,11 +114,12 @@ def test_denoiser_and_guider_vs_oracle(model, cuda):
     dev = lambda d: {k: v.to(cuda) for k, v in d.items()}
     inp = g.prepare_inputs(x.to(cuda), sigma, dev(c), dev(uc))
     got = g(m.denoiser(m.model, *inp, control_scale=1.0, fbcache_mode="none", partial_info=None), sigma)
-    _cmp(got, want, 1.5e-2, "guided x0 prediction at sigma 7.3")
+    _cmp(got, want, 6e-3, "guided x0 prediction at sigma 7.3")                       # measured 2.8e-3 x range
 
 
 def test_vae_and_colorfix_vs_reference_golden(model, cuda, golden_dir):
-    """VAE in bf16 (8-bit mantissa) vs fp32 goldens: 4e-2 x range; posterior/colour-fix kernels are fp32: 1e-5."""
+    """VAE in bf16 (8-bit mantissa) vs fp32 goldens; bounds = 2 x the measured error (in units of each tensor's range:
+    bf16 moments 1.4e-2, decode 9.8e-3, denoise-encode 1.1e-2; fp16 2.0e-3 / 1.2e-3); posterior/colour-fix kernels are fp32."""
     from oracle import seeded
     from rsvld_amd import ops
     from rsvld_amd.utils import colorfix
@@ -122,12 +127,12 @@ def test_vae_and_colorfix_vs_reference_golden(model, cuda, golden_dir):
     z = np.load(os.path.join(golden_dir, "s2_vae_colorfix.npz"))
     img = seeded.synthetic_image((1, 3, 64, 64), seed=80, smooth=3).to(cuda)
     fs = m.first_stage_model
-    _cmp(_n(fs.moments(img)), z["moments"], 4e-2, "VAE moments (bf16)")
-    _cmp(m.decode_first_stage(S.rnd((1, 4, 8, 8), 81).to(cuda)), z["decoded"], 4e-2, "VAE decode (bf16)")
-    _cmp(m.encode_first_stage_with_denoise(img, use_sample=False), z["z_denoise"], 4e-2, "denoise-encoder mode")
+    _cmp(_n(fs.moments(img)), z["moments"], 3e-2, "VAE moments (bf16)")
+    _cmp(m.decode_first_stage(S.rnd((1, 4, 8, 8), 81).to(cuda)), z["decoded"], 2e-2, "VAE decode (bf16)")
+    _cmp(m.encode_first_stage_with_denoise(img, use_sample=False), z["z_denoise"], 2.5e-2, "denoise-encoder mode")
     fs.set_compute_dtype(torch.float16)
-    _cmp(_n(fs.moments(img)), z["moments"], 6e-3, "VAE moments (fp16)")
-    _cmp(m.decode_first_stage(S.rnd((1, 4, 8, 8), 81).to(cuda)), z["decoded"], 6e-3, "VAE decode (fp16)")
+    _cmp(_n(fs.moments(img)), z["moments"], 4e-3, "VAE moments (fp16)")
+    _cmp(m.decode_first_stage(S.rnd((1, 4, 8, 8), 81).to(cuda)), z["decoded"], 2.5e-3, "VAE decode (fp16)")
     fs.set_compute_dtype(torch.bfloat16)
     a, b = S.rnd((2, 3, 48, 40), 82).to(cuda), (S.rnd((2, 3, 48, 40), 83, 0.5) + 0.2).to(cuda)
     _cmp(colorfix.wavelet_reconstruction(a, b), z["wavelet"], 1e-6, "wavelet_reconstruction")
@@ -139,8 +144,16 @@ def test_vae_and_colorfix_vs_reference_golden(model, cuda, golden_dir):
     _cmp(ops.gaussian_sample(mom, 4, noise.to(cuda), 0.13025), want, 1e-6, "posterior sample")
 
 
+# end-to-end bounds per VAE compute type: (max|d|, mean|d|) = 2 x measured on an output of range 2.2-2.4.  bf16 is the
+# reference's ae_dtype (SR_model.py:28-33) and dominates the error (its decode alone is 1e-2 x range); with the VAE in
+# fp16 what is left is the fp16 UNet/ControlNet over 6 steps.  north_star's 1e-3 is an fp32-vs-fp32 figure: the reference's
+# own GPU path (autocast bf16 VAE + fp16 UNet) sits at the same distance from its CPU path.
+PIPE_BOUNDS = {"bf16": (7e-2, 1e-2), "fp16": (1.2e-2, 2e-3)}
+
+
+@pytest.mark.parametrize("vae", ["bf16", "fp16"])
 @pytest.mark.parametrize("tag", ["nocache", "cache"])
-def test_just_sampling_vs_reference_golden(model, cuda, golden_dir, tag):
+def test_just_sampling_vs_reference_golden(model, cuda, golden_dir, tag, vae):
     """The whole Stage-2 pipeline with the reference's RNG order (CPU generator), 6 steps.  The cache trace
     (hit/miss per step and the diff that replaces the threshold) must reproduce the reference's decisions."""
     from oracle import seeded
@@ -159,7 +172,7 @@ def test_just_sampling_vs_reference_golden(model, cuda, golden_dir, tag):
     RS.get_can_use_cache_multi = spy
     try:
         m.noise_source = "cpu"
-        m.first_stage_model.set_compute_dtype(torch.float16 if os.environ.get("RSVLD_VAE_FP16") else torch.bfloat16)
+        m.first_stage_model.set_compute_dtype(torch.float16 if vae == "fp16" else torch.bfloat16)
         torch.manual_seed(7)
         thr = opt["img_threshold"] if tag == "cache" else 0.0
         out = m.just_sampling(img, [""], p_p="", n_p="", img_threshold=thr, dec_img=opt["dec_img"], num_steps=opt["num_steps"],
@@ -169,16 +182,17 @@ def test_just_sampling_vs_reference_golden(model, cuda, golden_dir, tag):
     finally:
         RS.get_can_use_cache_multi = orig
         m.noise_source = "device"
+        m.first_stage_model.set_compute_dtype(torch.bfloat16)
     want = torch.tensor(z[f"{tag}.final"])
     d = (out.cpu() - want).abs()
-    print(f"just_sampling[{tag}]: max|d| = {float(d.max()):.3e}, mean|d| = {float(d.mean()):.3e} (range {float(want.abs().max()):.2f})")
+    print(f"just_sampling[{tag}, VAE {vae}]: max|d| = {float(d.max()):.3e}, mean|d| = {float(d.mean()):.3e} (range {float(want.abs().max()):.2f})")
     print("   cache trace:", [(round(a, 4), round(b, 4), h) for a, b, h in trace])
     wt = z[f"{tag}.trace"]
     assert len(trace) == len(wt)
     for (a, b, h), w in zip(trace, wt):
         assert bool(w[2]) == h, "cache decision flipped vs the reference"
         assert abs(b - w[1]) < 2e-2 * max(1.0, w[1])
-    assert float(d.mean()) < 2e-2 and float(d.max()) < 0.25
+    assert float(d.max()) < PIPE_BOUNDS[vae][0] and float(d.mean()) < PIPE_BOUNDS[vae][1]
 
 
 def test_batched_sampling_is_per_image(model, cuda):
@@ -203,7 +217,7 @@ def test_batched_sampling_is_per_image(model, cuda):
     one = torch.cat([run(imgs[i:i + 1], slice(i, i + 1)) for i in range(2)])
     d = float((both - one).abs().max())
     print("batch-of-2 vs 2 x batch-of-1: max|d| =", d)
-    assert d < 2e-2
+    assert d == 0.0        # batch-invariant launch plans (ops.plan_units): bit-identical
 
 
 def test_tile_blend_kernels(cuda):
@@ -253,7 +267,7 @@ def test_tiled_restore_edm_sampler_vs_oracle(model, cuda):
 
     got = sampler(denoiser, x0.to(cuda), dev({**cd, "control": zc}), uc=dev({**ucd, "control": zc}), x_center=xc.to(cuda))
     assert got.shape == (1, 4, 24, 24)
-    _cmp(got, want, 2e-2, "tiled sampler, 2 steps x 4 tiles")
+    _cmp(got, want, 6e-3, "tiled sampler, 2 steps x 4 tiles")                         # measured 2.6e-3 x range
     with pytest.raises(ValueError):
         sampler(denoiser, x0[:, :, :8, :8].to(cuda), dev({**cd, "control": zc[:, :, :8, :8]}), uc=dev({**ucd, "control": zc[:, :, :8, :8]}))
 

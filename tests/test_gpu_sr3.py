@@ -82,14 +82,15 @@ def test_unet_layers_teacher_forced(sr3, cuda, golden_dir):
         scale = float(np.abs(want).max())
         e = _err(got, want)
         report[name] = (e, scale)
-        assert e <= 5e-3 * scale + 1e-4, f"{name}: max|d|={e:.3e} range={scale:.3e}"
+        assert e <= 1.5e-3 * scale + 1e-4, f"{name}: max|d|={e:.3e} range={scale:.3e}"   # measured worst 7.0e-4 x range
     print("per-layer max|d| / range:", {k: f"{e:.2e}/{s:.2f}" for k, (e, s) in report.items()})
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_unet_forward_vs_reference_golden(sr3, cuda, golden_dir, tag):
     """Whole UNet forward (26 res-blocks, 4 attention sites) vs the reference's fp32 output.
-    Tolerance: 2e-2 absolute on an output of range ~2.3 (fp16 storage through ~60 layers)."""
+    Tolerance: 1e-2 absolute / 1.5e-3 mean on an output of range ~2.3 (fp16 storage through ~60 layers; measured
+    4.9e-3 / 7.3e-4)."""
     from oracle import seeded
     net, _ = sr3
     z = np.load(os.path.join(golden_dir, "sr3_unet_forward.npz"))
@@ -100,12 +101,12 @@ def test_unet_forward_vs_reference_golden(sr3, cuda, golden_dir, tag):
     e = _err(y, z[f"{tag}.y"])
     print(f"unet forward {tag}: max|d| = {e:.3e}, mean|d| = "
           f"{float((y.cpu() - torch.tensor(z[f'{tag}.y'])).abs().mean()):.3e}")
-    assert e < 2e-2
+    assert e < 1e-2 and float((y.cpu() - torch.tensor(z[f'{tag}.y'])).abs().mean()) < 1.5e-3
 
 
 @pytest.mark.parametrize("t", [9, 1, 0])
 def test_p_sample_vs_reference_golden(sr3, cuda, golden_dir, t):
-    """One ancestral step with the reference's noise draw (CPU generator). Tolerance 5e-3."""
+    """One ancestral step with the reference's noise draw (CPU generator). Tolerance 3e-4 (measured 1.4e-4)."""
     net, _ = sr3
     net.set_new_noise_schedule(dict(schedule="linear", n_timestep=10, linear_start=1e-6, linear_end=1e-2), cuda)
     net.noise_source = "cpu"
@@ -114,7 +115,7 @@ def test_p_sample_vs_reference_golden(sr3, cuda, golden_dir, t):
     out = net.p_sample(torch.tensor(z["x"]).to(cuda), t, condition_x=torch.tensor(z["cond"]).to(cuda))
     e = _err(out, z[f"t{t}.out"])
     print(f"p_sample t={t}: max|d| = {e:.3e}")
-    assert e < 5e-3
+    assert e < 3e-4
 
 
 def test_pipeline_config1_vs_reference_golden(sr3, cuda, golden_dir):
@@ -136,9 +137,9 @@ def test_pipeline_config1_vs_reference_golden(sr3, cuda, golden_dir):
     lsb = np.abs(u8a.astype(int) - u8b.astype(int))
     print(f"config-1 pipeline: max|d| = {float(d.max()):.3e}, mean|d| = {float(d.mean()):.3e}, "
           f"uint8 equal = {float((lsb == 0).mean()):.4f}, max LSB diff = {int(lsb.max())}")
-    assert float(d.mean()) < 2e-3
-    assert float(d.max()) < 5e-2
-    assert int(lsb.max()) <= 6
+    # north_star: |d| < 1e-3 per pixel.  Measured: max 9.9e-4, mean 1.0e-4, 98.7 % of the 8-bit hand-off identical, 1 LSB.
+    assert float(d.max()) < 2e-3 and float(d.mean()) < 2e-4
+    assert float((lsb == 0).mean()) >= 0.98 and int(lsb.max()) <= 1
 
 
 def test_unet_forward_vs_oracle_fresh_input(sr3, cuda):
@@ -152,4 +153,4 @@ def test_unet_forward_vs_oracle_fresh_input(sr3, cuda):
     got = net.denoise_fn(x.to(cuda), lv.to(cuda))
     e = _err(got, want)
     print(f"unet vs oracle 48x80: max|d| = {e:.3e}")
-    assert e < 2e-2
+    assert e < 8e-3          # measured 4.0e-3

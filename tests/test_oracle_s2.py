@@ -105,6 +105,50 @@ def test_oracle_vae_colorfix(model, golden_dir):
     assert _d(O.adain(a, b), z["adain"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["restore", "lincs", "adain", "ns2"])
+def test_oracle_pipeline_branches(model, golden_dir, tag):
+    """The branches the default call does not take (restore pull, linear control scale, AdaIN, num_samples = 2),
+    each against the reference's own output (tests/golden/s2_branches.npz)."""
+    _, sd = model
+    z = np.load(os.path.join(golden_dir, "s2_branches.npz"))
+    img = seeded.synthetic_image((1, 3, 64, 64), seed=80, smooth=3)
+    c, uc = S.cond_dicts()
+    trace = []
+    torch.manual_seed(7)
+    out = O.just_sampling(sd, img, c, uc, dict(S.PIPE_OPT, **S.BRANCHES[tag]), trace=trace)
+    assert _d(out, z[f"pipe.{tag}.final"]) < 1e-4
+    want = z[f"pipe.{tag}.trace"]
+    assert len(trace) == len(want)
+    for (a, b, h), w in zip(trace, want):
+        assert bool(w[2]) == h and abs(a - w[0]) < 1e-4 and abs(b - w[1]) < 1e-3
+
+
+@pytest.mark.parametrize("i", [0, 1, 49])
+def test_oracle_sampler_step(model, golden_dir, i):
+    """G3: RestoreEDMSampler.step at the first, second and last step of a 50-step schedule, churn noise by seed:
+    a miss, then a forced hit on a different latent (the cached prediction is reused)."""
+    _, sd = model
+    z = np.load(os.path.join(golden_dir, "s2_branches.npz"))
+    o = S.STEP_OPT
+    sigmas = O.legacy_ddpm_sigmas(o["num_steps"])
+    assert np.array_equal(sigmas.numpy(), z["step.sigmas"])
+    table = O.legacy_ddpm_sigmas(1000, append_zero=False, flip=True)
+    c0, uc0 = S.cond_dicts()
+    _z, x_center = S.rnd((1, 4, 8, 8), 201, 0.8), S.rnd((1, 4, 8, 8), 202, 0.8)
+    c, uc = dict(c0, control=_z), dict(uc0, control=_z)
+    sopt = dict(s_churn=o["s_churn"], s_noise=o["s_noise"], restore_cfg=o["restore_cfg"], scale=o["cfg_scale_start"],
+                scale_min=o["cfg_scale"], control_scale=1.0)
+    cache = O.Cache()
+    torch.manual_seed(1000 + i)
+    x_miss, t_miss = O.restore_edm_step(sd, table, cache, torch.tensor(z[f"step.i{i}.x_in"]), i, sigmas, c, uc, x_center, sopt,
+                                        1e-9, torch.randn)
+    torch.manual_seed(2000 + i)
+    x_hit, t_hit = O.restore_edm_step(sd, table, cache, torch.tensor(z[f"step.i{i}.x_in2"]), i, sigmas, c, uc, x_center, sopt,
+                                      1e9, torch.randn)
+    assert _d(x_miss, z[f"step.i{i}.miss"]) < 2e-4 and _d(x_hit, z[f"step.i{i}.hit"]) < 2e-4
+    assert [t_miss, t_hit] == list(z[f"step.i{i}.thr"])
+
+
 @pytest.mark.parametrize("tag", ["cache", "nocache"])
 def test_oracle_pipeline(model, golden_dir, tag):
     """just_sampling end to end (VAE x4, conditioner, 6 sampler steps, cache decisions, wavelet fix)."""

@@ -76,7 +76,7 @@ def test_oracle_tiled_vae(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt,rel", [(torch.float16, 8e-3), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("dt,rel", [(torch.float16, 5e-3), (torch.bfloat16, 3e-2)])   # 2 x measured (2.3e-3 / 1.5e-2 x range)
 def test_hip_vaehook_vs_reference_golden(cuda, golden_dir, dt, rel):
     """The product's VAEHook (all tiles HBM-resident, merged GroupNorm statistics) against the reference's
     VAEHook output.  fp16 storage: 8e-3 x range; bf16 (the reference's ae_dtype): 5e-2 x range."""
