@@ -5,8 +5,9 @@ Stage 1 SR3 upscale -> uint8 hand-off -> [caption] -> Stage 2 refinement -> PNG.
         --img_threshold 0.3 --edm_steps 50 [--no_llava] [--caption "..."] [--sr3_steps 50]
 
 Both diffusion stages run on ONE MI355X through librsvld_hip.so.  The LLaVA-Next captioner stays on stock
-PyTorch-ROCm and is optional here (``--caption`` supplies the text, empty = prompt-free like ``no_llava``);
-loading it needs network access for the checkpoints, which this build does not assume."""
+PyTorch-ROCm (rsvld_amd.llava_next: SDPA attention, seeded sampling); ``--no_llava`` skips it like the reference's
+``no_llava`` and ``--caption`` supplies the text directly.  Its checkpoints must already be on disk
+(``--llava_path`` / ``--llava_adapter``): nothing is fetched from the network."""
 import argparse
 from dataclasses import dataclass
 from pathlib import Path
@@ -55,8 +56,13 @@ class PipelineConfig:
     spt_linear_s_stage2: float = 0.0
     ae_dtype: str = "bf16"
     diff_dtype: str = "fp16"
-    no_llava: bool = True
-    caption: str = ""
+    no_llava: bool = False
+    caption: str = ""                 # when non-empty it is used as the caption and LLaVA is not loaded
+    prompt_yaml: str = str(_HERE / "prompts" / "prompt_config.yaml")
+    base_model_device: str = "cuda:0" # the reference puts LLaVA on a second GPU (cuda:1); one MI355X holds everything
+    llava_path: str = "lmms-lab/llama3-llava-next-8b"
+    llava_adapter: str = "./CKPT_PTH/Llava-next"
+    llava_seed: int = 0
     use_tile_vae: bool = False
     encoder_tile_size: int = 512
     decoder_tile_size: int = 64
@@ -75,7 +81,10 @@ class SuperResolutionPipeline:
         self.cfg = cfg
         if cfg.seed >= 0:
             torch.manual_seed(cfg.seed)
+        self.llava_model = self.llava_tokenizer = self.llava_image_processor = None
         self._load_sr3_model()
+        if not cfg.no_llava and not cfg.caption:
+            self._load_llava_model()
         self._load_refinement_model()
 
     def _load_sr3_model(self):
@@ -85,6 +94,11 @@ class SuperResolutionPipeline:
         if self.cfg.sr3_steps > 0:
             sched["n_timestep"] = self.cfg.sr3_steps
         self.sr3_model.set_new_noise_schedule(sched, schedule_phase="val")
+
+    def _load_llava_model(self):
+        from .models.util import load_llava
+        self.llava_tokenizer, self.llava_model, self.llava_image_processor = load_llava(
+            device=self.cfg.base_model_device, model_path=self.cfg.llava_path, adapter_path=self.cfg.llava_adapter)
 
     def _load_refinement_model(self):
         self.refinement_model = create_SR_model(self.cfg.model_yaml, allow_random_init=self.cfg.allow_random_init)
@@ -106,7 +120,22 @@ class SuperResolutionPipeline:
         return sr_pil
 
     def run_stage2_captioning(self, sr_image) -> str:
-        return "" if self.cfg.no_llava else self.cfg.caption
+        """infer.py:145-166: caption of the Stage-1 image.  Returns the caption STRING handed to just_sampling as p[0]
+        (the reference passes get_img_describe's one-element list straight through as ``[caption]``; the text is the same)."""
+        if self.cfg.caption:
+            return self.cfg.caption
+        if self.cfg.no_llava or self.llava_model is None:
+            return ""
+        import yaml
+        from . import llava_next as LN
+        with open(self.cfg.prompt_yaml, "r", encoding="utf-8") as f:
+            img_prompt = yaml.safe_load(f)["img_prompt"].format(DEFAULT_IMAGE_TOKEN=LN.DEFAULT_IMAGE_TOKEN)
+        dev = self.cfg.base_model_device
+        views = LN.process_images([sr_image], self.llava_image_processor, self.llava_model.config)
+        views = [v.to(dtype=torch.float16, device=dev) for v in views]
+        seed = self.cfg.llava_seed if self.cfg.seed < 0 else self.cfg.seed
+        return LN.get_img_describe(image_tensor=views, image=sr_image, model=self.llava_model, tokenizer=self.llava_tokenizer,
+                                   prompt=img_prompt, max_new_tokens=256, device=dev, seed=seed)[0]
 
     def run_stage3_refinement(self, sr_image, caption: str):
         lq, h0, w0 = PIL2Tensor(sr_image, upscale=1, min_size=self.cfg.min_size)
@@ -140,11 +169,14 @@ def main(argv=None):
     p.add_argument("--edm_steps", type=int, default=50)
     p.add_argument("--sr3_steps", type=int, default=0)
     p.add_argument("--caption", type=str, default="")
+    p.add_argument("--no_llava", action="store_true")
+    p.add_argument("--llava_path", type=str, default="lmms-lab/llama3-llava-next-8b")
+    p.add_argument("--llava_adapter", type=str, default="./CKPT_PTH/Llava-next")
     p.add_argument("--use_tile_vae", action="store_true")
     a = p.parse_args(argv)
     cfg = PipelineConfig(input_img=a.input_img, output_dir=a.output_dir, upscale_factor=a.upscale_factor, seed=a.seed,
                          img_threshold=a.img_threshold, edm_steps=a.edm_steps, sr3_steps=a.sr3_steps, caption=a.caption,
-                         no_llava=(a.caption == ""), use_tile_vae=a.use_tile_vae)
+                         no_llava=a.no_llava, llava_path=a.llava_path, llava_adapter=a.llava_adapter, use_tile_vae=a.use_tile_vae)
     SuperResolutionPipeline(cfg).process()
 
 

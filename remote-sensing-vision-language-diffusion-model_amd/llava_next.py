@@ -1,0 +1,389 @@
+"""LLaVA-NeXT caption pass on stock PyTorch-ROCm (BASELINE configs[3] "live LLaVA-Next prompt").
+
+The reference runs a vendored LLaVA-NeXT tree (``llava/``, ~20 k lines) whose loader defaults to
+``attn_implementation="flash_attention_2"`` (llava/model/builder.py:30) and wraps the model in a ``peft`` adapter
+(models/util.py:111-117).  Per BASELINE.json north_star this pass stays a PyTorch module (it is conditioning, not the
+hot path); what the build owns is a ROCm-clean way to load and drive it:
+
+  * ``LlavaNextLlama``: transformers' own ``LlamaForCausalLM`` + ``CLIPVisionModel`` (SDPA attention -- no flash-attn, no
+    bitsandbytes) with the multimodal members named as in the reference model (``model.vision_tower.vision_tower.*``,
+    ``model.mm_projector.{0,2}``, ``model.image_newline``; llava/model/llava_arch.py:36-49), so the reference's
+    ``lmms-lab/llama3-llava-next-8b`` checkpoint loads unchanged;
+  * the "anyres" image path: tile selection, resize+pad, tiling (llava/mm_utils.py:121-296), CLIP layer -2 patch features
+    -> 2-layer GELU MLP (multimodal_encoder/clip_encoder.py:48-82, multimodal_projector/builder.py:41-48), un-padding of
+    the tile grid and one ``image_newline`` embedding per feature row (llava_arch.py:129-161,372-409), spliced into the
+    token embeddings where the prompt holds IMAGE_TOKEN_INDEX (llava_arch.py:440-497);
+  * ``get_img_describe`` with the reference's signature (models/util.py:17-66): Llama-3 chat template of
+    ``conv_llava_llama_3`` (llava/conversation.py:98-110,387-398), sampling at temperature 0.2 -- plus an explicit
+    ``seed`` so captions are reproducible;
+  * ``merge_lora``: the adapter of ``./CKPT_PTH/Llava-next`` folded into the base weights (W += B A * alpha / r) when
+    ``peft`` is not installed.
+
+Pinned offline by tests/test_llava_next.py against token ids, input embeddings and logits the REFERENCE model produced on a
+tiny seeded LLaMA + CLIP configuration (tests/golden/gen_llava_golden.py).
+"""
+import ast
+import json
+import math
+import os
+import re
+
+import torch
+from torch import nn
+
+IGNORE_INDEX = -100
+IMAGE_TOKEN_INDEX = -200            # llava/constants.py
+DEFAULT_IMAGE_TOKEN = "<image>"
+LLAMA3_SYSTEM = ("You are a helpful language and vision assistant. You are able to understand the visual content that the user "
+                 "provides, and assist the user with a variety of tasks using natural language.")   # conversation.py:388
+DEFAULT_MODEL = "lmms-lab/llama3-llava-next-8b"     # models/util.py:112-114
+DEFAULT_ADAPTER = "./CKPT_PTH/Llava-next"           # models/util.py:115
+
+
+# ------------------------------------------------------------------------------------------------ image side (host)
+def _resolutions(grid_pinpoints, patch_size):
+    """``image_grid_pinpoints`` as a list of (width, height): a list, its string form, or the "(1x1),...,(3x3)" range form."""
+    if isinstance(grid_pinpoints, str) and "x" in grid_pinpoints:
+        spans = [(int(a), int(b)) for a, b in re.findall(r"\((\d+)x(\d+)\)", grid_pinpoints)]
+        (a0, b0), (a1, b1) = spans[0], spans[-1]
+        return [[i * patch_size, j * patch_size] for i in range(a0, a1 + 1) for j in range(b0, b1 + 1)]
+    return grid_pinpoints if isinstance(grid_pinpoints, list) else ast.literal_eval(grid_pinpoints)
+
+
+def select_best_resolution(original_size, possible_resolutions):
+    """The candidate (width, height) that keeps most of the image's pixels after an aspect-preserving fit, ties broken by
+    the least wasted canvas (mm_utils.py:121-151)."""
+    ow, oh = original_size
+    best, best_key = None, None
+    for w, h in possible_resolutions:
+        s = min(w / ow, h / oh)
+        eff = min(int(ow * s) * int(oh * s), ow * oh)
+        key = (eff, -(w * h - eff))
+        if best_key is None or key > best_key:
+            best, best_key = (w, h), key
+    return best
+
+
+def resize_and_pad_image(image, target_resolution):
+    """Aspect-preserving resize (PIL default filter, like the reference) centred on a black canvas (mm_utils.py:154-190)."""
+    from PIL import Image
+    ow, oh = image.size
+    tw, th = target_resolution
+    sw, sh = tw / ow, th / oh
+    if sw < sh:
+        nw, nh = tw, min(math.ceil(oh * sw), th)
+    else:
+        nw, nh = min(math.ceil(ow * sh), tw), th
+    canvas = Image.new("RGB", (tw, th), (0, 0, 0))
+    canvas.paste(image.resize((nw, nh)), ((tw - nw) // 2, (th - nh) // 2))
+    return canvas
+
+
+def _proc_sizes(processor):
+    """(shortest_edge, crop) of a CLIP image processor across transformers versions (dict, SizeDict or int pair)."""
+    def get(obj, key):
+        try:
+            return obj[key]
+        except (KeyError, TypeError, IndexError):
+            return getattr(obj, key, None)
+    size, crop = processor.size, processor.crop_size
+    edge = get(size, "shortest_edge")
+    if edge is None:
+        edge = min(v for v in (get(size, "height"), get(size, "width")) if v is not None) if not isinstance(size, (tuple, list)) \
+            else min(size)
+    return int(edge), int(get(crop, "height"))
+
+
+def process_anyres_image(image, processor, grid_pinpoints):
+    """-> ``[1 + tiles, 3, S, S]``: the whole image squashed to S x S (the reference resizes, it does not pad,
+    mm_utils.py:281-293), then the row-major S x S tiles of the best-fitting padded canvas."""
+    edge, crop = _proc_sizes(processor)
+    canvas = resize_and_pad_image(image, select_best_resolution(image.size, _resolutions(grid_pinpoints, edge)))
+    w, h = canvas.size
+    views = [image.resize((edge, edge))]
+    views += [canvas.crop((x, y, x + crop, y + crop)) for y in range(0, h, crop) for x in range(0, w, crop)]
+    return torch.stack([processor.preprocess(v, return_tensors="pt")["pixel_values"][0] for v in views], dim=0)
+
+
+def process_images(images, image_processor, model_cfg):
+    """mm_utils.py:316-340 for the aspect modes the shipped LLaVA-NeXT checkpoints use ("anyres"; plain preprocess otherwise)."""
+    mode = getattr(model_cfg, "image_aspect_ratio", None)
+    if mode == "anyres" or (mode is not None and "anyres_max" in mode):
+        out = [process_anyres_image(im, image_processor, model_cfg.image_grid_pinpoints) for im in images]
+        return torch.stack(out, dim=0) if all(o.shape == out[0].shape for o in out) else out
+    if mode in ("highres", "crop_split", "pad"):
+        raise NotImplementedError(f"image_aspect_ratio={mode!r}: the LLaVA-NeXT checkpoints of the pipeline use 'anyres'")
+    return image_processor.preprocess(images, return_tensors="pt")["pixel_values"]
+
+
+def anyres_grid_shape(image_size, grid_pinpoints, patch_size):
+    """(tiles across, tiles down) of the canvas chosen for ``image_size`` = (width, height) (mm_utils.py:215-242)."""
+    w, h = select_best_resolution(image_size, _resolutions(grid_pinpoints, patch_size))
+    return w // patch_size, h // patch_size
+
+
+def unpad_image(feat, original_size):
+    """Crop a ``[C, H, W]`` feature map of a padded canvas back to the image's aspect (llava_arch.py:129-161; note the
+    truncating ``int`` and the symmetric crop, which can leave one padded row / column)."""
+    ow, oh = original_size
+    ch, cw = feat.shape[1:]
+    if ow / oh > cw / ch:                       # padded above / below
+        pad = (ch - int(oh * (cw / ow))) // 2
+        return feat[:, pad:ch - pad, :]
+    pad = (cw - int(ow * (ch / oh))) // 2       # padded left / right
+    return feat[:, :, pad:cw - pad]
+
+
+# ------------------------------------------------------------------------------------------------ text side (host)
+def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, return_tensors=None):
+    """Tokenise around every "<image>" and put ``image_token_index`` in its place; a BOS the tokenizer prepends to each
+    chunk is kept once (mm_utils.py:343-362)."""
+    chunks = [tokenizer(c).input_ids for c in prompt.split(DEFAULT_IMAGE_TOKEN)]
+    has_bos = bool(chunks and chunks[0] and chunks[0][0] == tokenizer.bos_token_id)
+    ids = [chunks[0][0]] if has_bos else []
+    skip = 1 if has_bos else 0
+    for i, c in enumerate(chunks):
+        if i > 0:
+            ids.append(image_token_index)
+        ids.extend(c[skip:])
+    if return_tensors is None:
+        return ids
+    if return_tensors != "pt":
+        raise ValueError(f"Unsupported tensor type: {return_tensors}")
+    return torch.tensor(ids, dtype=torch.long)
+
+
+def llama3_prompt(tokenizer, question, system=LLAMA3_SYSTEM):
+    """The prompt ``conv_templates["llava_llama_3"]`` builds for one user turn (conversation.py:98-110): the tokenizer's own
+    chat template over [system, user], with the generation header appended."""
+    messages = [{"role": "system", "content": system}, {"role": "user", "content": question}]
+    return tokenizer.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+
+
+class _Llama3Template:
+    """Minimal stand-in for an entry of the reference's ``conv_templates`` dict, for callers that pass one through
+    ``get_img_describe(conv_templates=...)``."""
+    system, roles = LLAMA3_SYSTEM, ("user", "assistant")
+
+
+conv_templates = {"llava_llama_3": _Llama3Template()}
+
+
+# ------------------------------------------------------------------------------------------------ the model
+def _llama_config_cls():
+    from transformers import LlamaConfig
+
+    class LlavaNextConfig(LlamaConfig):
+        model_type = "llava_llama"          # what config.json of the reference checkpoints says (llava_llama.py:30-37)
+
+    return LlavaNextConfig
+
+
+class _VisionTower(nn.Module):
+    """``model.vision_tower``: holds the CLIP vision model as ``.vision_tower`` like the reference's CLIPVisionTower, and
+    returns the hidden states of ``select_layer`` without the class token (clip_encoder.py:48-82)."""
+
+    def __init__(self, clip, select_layer, select_feature):
+        super().__init__()
+        self.vision_tower = clip
+        self.select_layer, self.select_feature = select_layer, select_feature
+        if select_feature not in ("patch", "cls_patch"):
+            raise NotImplementedError(f"mm_vision_select_feature={select_feature!r}")
+
+    @property
+    def config(self):
+        return self.vision_tower.config
+
+    @property
+    def image_size(self):
+        return self.config.image_size
+
+    @property
+    def num_patches_per_side(self):
+        return self.config.image_size // self.config.patch_size
+
+    def forward(self, images):
+        p = next(self.vision_tower.parameters())
+        hs = self.vision_tower(images.to(device=p.device, dtype=p.dtype), output_hidden_states=True).hidden_states[self.select_layer]
+        return (hs[:, 1:] if self.select_feature == "patch" else hs).to(images.dtype)
+
+
+def build_model(config, clip=None):
+    """``LlavaNextLlama(config)``.  ``config``: a LlamaConfig carrying the reference's multimodal fields (mm_vision_tower,
+    mm_projector_type, mm_hidden_size, mm_vision_select_layer, image_aspect_ratio, image_grid_pinpoints,
+    mm_patch_merge_type).  ``clip``: a ready CLIPVisionModel, else one is built from ``config.mm_vision_tower``'s config."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel, LlamaForCausalLM
+
+    class LlavaNextLlama(LlamaForCausalLM):
+        config_class = _llama_config_cls()
+
+        def __init__(self, cfg):
+            super().__init__(cfg)
+            tower = clip if clip is not None else CLIPVisionModel(CLIPVisionConfig.from_pretrained(cfg.mm_vision_tower))
+            tower.requires_grad_(False)
+            self.model.vision_tower = _VisionTower(tower, cfg.mm_vision_select_layer, getattr(cfg, "mm_vision_select_feature", "patch"))
+            m = re.match(r"^mlp(\d+)x_gelu$", getattr(cfg, "mm_projector_type", "linear"))
+            if m is None and cfg.mm_projector_type != "linear":
+                raise NotImplementedError(f"mm_projector_type={cfg.mm_projector_type!r}")
+            layers = [nn.Linear(cfg.mm_hidden_size, cfg.hidden_size)]
+            for _ in range(1, int(m.group(1)) if m else 1):
+                layers += [nn.GELU(), nn.Linear(cfg.hidden_size, cfg.hidden_size)]
+            self.model.mm_projector = nn.Sequential(*layers) if m else layers[0]
+            if "unpad" in getattr(cfg, "mm_patch_merge_type", ""):
+                self.model.image_newline = nn.Parameter(torch.zeros(cfg.hidden_size))
+
+        # -------- image features -> one [tokens, hidden] block per image
+        def encode_images(self, pixel_values):
+            return self.model.mm_projector(self.model.vision_tower(pixel_values))
+
+        def image_blocks(self, images, image_sizes):
+            """``images``: list of ``[1 + tiles, 3, S, S]`` (or a 5-D stack).  Base view first, then the un-padded tile grid
+            with a newline embedding closing every feature row (mm_patch_merge_type "spatial_unpad", llava_arch.py:339-409)."""
+            cfg = self.config
+            merge = getattr(cfg, "mm_patch_merge_type", "flat")
+            views = [im if im.ndim == 4 else im.unsqueeze(0) for im in images]
+            feats = torch.split(self.encode_images(torch.cat(views, dim=0)), [v.shape[0] for v in views])
+            if merge == "flat":
+                return [f.flatten(0, 1) for f in feats]
+            if merge != "spatial_unpad":
+                raise NotImplementedError(f"mm_patch_merge_type={merge!r}")
+            side = self.model.vision_tower.num_patches_per_side
+            nl = self.model.image_newline
+            out = []
+            for f, size in zip(feats, image_sizes):
+                if f.shape[0] == 1:
+                    out.append(torch.cat([f[0], nl[None].to(f.dtype)], dim=0))
+                    continue
+                nx, ny = anyres_grid_shape(size, cfg.image_grid_pinpoints, self.model.vision_tower.image_size)
+                grid = f[1:].view(ny, nx, side, side, -1).permute(4, 0, 2, 1, 3).reshape(f.shape[-1], ny * side, nx * side)
+                grid = unpad_image(grid, size)
+                grid = torch.cat([grid, nl.to(grid.dtype)[:, None, None].expand(-1, grid.shape[1], 1)], dim=-1)
+                out.append(torch.cat([f[0], grid.flatten(1, 2).transpose(0, 1)], dim=0))
+            return out
+
+        def multimodal_embeds(self, input_ids, images, image_sizes):
+            """``input_ids [1, T]`` holding IMAGE_TOKEN_INDEX placeholders -> ``inputs_embeds [1, T', hidden]``
+            (llava_arch.py:440-497, single sequence, no padding)."""
+            if input_ids.shape[0] != 1:
+                raise NotImplementedError("the caption pass runs one prompt at a time (models/util.py:39-43)")
+            ids = input_ids[0]
+            blocks = self.image_blocks(images, image_sizes)
+            where = (ids == IMAGE_TOKEN_INDEX).nonzero().flatten().tolist()
+            if len(where) != len(blocks):
+                raise ValueError(f"{len(where)} image placeholders in the prompt for {len(blocks)} images")
+            embed = self.model.embed_tokens
+            parts, start = [], 0
+            for pos, blk in zip(where, blocks):
+                parts += [embed(ids[start:pos]), blk.to(embed.weight.dtype)]
+                start = pos + 1
+            parts.append(embed(ids[start:]))
+            emb = torch.cat(parts, dim=0)
+            limit = getattr(self.config, "tokenizer_model_max_length", None)
+            return emb[:limit][None]
+
+        @torch.no_grad()
+        def generate(self, inputs=None, images=None, image_sizes=None, **kw):
+            """``generate(input_ids, images=[...], image_sizes=[(w, h)], do_sample=..., ...)`` like the reference's override
+            (llava_llama.py:118-137): the prompt is handed to the decoder as embeddings."""
+            kw.pop("modalities", None)
+            if images is None:
+                return super().generate(inputs, **kw)
+            return super().generate(inputs_embeds=self.multimodal_embeds(inputs, images, image_sizes), **kw)
+
+    return LlavaNextLlama(config)
+
+
+def normalise_checkpoint_keys(state_dict, model):
+    """Checkpoints written by transformers 4.x name the CLIP weights ``...vision_tower.vision_tower.vision_model.*``;
+    transformers 5 modules drop the ``vision_model.`` level (and vice versa).  Rename towards what ``model`` has."""
+    have = set(model.state_dict().keys())
+    mid = ".vision_tower.vision_tower."
+    out = {}
+    for k, v in state_dict.items():
+        if k not in have and mid in k:
+            alt = k.replace(mid + "vision_model.", mid) if mid + "vision_model." in k else k.replace(mid, mid + "vision_model.")
+            if alt in have:
+                k = alt
+        out[k] = v
+    return out
+
+
+def merge_lora(model, adapter_dir):
+    """Fold a PEFT LoRA adapter (adapter_config.json + adapter_model.safetensors / .bin) into ``model``'s Linear weights:
+    ``W += (B @ A) * lora_alpha / r``.  Equivalent to ``PeftModel.from_pretrained(...).merge_and_unload()`` for plain LoRA on
+    Linear layers; anything else in the adapter raises."""
+    cfg = json.load(open(os.path.join(adapter_dir, "adapter_config.json")))
+    if cfg.get("peft_type", "LORA") != "LORA" or cfg.get("use_dora") or cfg.get("modules_to_save"):
+        raise NotImplementedError("merge_lora handles plain LoRA adapters on Linear layers")
+    scale = cfg["lora_alpha"] / cfg["r"]
+    st = os.path.join(adapter_dir, "adapter_model.safetensors")
+    if os.path.exists(st):
+        import safetensors.torch
+        sd = safetensors.torch.load_file(st)
+    else:
+        sd = torch.load(os.path.join(adapter_dir, "adapter_model.bin"), map_location="cpu")
+    mods = dict(model.named_modules())
+    merged = 0
+    for ka, a in sd.items():
+        if ".lora_A" not in ka:
+            if ".lora_B" not in ka:
+                raise NotImplementedError(f"unexpected adapter tensor {ka}")
+            continue
+        name = re.sub(r"^base_model\.model\.", "", ka.split(".lora_A")[0])
+        b = sd[ka.replace(".lora_A", ".lora_B")]
+        lin = mods[name]
+        lin.weight.data += (b.to(torch.float32) @ a.to(torch.float32)).to(lin.weight) * scale
+        merged += 1
+    return merged
+
+
+def load_llava(device="cuda", model_path=DEFAULT_MODEL, adapter_path=DEFAULT_ADAPTER, dtype=torch.float16):
+    """-> (tokenizer, model, image_processor), the tuple of models/util.py:111-117.  SDPA attention (flash-attn does not
+    exist on this platform and is not needed); the adapter is applied by ``peft`` when installed, else merged here."""
+    from transformers import AutoTokenizer, CLIPImageProcessor
+    cfg_cls = _llama_config_cls()
+    config = cfg_cls.from_pretrained(model_path)
+    config._attn_implementation = "sdpa"
+    tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
+    model = build_model(config)
+    import glob
+
+    import safetensors.torch
+    shards = sorted(glob.glob(os.path.join(model_path, "*.safetensors")))
+    if not shards:
+        raise FileNotFoundError(f"load_llava: no *.safetensors under {model_path!r} (download the checkpoint there first; "
+                                f"this build does not fetch from the network)")
+    for sh in shards:
+        res = model.load_state_dict(normalise_checkpoint_keys(safetensors.torch.load_file(sh), model), strict=False)
+        if res.unexpected_keys:
+            raise RuntimeError(f"load_llava: unexpected keys in {sh}: {res.unexpected_keys[:5]}")
+    if adapter_path is not None:
+        if not os.path.isdir(adapter_path):
+            raise FileNotFoundError(f"load_llava: adapter directory {adapter_path!r} does not exist")
+        try:
+            from peft import PeftModel
+            model = PeftModel.from_pretrained(model, adapter_path, device_map="cpu").merge_and_unload()
+        except ImportError:
+            merge_lora(model, adapter_path)
+    model.eval().to(device=device, dtype=dtype)
+    image_processor = CLIPImageProcessor.from_pretrained(config.mm_vision_tower)
+    return tokenizer, model, image_processor
+
+
+def get_img_describe(image_tensor, image, model, tokenizer, prompt, conv_templates=conv_templates,
+                     image_token_index=IMAGE_TOKEN_INDEX, conv_template="llava_llama_3", num_beams=1, temperature=0.2,
+                     do_sample=True, max_new_tokens=512, device="cuda", seed=None):
+    """models/util.py:17-66 -> ``[caption]``.  ``seed`` (an addition): seeds the CPU and device generators right before
+    sampling, which makes the caption a function of (image, prompt, weights, seed)."""
+    if conv_template != "llava_llama_3":
+        raise NotImplementedError("the pipeline's captioner is the Llama-3 LLaVA-NeXT (conv_template 'llava_llama_3')")
+    system = getattr(conv_templates[conv_template], "system", LLAMA3_SYSTEM)
+    text = llama3_prompt(tokenizer, prompt, system)
+    input_ids = tokenizer_image_token(text, tokenizer, image_token_index, return_tensors="pt").unsqueeze(0).to(device)
+    if seed is not None:
+        torch.manual_seed(seed)
+    with torch.inference_mode():
+        out = model.generate(input_ids, images=image_tensor, image_sizes=[image.size], do_sample=do_sample,
+                             temperature=temperature, num_beams=num_beams, max_new_tokens=max_new_tokens,
+                             return_dict_in_generate=True, output_scores=True)
+    return [tokenizer.decode(out[0][0].cpu().tolist(), skip_special_tokens=True).lstrip()]

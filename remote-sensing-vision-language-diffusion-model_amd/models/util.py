@@ -57,6 +57,19 @@ def create_SR_model(config_path, load_default_setting=False, allow_random_init=F
     return model
 
 
+def load_llava(device="cuda", **kw):
+    """(tokenizer, model, image_processor) of the LLaVA-NeXT captioner (models/util.py:111-117), loaded ROCm-clean
+    (SDPA attention, no flash-attn / bitsandbytes; see rsvld_amd.llava_next)."""
+    from ..llava_next import load_llava as _load
+    return _load(device=device, **kw)
+
+
+def get_img_describe(*args, **kw):
+    """models/util.py:17-66 (same signature, plus ``seed``)."""
+    from ..llava_next import get_img_describe as _describe
+    return _describe(*args, **kw)
+
+
 def PIL2Tensor(img, upscale=1, min_size=1024, fix_resize=None):
     """PIL.Image -> Tensor[C,H,W] RGB in [-1,1]; sides rounded to multiples of 64 (util.py:132-156)."""
     from PIL import Image

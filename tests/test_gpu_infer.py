@@ -31,7 +31,7 @@ def test_pipeline_cli_flow(cuda, tmp_path):
     lr = Image.fromarray(rng.integers(0, 255, (24, 32, 3), dtype=np.uint8))
     lr.save(tmp_path / "tile.png")
     pc = infer.PipelineConfig(input_img=str(tmp_path / "tile.png"), output_dir=str(tmp_path / "out"), model_yaml=str(ypath),
-                              allow_random_init=True,
+                              allow_random_init=True, no_llava=True,
                               upscale_factor=2, min_size=128, edm_steps=3, sr3_steps=3, seed=1, img_threshold=0.3)
     pipe = infer.SuperResolutionPipeline(pc)
     # zero-initialised output convs would make Stage 2 a no-op: give them small seeded weights
@@ -48,3 +48,29 @@ def test_pipeline_cli_flow(cuda, tmp_path):
     assert final.size == (64, 64)                     # Tensor2PIL resizes back to the hand-off size (models/util.py:159-166)
     arr = np.asarray(final)
     assert arr.dtype == np.uint8 and arr.std() > 1.0
+
+
+def test_live_llava_caption_on_device(cuda, tmp_path):
+    """The caption pass on the GPU (stock PyTorch-ROCm, SDPA attention, fp16): a tiny seeded LLaVA-NeXT is put where
+    load_llava() would put the 8 B one and run_stage2_captioning drives it exactly as the CLI does; the caption is a
+    function of the seed.  (Token-level parity with the reference model is pinned on CPU in tests/test_llava_next.py.)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import llava_common as C
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModel
+    from rsvld_amd import infer, llava_next as LN
+    tower_dir = C.save_tiny_clip(str(tmp_path / "clip"))
+    cfg = LN._llama_config_cls()(**C.LLAMA, **C.MM, mm_vision_tower=tower_dir)
+    cfg._attn_implementation = "sdpa"
+    model = LN.build_model(cfg, clip=CLIPVisionModel(CLIPVisionConfig(**C.VISION))).eval()
+    C.name_seeded_state(model, C.WEIGHT_SEED)
+    model.to(device=cuda, dtype=torch.float16)
+    pipe = infer.SuperResolutionPipeline.__new__(infer.SuperResolutionPipeline)      # only the caption stage is under test
+    pipe.cfg = infer.PipelineConfig(input_img=str(tmp_path / "x.png"), output_dir=str(tmp_path / "out"), seed=3,
+                                    base_model_device="cuda:0")
+    pipe.llava_model, pipe.llava_tokenizer = model, C.build_tokenizer()
+    pipe.llava_image_processor = CLIPImageProcessor.from_pretrained(tower_dir)
+    img = C.test_image((100, 70), 5)
+    a, b = pipe.run_stage2_captioning(img), pipe.run_stage2_captioning(img)
+    assert isinstance(a, str) and a == b and len(a) > 0
+    pipe.cfg.caption = "a river delta"
+    assert pipe.run_stage2_captioning(img) == "a river delta"

@@ -81,7 +81,9 @@ def test_sampler_step_vs_reference_golden(model, cuda, golden_dir, i):
     _z, x_center = S.rnd((1, 4, 8, 8), 201, 0.8).to(cuda), S.rnd((1, 4, 8, 8), 202, 0.8).to(cuda)
     c, uc = m.prepare_condition(_z, [""], "", "", 1)
     _, s_in, sigmas, _, c, uc = sampler.init_loop(S.rnd((1, 4, 8, 8), 203).to(cuda), c, uc=uc, num_steps=S.STEP_OPT["num_steps"])
-    assert np.array_equal(sigmas.numpy(), z["step.sigmas"])
+    # (bit-equality of the schedule is pinned on the authoring host, tests/test_oracle_s2.py; another host CPU's libm
+    # may differ in the last ulp)
+    assert np.allclose(sigmas.numpy(), z["step.sigmas"], rtol=1e-6, atol=0)
 
     def denoiser(inp, sigma, cc, *a, **kw):
         return m.denoiser(m.model, inp, sigma, cc, *a, **kw)
