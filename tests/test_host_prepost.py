@@ -68,3 +68,28 @@ def test_stage1_loader_contract(tmp_path):
     sq2 = resize_and_convert(Image.fromarray(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)), 2)
     assert sq2.size == (32, 32)
 
+
+
+def test_stage1_loader_vs_fixture(tmp_path):
+    """Product loader == tests/golden/stage1_loader.npz bit for bit, and so is the oracle restatement that produced it
+    (torchvision formulas, oracle/loader_oracle.py; the reference loader needs torchvision and cannot run in the
+    authoring container: parity unpinned by a reference run)."""
+    import os
+    from oracle import loader_oracle as LO
+    from rsvld_amd.data.dataset import load_sr_input
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_loader_golden", os.path.join(sys_path, "gen_loader_golden.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    z = np.load(os.path.join(sys_path, "stage1_loader.npz"))
+    for i, ((w, h), s) in enumerate(G.CASES):
+        img = Image.fromarray(z[f"in{i}"])
+        assert img.size == (w, h)
+        want = ((z[f"out{i}_u8"].astype(np.float32) / np.float32(255)) - np.float32(0.5)) / np.float32(0.5)
+        assert np.array_equal(LO.load(img, s), want)
+        p = str(tmp_path / f"lr{i}.png")
+        img.save(p)
+        got = load_sr_input(p, s)["SR"].numpy()
+        side = int(max(w, h) * s)
+        assert got.shape == (1, 3, side, side) and np.array_equal(got, want), (i, w, h, s)
