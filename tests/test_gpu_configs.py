@@ -1,0 +1,106 @@
+"""BASELINE.json configs at their FULL sizes on the GPU (no oracle finishes a whole run there): each config is run for a
+few sampler steps and checked (i) against the CPU oracle on a teacher-forced slice where one is affordable, and (ii)
+through size-independent properties -- batch members equal their batch-of-1 runs bit for bit, cache traces are per image,
+outputs are finite and differ between images.
+
+  configs[1]  Stage 1 only, 128 -> 512 x4, batch 4           -> 2 ancestral steps vs the oracle, per-image identity
+  configs[2]  Stage 2, 2048^2 (latent 256), batch 8, cache 0.3 -> 3 steps, image 0 / image 5 alone == inside the batch
+  RCCL        the uint8 all-gather of finished images through the nccl (= RCCL) backend on this GPU (world size 1)
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_config1_stage1_512_batch4_vs_oracle(cuda):
+    import bench
+    from oracle import sr3_oracle as O
+    T = 50
+    net, _ = bench.build_stage1(T)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    cond = bench.stage1_input([0, 1, 2, 3], 128, 4)
+    noises = [torch.randn(4, 3, 512, 512, generator=torch.Generator().manual_seed(50 + i)) for i in range(3)]
+    it = iter(noises)
+    net._randn = lambda shape, device: next(it).to(device)            # x_T, then one draw per step with t > 0
+    sr = net.super_resolution(cond.to(cuda), continous=True, _max_steps=2)
+    got = sr[-4:].cpu()
+    assert got.shape == (4, 3, 512, 512) and bool(torch.isfinite(got).all())
+    # the oracle on image 2 alone, same draws (2 steps at 512^2 = 2 x 1.1 TFLOP on the host cores)
+    sch = O.schedule(dict(schedule="linear", n_timestep=T, linear_start=1e-6, linear_end=1e-2))
+    x = noises[0][2:3]
+    with torch.no_grad():
+        for n, t in enumerate((T - 1, T - 2)):
+            x = O.p_sample(sd, O.SR3_CFG, sch, x, t, cond[2:3], noises[1 + n][2:3])
+    err = float((got[2:3] - x).abs().max())
+    print(f"configs[1], 2 teacher-forced steps, image 2 of 4 vs CPU oracle: max|d| = {err:.3e}")
+    assert err < 1e-3                                                     # measured ~2e-4 (one step: 1.4e-4)
+    # per-image identity: image 2 sampled alone
+    it = iter([n[2:3] for n in noises])
+    alone = net.super_resolution(cond[2:3].to(cuda), continous=True, _max_steps=2)[-1:].cpu()
+    print("configs[1]: image 2 alone vs inside the batch of 4: max|d| =", float((alone - got[2:3]).abs().max()))
+    assert float((alone - got[2:3]).abs().max()) < 2e-3                   # Stage 1 plans launches on the whole batch (not bit-identical by design)
+
+
+def test_config2_stage2_2048_batch8_cache_is_per_image(cuda):
+    import bench
+    m = bench.build_stage2(cuda, True)                                    # full juggernautXL sizes, tiled VAE 512 / 64
+    B, side = 8, 2048
+    img = torch.cat([bench.synthetic_image((1, 3, side, side), seed=1234 + i, smooth=4) for i in range(B)])
+    kw = dict(bench.S2_KW, img_threshold=0.3, num_steps=50, _max_steps=3)
+    g = torch.Generator().manual_seed(7)
+    post, xt = torch.randn(B, 4, 256, 256, generator=g), torch.randn(B, 4, 256, 256, generator=g)
+    steps = [torch.randn(B, 4, 256, 256, generator=g) for _ in range(3)]
+
+    def run(sl):
+        draws = iter([xt] + steps)
+        m._posterior_noise = lambda shape: post[sl]
+        m._randn_like = lambda t: next(draws)[sl].to(t.device)
+        try:
+            out = m.just_sampling(img[sl].to(cuda), [""] * len(range(B)[sl]), **kw)
+            return out.cpu(), [list(s) for s in m.cache_trace]
+        finally:
+            del m._posterior_noise, m._randn_like
+
+    both, trace = run(slice(0, B))
+    assert both.shape == (B, 3, side, side) and bool(torch.isfinite(both).all())
+    assert len(trace) == 3 and all(len(s) == B for s in trace)
+    assert not torch.equal(both[0], both[1])
+    for b in (0, 5):
+        one, tr1 = run(slice(b, b + 1))
+        assert [s[b] for s in trace] == [s[0] for s in tr1], f"image {b}: cache trace differs"
+        d = float((both[b:b + 1] - one).abs().max())
+        print(f"configs[2]: image {b} alone vs inside the batch of 8: max|d| = {d}")
+        assert d == 0.0
+
+
+def test_rccl_all_gather_of_uint8_images(cuda):
+    """The collective of the data-parallel path through the nccl (= RCCL) backend itself (one rank: the same
+    all_gather_into_tensor call, dtype and layout `bench.py --gpus N` issues on N ranks)."""
+    import socket
+    import torch.distributed as dist
+    from rsvld_amd import parallel
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        imgs = (torch.rand(2, 3, 512, 512, device=cuda) * 2 - 1)
+        u8 = parallel.to_uint8(imgs)
+        out = torch.empty_like(u8)
+        dist.all_gather_into_tensor(out, u8.contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(out, u8)
+        got = parallel.run_sharded(lambda i: u8[i], 2, 0, 1)
+        assert torch.equal(got, u8)
+    finally:
+        dist.destroy_process_group()

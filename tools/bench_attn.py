@@ -10,6 +10,9 @@ torch.manual_seed(0)
 reps = int(os.environ.get("REPS", 10))
 CASES = [(4, 1, 4096, 512), (4, 1, 1024, 512), (1, 1, 16384, 512), (1, 1, 65536, 512),
          (2, 10, 4096, 64), (2, 20, 1024, 64), (2, 10, 16384, 64), (2, 20, 16384, 64), (1, 10, 32768, 64)]
+if os.environ.get("HEADLINE"):   # the attention shapes of the 512 -> 4096 headline workload (S1 at 4096^2, S2 at latent 512)
+    CASES = [(1, 1, 65536, 512), (1, 1, 262144, 512), (2, 20, 16384, 64), (2, 10, 65536, 64)]
+    reps = int(os.environ.get("REPS", 3))
 if os.environ.get("ONLY512"):
     CASES = [c for c in CASES if c[3] == 512]
 if os.environ.get("ONLY64"):
