@@ -164,7 +164,7 @@ def roofline_of(summ, pmc_file):
     """The dominant kernel = the group with the largest time share of the instrumented pass."""
     dom = max(summ.values(), key=lambda r: r["ms"])
     tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    traffic, src = None, None
+    traffic, src, busy = None, None, None
     path = os.path.join(ROOT, "profiles", pmc_file)
     if os.path.exists(path):
         alias = {"attention_d64": "attn_d64", "attention_d512": "attn_d512", "gemm_256x256": "gemm256"}
@@ -172,8 +172,9 @@ def roofline_of(summ, pmc_file):
         k = kern.get(dom["name"], kern.get(alias.get(dom["name"], "")))
         if k is not None:
             traffic, src = round(k["hbm_bytes_per_launch"]), f"profiles/{pmc_file}"
+            busy = None if k.get("mfma_busy_frac_est") is None else round(k["mfma_busy_frac_est"], 3)
     return {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_source": src,
+            "frac": round(tf / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_source": src, "mfma_busy_pmc": busy,
             "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
             "algorithmic_flops_per_launch": round(dom["flops"] / dom["n"]),
             "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 2),

@@ -64,9 +64,25 @@ constexpr float A5_DEFER_LOG2 = 8.0f;   // rescale O only when a row's running m
 #endif
 constexpr int A5B_TILE = 32 * 1024;        // one 32-key x 512 tile, 16-bit
 constexpr int A5B_SMEM = 4 * A5B_TILE;     // K[2] | V[2]
+// SH ("shared tile") instantiation: K and V are THE SAME tensor X (k == v pointers and strides).  Single-head attention
+// whose keys and values are both linear maps of one token matrix can always be brought to this form on the host side:
+//   softmax(q (x Wk)^T) (x Wv)  =  softmax((q Wk) x^T) x  Wv,   with q Wk folded into the query projection and Wv into
+// the output projection (biases: the key bias shifts every score of a row by the same amount and cancels in the softmax,
+// the value bias passes through because the probabilities of a row sum to 1).  One LDS image of X then serves BOTH the
+// row-wise K reads and the transposed V reads, so the in-loop LDS-DMA traffic -- the largest single cost of this kernel
+// at long sequences (ablation: 965 -> 1340 TFLOP/s without it, profiles/r02_attn_ablation.txt) -- is halved, and three
+// 32 KiB buffers (PV of tile t, S of tile t+1, landing tile t+2) replace four.
+// Dual-use swizzle: LDS chunk position c of tile row r holds source chunk c ^ f(r), f(r) = ((r & 3) << 2) | ((r >> 2) & 3).
+//   * row-wise ds_read_b128 (16 lanes = 16 rows of distinct r mod 16 per LDS cycle): f is a bijection on 4 bits, so the 16
+//     lanes hit 16 distinct 16-byte positions of a 256-byte bank period: conflict-free;
+//   * ds_read_b64_tr_b16 (32 lanes = 4 rows r = 4 lh + q (+8 hf, +16 s) x 64 contiguous bytes per LDS cycle): bits [3:2] of f
+//     are q, so the four rows land in four different 64-byte quarters of the bank period: conflict-free; bits [1:0] of f
+//     ((lh + 2 hf) & 3) only permute chunks inside a row's own quarter.
+constexpr int A5B_SMEM_SH = 3 * A5B_TILE;  // X[3]
+__host__ __device__ constexpr int a5b_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 
-template <typename T>
+template <typename T, bool SH>
 __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_per_split, float* part_o, float* part_ml) {
     constexpr int D = 512;
     typedef typename Mfma<T>::v8 v8;
@@ -111,21 +127,22 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     uint32_t kvo[8], vvo[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        kvo[i] = (uint32_t)(i * k_rowb) + (uint32_t)((lane ^ ((wu * 8 + i) & 15)) << 4);
+        kvo[i] = (uint32_t)(i * k_rowb) + (uint32_t)((lane ^ (SH ? a5b_f((wu * 8 + i) & 15) : ((wu * 8 + i) & 15))) << 4);
         vvo[i] = (uint32_t)(i * v_rowb) + (uint32_t)((lane ^ ((i & 3) << 2)) << 4);
     }
     const char* k_tile0 = (const char*)(Kb + (int64_t)(k_begin + wu * 8) * p.k_ts);   // + t * 32 rows
     const char* v_tile0 = (const char*)(Vb + (int64_t)(k_begin + wu * 8) * p.v_ts);
-    auto dma_k = [&](int t, int i) {   // key row 8w+i of tile t -> K buffer t&1
+    auto dma_kb = [&](int t, int buf, int i) {   // key row 8w+i of tile t -> tile buffer `buf`
         const int r = wu * 8 + i;
-        const uint32_t dst = lds0 + (t & 1) * A5B_TILE + r * 1024;
+        const uint32_t dst = lds0 + buf * A5B_TILE + r * 1024;
         if (k_begin + t * 32 + 32 <= p.Nk) {
             dma_one(k_tile0 + (int64_t)t * 32 * k_rowb, kvo[i], dst);
         } else {
             const int key = min(k_begin + t * 32 + r, p.Nk - 1);
-            dma_one((const char*)(Kb + (int64_t)key * p.k_ts), (uint32_t)((lane ^ (r & 15)) << 4), dst);
+            dma_one((const char*)(Kb + (int64_t)key * p.k_ts), (uint32_t)((lane ^ (SH ? a5b_f(r & 15) : (r & 15))) << 4), dst);
         }
     };
+    auto dma_k = [&](int t, int i) { dma_kb(t, t & 1, i); };   // K buffer t&1 (two-tensor form)
     auto dma_v = [&](int t, int i) {   // same row of V -> V buffer t&1
         const int r = wu * 8 + i;
         const uint32_t dst = lds0 + (2 + (t & 1)) * A5B_TILE + r * 1024;
@@ -138,13 +155,29 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     };
     // Software pipeline: iteration t runs S(t+1) beside softmax(t), then PV(t).  K is therefore fetched two tiles ahead
     // of its PV (K(t+2) lands in the buffer S(t) read in iteration t-1), V one tile ahead.
+    if constexpr (SH) {   // X(0) -> buffer 0, X(1) -> buffer 1
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma_kb(0, 0, i);
+        if (nt > 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dma_kb(1, 1, i);
+        }
+        if (A5B_ABL & 4) {
+            if (nt > 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dma_kb(2, 2, i);
+            }
+            abl_dma_on = false;
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { dma_k(0, i); dma_v(0, i); }
     if (nt > 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) dma_k(1, i);
     }
-    if (A5B_ABL & 4) {
+    }
+    if (!SH && (A5B_ABL & 4)) {
         if (nt > 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) dma_v(1, i);
@@ -171,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     // ---- per-lane read offsets.  K: row l31, chunk 2ks+lh = 16a + (2c+lh): off = kbase[c] + 256 a.
     int kbase[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) kbase[c] = l31 * 1024 + (((2 * c + lh) ^ (l31 & 15)) << 4);
+    for (int c = 0; c < 8; ++c) kbase[c] = l31 * 1024 + (((2 * c + lh) ^ (SH ? a5b_f(l31 & 15) : (l31 & 15))) << 4);
     // V (transposed read): lane 16g + 4q + p supplies row (4lh + q) + {16s + 8hf}, d = 32dt + 16(g&1) + 4p .. +3;
     // chunk = 4dt + 2(g&1) + (p>>1), swizzled by q<<2: with dt = 4e + f  ->  off = vbase[f] + 256 e + 1024 (16s + 8hf)
     int vbase[4];
@@ -179,7 +212,8 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
         const int qq = (lane >> 2) & 3, pp = lane & 3, g1 = (lane >> 4) & 1;
 #pragma unroll
         for (int f = 0; f < 4; ++f)
-            vbase[f] = 2 * A5B_TILE + (4 * lh + qq) * 1024 + ((f ^ qq) << 6) + ((2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
+            vbase[f] = SH ? (4 * lh + qq) * 1024 + ((f ^ qq) << 6) + (((2 * g1 + (pp >> 1)) ^ lh) << 4) + ((pp & 1) << 3)   // f(r): low bits lh (+2 hf)
+                          : 2 * A5B_TILE + (4 * lh + qq) * 1024 + ((f ^ qq) << 6) + ((2 * g1 + (pp >> 1)) << 4) + ((pp & 1) << 3);
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -229,9 +263,11 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc));   // MFMA D -> VALU reader (cdna_hip_programming.md §5.7 item 2)
     __syncthreads();   // every wave has read K(0): iteration 0 overwrites that buffer with K(2)
 
+    int b_pv = 0;   // SH: ring position of tile t (t % 3)
     for (int t = 0; t < nt; ++t) {
         const bool more = t + 1 < nt, more2 = t + 2 < nt;
-        const int vb = (t & 1) * A5B_TILE;
+        const int b_s = b_pv == 2 ? 0 : b_pv + 1, b_dma = b_pv == 0 ? 2 : b_pv - 1;   // (t + 1) % 3, (t + 2) % 3
+        const int vb = (SH ? b_pv : (t & 1)) * A5B_TILE;
 
         // ---- online softmax of tile t, register-local (this lane holds 16 of its query's 32 scores, lane^32 the
         // rest), cut into 8 parts for the hooks of the S(t+1) chain
@@ -258,13 +294,10 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sacc[r] *= p.scale_log2e;
-                    mx = fmaxf(mx, sacc[r]);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);   // on the raw scores: scale > 0 commutes with max
                 asm volatile("" : "+v"(sacc), "+v"(mx));
             } else if (part == 1) {
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;
                 // deferred max (T13): the reference point moves only when the tile max exceeds it by more than 2^8, so
                 // the rescale of O (256 accumulator registers through VGPRs) is skipped on almost every tile
                 need = mx > m_run + A5_DEFER_LOG2;   // true on the first tile (m_run = -inf)
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
                 const int r0 = 4 * (part - 2);
 #pragma unroll
                 for (int r = r0; r < r0 + 4; ++r) {
-                    sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - m_run);
+                    sacc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], p.scale_log2e, -m_run));   // one fma: no scale pass
                     rs += sacc[r];
                 }
                 asm volatile("" : "+v"(sacc[r0]), "+v"(sacc[r0 + 1]), "+v"(sacc[r0 + 2]), "+v"(sacc[r0 + 3]), "+v"(rs));
@@ -296,15 +329,19 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
 
         f32x16 snext;
         if (more) {
-#define A5B_HOOK(i)                          \
-    if (more2) dma_k(t + 2, i);              \
-    dma_v(t + 1, i);                         \
-    sm(i);                                   \
+#define A5B_HOOK(i)                                                   \
+    if constexpr (SH) {                                               \
+        if (more2) dma_kb(t + 2, b_dma, i);                           \
+    } else {                                                          \
+        if (more2) dma_k(t + 2, i);                                   \
+        dma_v(t + 1, i);                                              \
+    }                                                                 \
+    sm(i);                                                            \
     __builtin_amdgcn_sched_barrier(0)
             if constexpr (__is_same(T, f16)) {
-                A5B_CHAIN("v_mfma_f32_32x32x16_f16", snext, (t + 1) & 1, A5B_HOOK);
+                A5B_CHAIN("v_mfma_f32_32x32x16_f16", snext, (SH ? b_s : ((t + 1) & 1)), A5B_HOOK);
             } else {
-                A5B_CHAIN("v_mfma_f32_32x32x16_bf16", snext, (t + 1) & 1, A5B_HOOK);
+                A5B_CHAIN("v_mfma_f32_32x32x16_bf16", snext, (SH ? b_s : ((t + 1) & 1)), A5B_HOOK);
             }
 #undef A5B_HOOK
         } else {
@@ -318,7 +355,8 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
             const int dt = n >> 1, s2 = n & 1;
             const int off = vb + vbase[dt & 3] + (dt >> 2) * 256 + (16 * s2) * 1024;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off + 8 * 1024));
+            // rows +8 (hf = 1): in the shared image the low swizzle bits are (lh + 2 hf) & 3, i.e. chunk bit 1 flips
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + ((SH ? (off ^ 32) : off) + 8 * 1024)));
             typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
             return __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
@@ -356,6 +394,7 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
         if (more) sacc = snext;   // readable by VALU: 32 PV MFMAs have issued since the chain's last MFMA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of the next tiles have landed
         __syncthreads();   // everyone done with this tile's buffers
+        b_pv = b_s;
     }
 #undef A5B_NOHOOK
 #undef A5B_MFMA_NAME
@@ -740,15 +779,20 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
         float* part_o = (float*)ws;
         float* part_ml = ns > 1 ? part_o + (int64_t)ns * B * heads * Nq * 512 : nullptr;
         dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)ns, (unsigned)(B * heads));
-        auto go = [&](auto kern, auto comb) -> int {
-            static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, A5B_SMEM);
+        // keys and values are one tensor (see the SH note above): the shared-tile instantiation
+        const bool shared = k == v && k_batch_stride == v_batch_stride && k_tok_stride == v_tok_stride;
+        auto go = [&](auto kern, auto comb, int smem) -> int {
+            static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (attr != hipSuccess) return RSVLD_ELAUNCH;
-            hipLaunchKernelGGL(kern, grid, dim3(256), A5B_SMEM, s, a, kps, part_o, part_ml);
+            hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a, kps, part_o, part_ml);
             if (ns > 1) hipLaunchKernelGGL(comb, dim3((unsigned)Nq, (unsigned)(B * heads)), dim3(128), 0, s, a, ns, part_o, part_ml);
             return rsvld_check_launch();
         };
-        return dtype == RSVLD_F16 ? go(attn_d512b_kernel<f16>, attn_combine_kernel<f16>)
-                                  : go(attn_d512b_kernel<bf16>, attn_combine_kernel<bf16>);
+        if (shared)
+            return dtype == RSVLD_F16 ? go(attn_d512b_kernel<f16, true>, attn_combine_kernel<f16>, A5B_SMEM_SH)
+                                      : go(attn_d512b_kernel<bf16, true>, attn_combine_kernel<bf16>, A5B_SMEM_SH);
+        return dtype == RSVLD_F16 ? go(attn_d512b_kernel<f16, false>, attn_combine_kernel<f16>, A5B_SMEM)
+                                  : go(attn_d512b_kernel<bf16, false>, attn_combine_kernel<bf16>, A5B_SMEM);
     }
     if (D == 64) {
         dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);

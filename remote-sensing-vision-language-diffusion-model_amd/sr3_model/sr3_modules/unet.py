@@ -209,11 +209,26 @@ class UNet(nn.Module):
                     if layer.with_attn:
                         if layer.attn.n_head != 1:
                             raise NotImplementedError("SR3 SelfAttention is built with n_head=1 (unet.py:151)")
-                        conv(layer.attn.qkv)
-                        conv(layer.attn.out)
+                        self._pack_attention(pk, layer.attn, dt, dev)
         conv(self.final_conv.block[3])
         self._pk = pk
         return pk
+
+    @staticmethod
+    def _pack_attention(pk, at, dt, dev):
+        """Single-head attention with keys and values taken from ONE tensor (csrc/attention.hip, "SH" note):
+            softmax(q k^T / sqrt(C)) v,  q = n Wq^T, k = n Wk^T, v = n Wv^T   (unet.py:126-141, qkv without bias)
+          = softmax((n Wq^T Wk) n^T / sqrt(C)) n  Wv^T
+        so the query projection becomes Wk^T Wq (one C x C conv instead of the 3C-wide qkv conv), the keys AND values are
+        the normalised input itself, and Wv moves into the output projection (W_out Wv).  Products in fp32 on the host."""
+        w = at.qkv.weight.detach().to("cpu", torch.float32).flatten(1)          # [3C, C]
+        C_ = w.shape[1]
+        wq, wk, wv = w[:C_], w[C_:2 * C_], w[2 * C_:]
+        if at.qkv.bias is not None:
+            raise NotImplementedError("SR3 SelfAttention's qkv conv has no bias (unet.py:121)")
+        pk[("attn_q", id(at))] = ops.pack_conv((wk.t() @ wq).contiguous(), None, dt, dev)
+        wo = at.out.weight.detach().to("cpu", torch.float32).flatten(1)        # [C, C]
+        pk[("attn_out", id(at))] = ops.pack_conv((wo @ wv).contiguous(), at.out.bias, dt, dev)
 
     def _res_conv_packed(self, rb, split):
         key = ("resw", id(rb), split)
@@ -249,10 +264,10 @@ class UNet(nn.Module):
     def _attention(self, at, x):
         B, H, W, Cc = x.shape
         n = ops.group_norm(x, at.norm.weight, at.norm.bias, at.norm.num_groups, at.norm.eps)
-        qkv = ops.conv2d(n, self._pk[id(at.qkv)], pad=0).reshape(B, H * W, 3 * Cc)
-        o = ops.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads=1,
-                          scale=1.0 / math.sqrt(Cc))  # scale uses the full channel count (unet.py:135)
-        return ops.conv2d(o.reshape(B, H, W, Cc), self._pk[id(at.out)], pad=0, residual=x)
+        q = ops.conv2d(n, self._pk[("attn_q", id(at))], pad=0).reshape(B, H * W, Cc)
+        kv = n.reshape(B, H * W, Cc)              # keys and values are the normalised input itself (_pack_attention)
+        o = ops.attention(q, kv, kv, heads=1, scale=1.0 / math.sqrt(Cc))  # scale uses the full channel count (unet.py:135)
+        return ops.conv2d(o.reshape(B, H, W, Cc), self._pk[("attn_out", id(at))], pad=0, residual=x)
 
     def forward_nhwc(self, x, noise_level):
         """x: 16-bit NHWC ``[B,H,W,pad8(in_channel)]``; noise_level fp32 ``[B,1]`` -> fp32 NHWC eps

@@ -39,6 +39,26 @@ def test_attention_d512_full_size_properties(cuda, N):
     assert float((got.float() - ref.float()).abs().max()) < 4e-3 * max(1.0, float(ref.float().abs().max()))
 
 
+@pytest.mark.parametrize("N", [65536, 262144])
+def test_attention_d512_shared_tile_full_size_properties(cuda, N):
+    """The shared-tile form (keys = values = one tensor, what Stage 1 runs at 4096^2): Q = 0 returns the mean of X, key-order
+    invariance, and agreement with the two-tensor kernel on sampled rows."""
+    from rsvld_amd import ops
+    D, dt = 512, torch.float16
+    g = _gen(N + 1)
+    q = (torch.randn(1, 4096, D, device=cuda, generator=g) * 0.5).to(dt)
+    x = torch.randn(1, N, D, device=cuda, generator=g).to(dt)
+    out = ops.attention(torch.zeros_like(q), x, x, heads=1)
+    assert float((out[0].float() - x.float().mean(1)).abs().max()) < 2e-3
+    ref = ops.attention(q, x, x, heads=1)
+    two = ops.attention(q, x, x.clone(), heads=1)                 # separate K and V tensors: the two-tensor instantiation
+    assert float((ref.float() - two.float()).abs().max()) < 2e-3
+    perm = torch.randperm(N, device=cuda, generator=g)
+    xp = x[:, perm].contiguous()
+    got = ops.attention(q, xp, xp, heads=1)
+    assert float((got.float() - ref.float()).abs().max()) < 4e-3 * max(1.0, float(ref.float().abs().max()))
+
+
 def test_attention_d64_full_size_properties(cuda):
     """Stage-2 self-attention at latent 512: (L/2)^2 = 65 536 tokens, 10 heads of 64."""
     from rsvld_amd import ops

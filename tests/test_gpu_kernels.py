@@ -369,6 +369,28 @@ def test_attention_d512(cuda, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 64, 64), (2, 144, 144), (1, 1, 1), (1, 100, 333), (2, 1024, 1024), (3, 1000, 160),
+                                   (1, 300, 2500), (1, 2048, 4096), (1, 33, 95)])
+def test_attention_d512_shared_kv_tile(cuda, dtype, shape):
+    """Keys and values are ONE tensor (k is v): the shared-tile instantiation -- one LDS image read row-wise for S and
+    transposed for P V, three-buffer ring (1, 2, 3+ tiles; ragged tails; split-KV ranges)."""
+    from rsvld_amd import ops
+    B, Nq, Nk = shape
+    D = 512
+    g = torch.Generator().manual_seed(Nq * 5 + Nk)
+    q = _rt(torch.randn(B, Nq, D, generator=g), dtype)
+    x = _rt(torch.randn(B, Nk, D, generator=g), dtype)
+    scale = 1.0 / math.sqrt(D)
+    want = torch.softmax(q @ x.transpose(1, 2) * scale, -1) @ x
+    dx = x.to(cuda, dtype)
+    got = ops.attention(q.to(cuda, dtype), dx, dx, heads=1, scale=scale)
+    _close(got, want, dtype)
+    # and it agrees with the two-tensor kernel on the same data (k and v as separate copies)
+    ref = ops.attention(q.to(cuda, dtype), dx, dx.clone(), heads=1, scale=scale)
+    assert float((got.float() - ref.float()).abs().max()) < (2e-3 if dtype == torch.float16 else 1.6e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 10, 256, 256), (1, 20, 64, 77), (2, 5, 100, 333), (1, 10, 4096, 4096), (3, 2, 1, 1)])
 def test_attention_d64_multihead(cuda, dtype, shape):
     """SDXL self / cross attention and ZeroCrossAttn: heads x d=64, keys 77 (text), ragged, 4096 tokens."""

@@ -21,6 +21,8 @@ print("library:", os.environ.get("RSVLD_LIB", "in-tree build"))
 for (B, heads, N, D) in CASES:
     qkv = torch.randn(B, N, 3 * heads * D, device=dev, dtype=torch.float16)
     q, k, v = qkv[..., :heads * D], qkv[..., heads * D:2 * heads * D], qkv[..., 2 * heads * D:]
+    if os.environ.get("SHARED") and D == 512:     # keys = values = one tensor: the shared-tile instantiation (Stage 1)
+        v = k
     for _ in range(2):
         o = ops.attention(q, k, v, heads)
     torch.cuda.synchronize()
