@@ -493,33 +493,42 @@ constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
 #ifndef A6B_OCC4
 #define A6B_OCC4 1
 #endif
-template <typename T>
-__global__ __launch_bounds__(256, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(AttnArgs p) {
+// NW = waves per workgroup: 4 (128 query rows) or 8 (256 query rows).  The 64-key K / V tile is filled once per workgroup,
+// so with 8 waves every wave issues ONE LDS-DMA piece per tensor per tile instead of two and there is one barrier per 256
+// query rows: the in-loop DMA + barrier cost (ablation: +13 % without it at 65 536 tokens) is halved per MFMA.  Two
+// 8-wave workgroups per CU keep the four waves per SIMD.  Chosen for long query sequences (A6B_NW8_MIN); the gain is small: the kernel is not bound by that term alone.
+#ifndef A6B_NW8_MIN
+#define A6B_NW8_MIN 32768   // measured (one box, 2 x 10 heads): +1.5 % at 65 536 tokens, -0.5 % (noise) at 16 384
+#endif
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(AttnArgs p) {
     constexpr int D = 64;
+    constexpr int RPW = 64 / NW;     // tile rows each wave moves: 16 or 8
+    constexpr int NP = RPW / 8;      // LDS-DMA pieces (8 rows x 128 B) per tensor per wave: 2 or 1
     typedef typename Mfma<T>::v8 v8;
     typedef typename Mfma<T>::v4 v4;
     __shared__ __attribute__((aligned(16))) char smem[A6B_SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int q0 = (blockIdx.x * 4 + w) * 32, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + w) * 32, h = blockIdx.y, b = blockIdx.z;
     const T* Qb = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)h * D;
     const T* Kb = (const T*)p.k + (int64_t)b * p.k_bs + (int64_t)h * D;
     const T* Vb = (const T*)p.v + (int64_t)b * p.v_bs + (int64_t)h * D;
     const int nt = (p.Nk + 63) >> 6;
 
-    // ---- tile DMA.  Wave w moves key rows 16w .. 16w+15 of the tile: two wave-instructions of 8 rows x 128 B per tensor.
-    // Lane (row = lane>>3, pos = lane&7) of piece i fills LDS chunk `pos` of row 16w + 8i + row with source chunk
-    // pos ^ ((row'>>1)&7) for K (row' = row within the 16) and pos ^ (((row'>>1)&1)<<2) for V.
+    // ---- tile DMA.  Wave w moves key rows RPW w .. RPW w + RPW-1 of the tile: NP wave-instructions of 8 rows x 128 B per
+    // tensor.  Lane (row = lane>>3, pos = lane&7) of piece i fills LDS chunk `pos` of tile row r = RPW w + 8i + row with
+    // source chunk pos ^ ((r'>>1)&7) for K (r' = r & 15) and pos ^ (((r'>>1)&1)<<2) for V.
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     const int64_t k_rowb = p.k_ts * (int64_t)sizeof(T), v_rowb = p.v_ts * (int64_t)sizeof(T);
-    uint32_t kvo[2], vvo[2];
+    uint32_t kvo[NP], vvo[NP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rr = 8 * i + (lane >> 3);
-        kvo[i] = (uint32_t)(rr * k_rowb) + (uint32_t)(((lane & 7) ^ ((rr >> 1) & 7)) << 4);
-        vvo[i] = (uint32_t)(rr * v_rowb) + (uint32_t)(((lane & 7) ^ (((rr >> 1) & 1) << 2)) << 4);
+    for (int i = 0; i < NP; ++i) {
+        const int rr = 8 * i + (lane >> 3), r16 = (wu * RPW + rr) & 15;
+        kvo[i] = (uint32_t)(rr * k_rowb) + (uint32_t)(((lane & 7) ^ ((r16 >> 1) & 7)) << 4);
+        vvo[i] = (uint32_t)(rr * v_rowb) + (uint32_t)(((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4);
     }
     auto dma_fast = [&](const char* base, uint32_t voff, uint32_t dst) {
         uint32_t keep;
@@ -533,22 +542,22 @@ __global__ __launch_bounds__(256, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(AttnAr
     };
     auto dma_tile = [&](int t) {
         const int buf = t & 1;
-        const uint32_t kd = lds0 + buf * A6B_TILE + wu * 2048, vd = kd + 2 * A6B_TILE;
+        const uint32_t kd = lds0 + buf * A6B_TILE + wu * (RPW * 128), vd = kd + 2 * A6B_TILE;
         if (t * 64 + 64 <= p.Nk) {
-            const char* kb = (const char*)(Kb + (int64_t)(t * 64 + wu * 16) * p.k_ts);
-            const char* vb = (const char*)(Vb + (int64_t)(t * 64 + wu * 16) * p.v_ts);
+            const char* kb = (const char*)(Kb + (int64_t)(t * 64 + wu * RPW) * p.k_ts);
+            const char* vb = (const char*)(Vb + (int64_t)(t * 64 + wu * RPW) * p.v_ts);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 dma_fast(kb, kvo[i], kd + i * 1024);
                 dma_fast(vb, vvo[i], vd + i * 1024);
             }
         } else {   // rows past Nk re-read the last key; their scores are masked
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rr = 8 * i + (lane >> 3);
-                const int key = min(t * 64 + wu * 16 + rr, p.Nk - 1);
-                dma_slow((const char*)(Kb + (int64_t)key * p.k_ts) + (((lane & 7) ^ ((rr >> 1) & 7)) << 4), kd + i * 1024);
-                dma_slow((const char*)(Vb + (int64_t)key * p.v_ts) + (((lane & 7) ^ (((rr >> 1) & 1) << 2)) << 4), vd + i * 1024);
+            for (int i = 0; i < NP; ++i) {
+                const int rr = 8 * i + (lane >> 3), r16 = (wu * RPW + rr) & 15;
+                const int key = min(t * 64 + wu * RPW + rr, p.Nk - 1);
+                dma_slow((const char*)(Kb + (int64_t)key * p.k_ts) + (((lane & 7) ^ ((r16 >> 1) & 7)) << 4), kd + i * 1024);
+                dma_slow((const char*)(Vb + (int64_t)key * p.v_ts) + (((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4), vd + i * 1024);
             }
         }
     };
@@ -659,13 +668,19 @@ __global__ __launch_bounds__(256, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(AttnAr
                     if (kv >= p.Nk) sacc[kt][r] = -INFINITY;
                 }
         }
-        float mx = -INFINITY;
+        // The running max and the row sum are reductions over the lane's 32 scores.  As ONE serial chain each (16 dependent
+        // v_max3, 32 dependent v_add) they are bound by instruction latency, not issue (ablation: removing them bought 11 %,
+        // removing the 32 exponentials nothing); four independent chains each, merged at the end.
+        float mx;
         if (A6B_ABL & 8) mx = sacc[0][0];
-        else
+        else {
+            float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
+                for (int r = 0; r < 16; ++r) m4[r >> 2] = fmaxf(m4[r >> 2], sacc[kt][r]);
+            mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;   // scale > 0: max commutes with it
         const bool need = mx > m_run + 8.0f;                   // deferred max (T13); true on the first tile
         float alpha = 1.0f;
@@ -674,7 +689,7 @@ __global__ __launch_bounds__(256, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(AttnAr
             m_run = mx;
         }
         const float nm = -m_run;
-        float rs = 0.f;
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -682,8 +697,9 @@ __global__ __launch_bounds__(256, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(AttnAr
                 float pv = __builtin_fmaf(sacc[kt][r], p.scale_log2e, nm);
                 if (!(A6B_ABL & 1)) pv = __builtin_amdgcn_exp2f(pv);
                 sacc[kt][r] = pv;
-                if (!(A6B_ABL & 8) || r == 0) rs += pv;
+                if (!(A6B_ABL & 8) || r == 0) r4[r >> 2] += pv;
             }
+        const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
         l_run = l_run * alpha + rs;
         if (__any(need)) {
 #pragma unroll
@@ -795,9 +811,15 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
                                   : go(attn_d512b_kernel<bf16, false>, attn_combine_kernel<bf16>, A5B_SMEM);
     }
     if (D == 64) {
-        dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
-        if (dtype == RSVLD_F16) hipLaunchKernelGGL(attn_d64b_kernel<f16>, grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(attn_d64b_kernel<bf16>, grid, dim3(256), 0, s, a);
+        if (Nq >= A6B_NW8_MIN) {   // long query sequences: 8 waves (256 query rows) share each K / V tile
+            dim3 grid((unsigned)((Nq + 255) / 256), (unsigned)heads, (unsigned)B);
+            if (dtype == RSVLD_F16) hipLaunchKernelGGL((attn_d64b_kernel<f16, 8>), grid, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((attn_d64b_kernel<bf16, 8>), grid, dim3(512), 0, s, a);
+        } else {
+            dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
+            if (dtype == RSVLD_F16) hipLaunchKernelGGL((attn_d64b_kernel<f16, 4>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_d64b_kernel<bf16, 4>), grid, dim3(256), 0, s, a);
+        }
         return rsvld_check_launch();
     }
     return RSVLD_EUNSUPPORTED;
