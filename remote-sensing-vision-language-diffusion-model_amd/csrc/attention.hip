@@ -59,6 +59,9 @@ constexpr float A5_DEFER_LOG2 = 8.0f;   // rescale O only when a row's running m
 // Split-KV: when the query tiles alone cannot fill the chip, blockIdx.y walks key ranges and the
 // partial (O / l, m, l) triples are merged by attn_combine_kernel.
 // ---------------------------------------------------------------------------------------
+#ifndef A5B_M0_CLOBBER
+#define A5B_M0_CLOBBER 0
+#endif
 #ifndef A5B_ABL
 #define A5B_ABL 0   // diagnostic builds (tools/ablate_attn.sh): 1 no softmax VALU, 2 no V reads, 4 no DMA, 8 no K reads
 #endif
@@ -114,11 +117,15 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
                               // real data: zero-filled operands would raise the clock and overstate the saving)
     auto dma_one = [&](const char* base, uint32_t voff, uint32_t dst) {
         if ((A5B_ABL & 4) && !abl_dma_on) return;
+#if A5B_M0_CLOBBER   // experiment: M0 declared clobbered instead of saved / restored around every piece (2 SALU fewer per piece)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
+#else
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(voff), "s"(dst), "s"(base)
                      : "memory");
+#endif
     };
     // Full tiles: ONE scalar base per tensor (row 8w of the tile, advanced by 32 rows per tile with two SALU adds);
     // the row i of the piece and its source-side swizzle sit in a precomputed 32-bit lane offset.  The tail tile (rows

@@ -10,6 +10,9 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 SHAPES = [(8192, 1280, 1280, 0), (8192, 1280, 3840, 0), (8192, 1280, 10240, 2), (8192, 5120, 1280, 0),
           (32768, 640, 640, 0), (32768, 640, 5120, 2), (32768, 2560, 640, 0), (131072, 640, 1920, 0), (131072, 640, 5120, 2)]
+if os.environ.get("HEADLINE"):   # Stage-2 transformer GEMMs at latent 512 (CFG pair): level 3 (1280 ch, 32 768 tokens), level 2 (640 ch, 131 072)
+    SHAPES = [(32768, 1280, 1280, 0), (32768, 1280, 3840, 0), (32768, 1280, 10240, 2), (32768, 5120, 1280, 0), (32768, 2048, 2560, 0),
+              (131072, 640, 640, 0), (131072, 640, 1920, 0), (131072, 640, 5120, 2), (131072, 2560, 640, 0)]
 reps = int(os.environ.get("REPS", 10))
 for (M, K, N, act) in SHAPES:
     x = torch.randn(M, K, device=dev, dtype=torch.float16)
