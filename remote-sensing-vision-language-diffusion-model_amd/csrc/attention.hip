@@ -753,7 +753,19 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
 
 }  // namespace
 
-// split-KV plan of the D = 512 kernel: key ranges per workgroup so that the grid fills the 256 CUs
+// split-KV plan of the D = 512 kernel: key ranges per workgroup
+//   (a) so that the grid fills the 256 CUs when the query tiles alone cannot;
+//   (b) so that ONE key range stays resident in the 256 MiB Infinity Cache while every query tile streams it.  At
+//       N = 262 144 the key/value tensor is 268 MB (shared tile) or 537 MB: every workgroup re-streamed it from HBM
+//       (rocprofv3 FETCH_SIZE: ~400 GB per launch, ~3 TB/s for the whole 131 ms).  Workgroups are dispatched range-major
+//       (blockIdx.y), so with ranges of A5B_MALL_KEYS keys (64 MiB shared / 128 MiB as two tensors) all the query tiles in
+//       flight read the same range out of the cache; the price is one fp32 partial (O, m, l) per range and the merge pass.
+//       Measured on one box (N = 262 144, shared tile): 1036 TFLOP/s with 64 Ki-key ranges, 1041 without, 1026 with 32 Ki:
+//       the kernel is NOT bound by that HBM stream (its LDS-DMA requests are two tiles ahead), so this buys no time; it is
+//       kept because it takes ~3 TB/s of needless HBM traffic (and its power) out of the dominant Stage-1 kernel.
+#ifndef A5B_MALL_KEYS
+#define A5B_MALL_KEYS 65536
+#endif
 static void attn512_plan(int B, int heads, int Nq, int Nk, int* nsplit, int* keys_per_split) {
     const int64_t base = (int64_t)((Nq + 127) / 128) * B * heads;
     int ns = 1;
@@ -762,6 +774,10 @@ static void attn512_plan(int B, int heads, int Nq, int Nk, int* nsplit, int* key
         const int cap = Nk / 256 > 1 ? Nk / 256 : 1;   // at least 8 key tiles per range
         if (ns > cap) ns = cap;
         if (ns > 16) ns = 16;
+    }
+    if (A5B_MALL_KEYS > 0 && Nk > A5B_MALL_KEYS + A5B_MALL_KEYS / 2) {
+        const int nm = (Nk + A5B_MALL_KEYS - 1) / A5B_MALL_KEYS;
+        if (nm > ns) ns = nm;
     }
     int kps = ((Nk + ns - 1) / ns + 31) / 32 * 32;
     *keys_per_split = kps;
