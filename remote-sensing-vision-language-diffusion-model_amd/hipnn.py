@@ -20,20 +20,24 @@ class HipNet(nn.Module):
         super().__init__()
         self._pk = {}
 
-    # ---- cache invalidation whenever the fp32 master parameters move or change
+    # ---- cache invalidation whenever the fp32 master parameters move or change.  ``pack_version`` counts them: captured
+    # hipGraphs hold raw pointers into the packed tensors and key themselves on it.
+    pack_version = 0
+
     def invalidate_packed(self):
         self._pk = {}
+        self.pack_version += 1
 
     def load_state_dict(self, *a, **k):
-        self._pk = {}
+        self.invalidate_packed()
         return super().load_state_dict(*a, **k)
 
     def _load_from_state_dict(self, *a, **k):
-        self._pk = {}
+        self.invalidate_packed()
         return super()._load_from_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._pk = {}
+        self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 
     # ---- packing

@@ -74,7 +74,7 @@ class RestoreEDMSampler(BaseDiffusionSampler):
             if context.final_decode is not None:
                 return context.final_decode, threshold
             raise RuntimeError("feature cache hit without a cached prediction")  # unreachable: step 0 always misses
-        context.prev = partial_info["h"]   # stage 2 never writes into it, so no clone is needed
+        context.prev = partial_info["h"].clone()   # (:581) a replayed graph overwrites its static output on the next step
         denoised = denoiser(*self.guider.prepare_inputs(x, sigma, cond, uc), control_scale=control_scale,
                             fbcache_mode=self.fb_mode + "2", partial_info=partial_info)
         denoised = self.guider(denoised, sigma)
@@ -106,7 +106,7 @@ class RestoreEDMSampler(BaseDiffusionSampler):
         if not miss:
             return context.final_decode, new_thr
         if len(miss) == B:
-            context.prev = h
+            context.prev = h.clone()
             denoised = self.guider(denoiser(x2, s2, c2, control_scale=control_scale, fbcache_mode=self.fb_mode + "2",
                                             partial_info=partial_info), sigma)
             context.final_decode = denoised
