@@ -399,8 +399,6 @@ def bench_stage2(args, dev, rank, world):
             args.s2_threshold = 0.3
     t0 = time.perf_counter()
     m = build_stage2(dev, args.tile_vae)
-    if args.no_graph:
-        m.graph_replay = False        # A/B: launch the denoiser call eagerly instead of replaying its hipGraph (latents <= 128)
     side = args.s2_side
     img = torch.cat([synthetic_image((1, 3, side, side), seed=1234 + rank * args.batch + i, smooth=4)
                      for i in range(args.batch)]).to(dev)
@@ -535,7 +533,7 @@ def main():
     ap.add_argument("--s2-threshold", type=float, default=None, help="feature-cache threshold (headline: 0 = off; c3/s2: 0.3)")
     ap.add_argument("--tile-vae", action="store_true", help="s2: VAEHook tiling (needed from 2048x2048 up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="c2 / s2: launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="c2: launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--pmc-pass", action="store_true", help="c4: one iteration of each stage + the fixed part and nothing "
                                                              "else (the process rocprofv3 --pmc counts)")
     args = ap.parse_args()

@@ -41,9 +41,6 @@ class SR_backbone(DiffusionEngine):
         self.p_p, self.n_p = p_p, n_p
         self.noise_source = "device"
         self.upscale, self.min_size = 1, 256
-        # hipGraph replay of the denoiser call: "auto" = latents up to 128 x 128 (launch-bound there; at 256+ the launches
-        # are long enough for the host to stay ahead); True / False force it
-        self.graph_replay = "auto"
 
     # ---- first stage ------------------------------------------------------------------------
     @torch.no_grad()
@@ -175,8 +172,6 @@ class SR_backbone(DiffusionEngine):
             # the cache decides PER IMAGE: one threshold per image; sampler.step then returns a list
             img_threshold = [float(img_threshold)] * N
         stamp("sampler_init")
-        L = max(_z.shape[-2:])
-        self.model.use_graph = (L <= 128) if self.graph_replay == "auto" else bool(self.graph_replay)
         self.cache_trace = []
         n_iter = num_sigmas - 1 if _max_steps is None else min(_max_steps, num_sigmas - 1)
         with cache_context(MyCacheContext()) as ctx:
