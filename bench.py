@@ -564,6 +564,8 @@ def main():
         local = int(os.environ["RSVLD_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:   # N ranks initialise 3.9 B parameters each on the host at the same time: share the cores instead of fighting
+        torch.set_num_threads(max(4, schedulable_cores() // world))
     if headline:
         bench_headline(args, dev, rank, world)
     elif args.workload in ("s2", "c3"):
