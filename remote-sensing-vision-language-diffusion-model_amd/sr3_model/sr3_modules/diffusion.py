@@ -83,6 +83,8 @@ class GaussianDiffusion(nn.Module):
         self.denoise_fn, self.loss_type, self.conditional = denoise_fn, loss_type, conditional
         self.noise_source = "device"
         self.use_graph = False     # replay the UNet forward from a captured hipGraph (one per input shape)
+        self.batch_invariant = False   # plan every launch for ONE image of the batch (ops.plan_units): image b of a batch is then
+                                       # bit-identical to its batch-of-1 run, at some cost in launch plans tuned to the whole batch
         self._graphs = {}
         self._host = None
 
@@ -173,6 +175,13 @@ class GaussianDiffusion(nn.Module):
     def p_sample_loop(self, x_in, continous=False, _max_steps=None, _stamp=None):
         """``_max_steps`` / ``_stamp`` are measurement hooks (bench.py): run only the first ``_max_steps`` ancestral
         steps, and call ``_stamp(name)`` at the phase borders (set-up | loop)."""
+        if self.batch_invariant:
+            B = x_in.shape[0] if self.conditional else x_in[0]
+            with ops.plan_units(B):
+                return self._p_sample_loop(x_in, continous, _max_steps, _stamp)
+        return self._p_sample_loop(x_in, continous, _max_steps, _stamp)
+
+    def _p_sample_loop(self, x_in, continous, _max_steps, _stamp):
         if self._host is None:
             raise RsvldError("call set_new_noise_schedule() first")
         device = self.betas.device

@@ -74,3 +74,53 @@ def test_live_llava_caption_on_device(cuda, tmp_path):
     assert isinstance(a, str) and a == b and len(a) > 0
     pipe.cfg.caption = "a river delta"
     assert pipe.run_stage2_captioning(img) == "a river delta"
+
+
+def test_pipeline_with_live_caption_end_to_end(cuda, tmp_path):
+    """BASELINE configs[3] in miniature: Stage 1 -> uint8 hand-off -> LIVE LLaVA-NeXT caption (tiny seeded model on the device)
+    -> Stage 2 with that caption -> PNG, through SuperResolutionPipeline.process() exactly as the CLI runs it."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import llava_common as C
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModel
+    from rsvld_amd import infer, llava_next as LN
+    cfg = yaml.safe_load(open(S.YAML.replace("juggernautXL.yaml", "juggernautXL_cached.yaml")))
+    for k in ("control_stage_config", "network_config"):
+        cfg["model"]["params"][k]["params"].update(S.SMALL)
+    c, uc = S.cond_dicts()
+    torch.save(c, tmp_path / "c.pth")
+    torch.save(uc, tmp_path / "uc.pth")
+    cfg["model"]["params"]["conditioner_config"]["params"] = {"cond_pth": str(tmp_path / "c.pth"), "un_cond_pth": str(tmp_path / "uc.pth")}
+    cfg["SR_CKPT"] = cfg["SR_CKPT_Q"] = None
+    yaml.safe_dump(cfg, open(tmp_path / "model.yaml", "w"))
+    rng = np.random.default_rng(1)
+    Image.fromarray(rng.integers(0, 255, (32, 32, 3), dtype=np.uint8)).save(tmp_path / "tile.png")
+    pc = infer.PipelineConfig(input_img=str(tmp_path / "tile.png"), output_dir=str(tmp_path / "out"), model_yaml=str(tmp_path / "model.yaml"),
+                              allow_random_init=True, no_llava=True, upscale_factor=2, min_size=128, edm_steps=2, sr3_steps=2,
+                              seed=1, img_threshold=0.3, base_model_device="cuda:0")
+    pipe = infer.SuperResolutionPipeline(pc)                 # no_llava=True: nothing is loaded from disk ...
+    tower_dir = C.save_tiny_clip(str(tmp_path / "clip"))     # ... the tiny captioner is put where load_llava() puts the 8 B one
+    lcfg = LN._llama_config_cls()(**C.LLAMA, **C.MM, mm_vision_tower=tower_dir)
+    lcfg._attn_implementation = "sdpa"
+    llava = LN.build_model(lcfg, clip=CLIPVisionModel(CLIPVisionConfig(**C.VISION))).eval()
+    C.name_seeded_state(llava, C.WEIGHT_SEED)
+    pipe.llava_model, pipe.llava_tokenizer = llava.to(device=cuda, dtype=torch.float16), C.build_tokenizer()
+    pipe.llava_image_processor = CLIPImageProcessor.from_pretrained(tower_dir)
+    pipe.cfg.no_llava = False
+    seen = {}
+    orig = pipe.refinement_model.just_sampling
+
+    def spy(x, p, *a, **k):
+        seen["caption"] = p[0]
+        return orig(x, p, *a, **k)
+
+    pipe.refinement_model.just_sampling = spy
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p_ in pipe.refinement_model.parameters():
+            if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
+                p_.copy_((torch.randn(p_.shape, generator=g) * 0.02).to(p_.device))
+    outs = pipe.process()
+    assert isinstance(seen["caption"], str) and len(seen["caption"]) > 0          # the live caption reached Stage 2
+    assert [os.path.basename(o) for o in outs] == ["tile_final_0.png"]
+    assert np.asarray(Image.open(outs[0])).std() > 1.0

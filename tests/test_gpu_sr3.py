@@ -154,3 +154,30 @@ def test_unet_forward_vs_oracle_fresh_input(sr3, cuda):
     e = _err(got, want)
     print(f"unet vs oracle 48x80: max|d| = {e:.3e}")
     assert e < 8e-3          # measured 4.0e-3
+
+
+def test_batch_invariant_sampling(sr3, cuda):
+    """``batch_invariant = True`` plans every launch for one image (rsvld_conv_desc.plan_div): images of a batch of 3 are
+    bit-identical to their batch-of-1 runs (what data-parallel sharding with batches per rank relies on)."""
+    from oracle import seeded
+    net, _ = sr3
+    net.set_new_noise_schedule(dict(schedule="linear", n_timestep=4, linear_start=1e-6, linear_end=1e-2), cuda)
+    cond = torch.cat([seeded.synthetic_image((1, 3, 64, 64), seed=20 + i, smooth=3) for i in range(3)]).to(cuda)
+    noises = [torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(70 + i)) for i in range(5)]
+
+    def run(sl):
+        it = iter(noises)
+        net._randn = lambda shape, device: next(it)[sl].to(device)
+        try:
+            return net.super_resolution(cond[sl], continous=True)[-len(range(3)[sl]):].cpu()
+        finally:
+            del net._randn
+
+    net.batch_invariant = True
+    try:
+        both = run(slice(0, 3))
+        for b in range(3):
+            one = run(slice(b, b + 1))
+            assert torch.equal(both[b:b + 1], one), f"image {b}: batched vs single max|d| = {float((both[b:b+1] - one).abs().max()):.3e}"
+    finally:
+        net.batch_invariant = False
