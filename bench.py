@@ -160,6 +160,25 @@ def kernel_table(summ):
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
 
 
+PMC_ALIAS = {"attention_d64": "attn_d64", "attention_d512": "attn_d512", "gemm_256x256": "gemm256"}
+
+
+def mfma_busy_of_pass(summ, pmc_file):
+    """Time-weighted MFMA-busy fraction of the instrumented pass: every kernel group's busy fraction from the committed PMC
+    passes of this workload (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)) weighted by its HIP-event time
+    in THIS run; kernels without matrix work (or without a PMC entry) count as 0."""
+    path = os.path.join(ROOT, "profiles", pmc_file)
+    if not os.path.exists(path):
+        return None
+    kern = json.load(open(path)).get("kernels", {})
+    tot = sum(r["ms"] for r in summ.values())
+    acc = 0.0
+    for name, r in summ.items():
+        k = kern.get(name, kern.get(PMC_ALIAS.get(name, ""), {}))
+        acc += r["ms"] * float(k.get("mfma_busy_frac_est") or 0.0)
+    return round(acc / tot, 3) if tot > 0 else None
+
+
 def roofline_of(summ, pmc_file):
     """The dominant kernel = the group with the largest time share of the instrumented pass."""
     dom = max(summ.values(), key=lambda r: r["ms"])
@@ -167,9 +186,8 @@ def roofline_of(summ, pmc_file):
     traffic, src, busy = None, None, None
     path = os.path.join(ROOT, "profiles", pmc_file)
     if os.path.exists(path):
-        alias = {"attention_d64": "attn_d64", "attention_d512": "attn_d512", "gemm_256x256": "gemm256"}
         kern = json.load(open(path)).get("kernels", {})
-        k = kern.get(dom["name"], kern.get(alias.get(dom["name"], "")))
+        k = kern.get(dom["name"], kern.get(PMC_ALIAS.get(dom["name"], "")))
         if k is not None:
             traffic, src = round(k["hbm_bytes_per_launch"]), f"profiles/{pmc_file}"
             busy = None if k.get("mfma_busy_frac_est") is None else round(k["mfma_busy_frac_est"], 3)
@@ -373,6 +391,7 @@ def bench_headline(args, dev, rank, world):
                 "phases_ms": {k: round(v * 1e3, 1) for k, v in a.items()},
                 "timed_region_s": round(dt, 2), "model_build_s": round(build_s, 1), "finite": finite,
                 "algorithmic_tflops_whole_image": round(tf_img / (T * it1 + T * it2 + fx), 1),
+                "mfma_busy_instrumented_pass_pmc": mfma_busy_of_pass(summ, "r02_c4_pmc_traffic.json"),
                 "feature_cache": "off" if thr <= 0 else thr},
             "roofline": roof}
     if rank == 0:
