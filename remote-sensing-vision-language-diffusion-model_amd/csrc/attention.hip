@@ -488,7 +488,7 @@ namespace {
 constexpr int A6B_TILE = 64 * 128;            // 64 keys x 64 d, 16-bit
 #ifndef A6B_ABL
 #define A6B_ABL 0   // diagnostic builds (tools/ablate_attn.sh; results WRONG, timing only): 1 no exp, 2 no in-loop DMA / barrier,
-                    // 8 no running max / row sum
+                    // 8 no running max / row sum, 16 no V fragment reads, 32 no K fragment reads
 #endif
 constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
 
@@ -500,6 +500,7 @@ constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
 #ifndef A6B_OCC4
 #define A6B_OCC4 1
 #endif
+
 // NW = waves per workgroup: 4 (128 query rows) or 8 (256 query rows).  The 64-key K / V tile is filled once per workgroup,
 // so with 8 waves every wave issues ONE LDS-DMA piece per tensor per tile instead of two and there is one barrier per 256
 // query rows: the in-loop DMA + barrier cost (ablation: +13 % without it at 65 536 tokens) is halved per MFMA.  Two
@@ -612,8 +613,10 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    v8 abl_frag = *(const v8*)(smem + koff[0]);   // diagnostic builds only (A6B_ABL & 48): one constant fragment instead of LDS reads
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
+        if (A6B_ABL & 48) asm volatile("" : "+v"(abl_frag));
         if (!(A6B_ABL & 2) && t + 1 < nt) dma_tile(t + 1);   // the other buffers were last read in tile t-1, before the barrier
         const char* Ks = smem + buf * A6B_TILE;
         const int vb = buf * A6B_TILE;
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         for (int kt = 0; kt < 2; ++kt) {
             if (A6B_OCC4) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const v8*)(Ks + kt * 4096 + koff[ks]);
+                for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = (A6B_ABL & 32) ? abl_frag : *(const v8*)(Ks + kt * 4096 + koff[ks]);
             }
             if constexpr (__is_same(T, f16)) {
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sacc[kt]) : "v"(kf[kt][0]), "v"(qf[0]));
@@ -655,6 +658,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
+                    if (A6B_ABL & 16) { vf[dt][s4] = abl_frag; continue; }
                     const int off = vb + voff[dt] + s4 * 2048;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off + 1024));
