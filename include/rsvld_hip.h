@@ -38,6 +38,7 @@ extern "C" {
 
 #define RSVLD_F16 0
 #define RSVLD_BF16 1
+#define RSVLD_F32 2   /* accepted ONLY by the *_f32 entry points at the end of this header */
 
 /* epilogue activations for rsvld_conv2d_nhwc */
 #define RSVLD_ACT_NONE 0
@@ -270,6 +271,32 @@ int rsvld_adain(const float* content, const float* style, float* out, float* ws_
 /* channel concatenation of two 16-bit NHWC tensors [rows,C1] | [rows,C2] -> [rows,C1+C2] */
 int rsvld_concat_c(const void* a, const void* b, void* out, int64_t rows, int C1, int C2,
                    int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * fp32-operand family: the VAE under ``ae_dtype: fp32`` (models/SR_model.py:28-33 runs it without autocast;
+ * sgm/modules/diffusionmodules/model.py:55-262,482-743).  fp32 NHWC activations (C % 8 == 0), fp32 K-major weights,
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32).  Accuracy mode: simple LDS tiling, 1/16 of the 16-bit matrix rate.
+ * ------------------------------------------------------------------------------------- */
+/* rsvld_conv2d_nhwc with dtype = RSVLD_F32: x, w, residual, out are fp32; x2 / rowvec / GEGLU unsupported;
+ * out_f32, plan_div and tune are ignored (the plan never depends on the batch). */
+int rsvld_conv2d_nhwc_f32(const rsvld_conv_desc* d, void* stream);
+/* GroupNorm on fp32 NHWC [B,HW,C]: statistics (mean, biased variance) per (image, group) through fp64 partial sums
+ * merged in a fixed order; apply = (x - mean) * rsqrt(var + eps) * gamma + beta (+ SiLU). */
+int64_t rsvld_groupnorm_f32_ws_bytes(int B, int HW, int C, int groups);
+int rsvld_groupnorm_stats_f32(const float* x, float* mean_var, int B, int HW, int C, int groups, void* ws, void* stream);
+int rsvld_groupnorm_apply_f32(const float* x, float* y, const float* mean_var, const float* gamma, const float* beta,
+                              int B, int HW, int C, int groups, float eps, int silu, void* stream);
+/* rsvld_attention on fp32 tensors (same addressing; D % 32 == 0, D <= 512; scores never materialised) */
+int rsvld_attention_f32(const float* q, const float* k, const float* v, float* out,
+                        int B, int heads, int Nq, int Nk, int D,
+                        int64_t q_batch_stride, int64_t q_tok_stride,
+                        int64_t k_batch_stride, int64_t k_tok_stride,
+                        int64_t v_batch_stride, int64_t v_tok_stride,
+                        int64_t o_batch_stride, int64_t o_tok_stride,
+                        float scale, void* stream);
+/* rsvld_nchw_f32_to_nhwc with an fp32 destination */
+int rsvld_nchw_f32_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W,
+                               int Cdst, int c_off, int zero_pad, float scale, void* stream);
 
 #ifdef __cplusplus
 }

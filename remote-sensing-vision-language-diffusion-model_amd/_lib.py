@@ -10,7 +10,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # RSVLD_LIB: developer override used by the ablation / A-B tools (another build of the same library)
 LIB_PATH = os.environ.get("RSVLD_LIB") or os.path.join(_PKG_DIR, "librsvld_hip.so")
 
-F16, BF16 = 0, 1
+F16, BF16, F32 = 0, 1, 2   # F32: the *_f32 entry points only (fp32-operand VAE family)
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 # rsvld_conv_desc.tune (developer A/B overrides)
 TUNE_TILE = {"256x64": 1, "128x64": 2, "128x128": 3, "64x128": 4}
@@ -77,6 +77,13 @@ SIGNATURES = {
     "rsvld_add_f32": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "rsvld_adain": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "rsvld_concat_c": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "rsvld_conv2d_nhwc_f32": (_i, [C.POINTER(ConvDesc), _vp]),
+    "rsvld_groupnorm_f32_ws_bytes": (_i64, [_i, _i, _i, _i]),
+    "rsvld_groupnorm_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rsvld_groupnorm_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "rsvld_attention_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
+    "rsvld_nchw_f32_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
 }
 
 _lib = None

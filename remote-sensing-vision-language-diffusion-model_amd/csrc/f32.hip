@@ -1,0 +1,417 @@
+// f32.hip — the fp32-operand kernel family behind ``ae_dtype: fp32`` (reference: models/SR_model.py:28-33 — the VAE
+// runs without autocast).  Everything the VAE needs, on fp32 NHWC tensors with fp32 weights:
+//   conv_f32_kernel        implicit-GEMM convolution / 1x1 on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate)
+//   gn_f32_*               GroupNorm statistics (fp64 partial sums, fixed merge order) and apply (+SiLU)
+//   attn_f32_kernel        flash-style attention (scores never materialised), any head dim that is a multiple of 32 up to 512
+//   nchw_to_nhwc_f32       layout conversion
+// This is the ACCURACY mode of the library, not the fast path: simple LDS tiling, no LDS-DMA pipelines.  The fp32 matrix
+// rate of gfx950 is 1/16 of the 16-bit rate, so the reference's default (bf16 VAE) stays the benchmarked configuration.
+#include "rsvld_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------- convolution
+// out[m][n] = sum_k A[m][k] W[n][k];  m = (b, oy, ox), k = (tap, channel), gathered on the fly.
+// Workgroup: 4 waves, 64 output pixels x 64 output channels, wave (wm, wn) owns 32 x 32.  K in chunks of 32 through LDS.
+// MFMA 32x32x2 f32 operand map: lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31];
+// D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+struct ConvF32Args {
+    const float* x; const float* w; const float* bias; const float* res; float* out;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, ups, act;
+    float alpha, beta;
+    int Ktot;
+    int64_t M;
+};
+constexpr int CF_BK = 32, CF_LD = CF_BK + 1;   // 33-float rows: the 32 rows one ds_read_b32 touches sit on 32 banks
+
+__global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args p) {
+    __shared__ float As[64 * CF_LD];
+    __shared__ float Bs[64 * CF_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    const int lr = tid >> 3, kq = (tid & 7) * 4;   // staging: rows lr and lr + 32, floats kq .. kq+3 of the chunk
+
+    // the two A rows this thread stages: pixel coordinates
+    int64_t xb[2];
+    int oy[2], ox[2];
+    bool mv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = m0 + lr + 32 * i;
+        mv[i] = m < p.M;
+        const int64_t mm = mv[i] ? m : 0;
+        const int64_t b = mm / ((int64_t)p.Ho * p.Wo);
+        const int r = (int)(mm - b * (int64_t)p.Ho * p.Wo);
+        oy[i] = r / p.Wo;
+        ox[i] = r - oy[i] * p.Wo;
+        xb[i] = b * (int64_t)p.H * p.W;
+    }
+    const int Hin = p.ups ? 2 * p.H : p.H, Win = p.ups ? 2 * p.W : p.W;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int k0 = 0; k0 < p.Ktot; k0 += CF_BK) {
+        const int k = k0 + kq;
+        const bool kv = k < p.Ktot;          // Ktot % 8 == 0: a quad is inside or outside as a whole
+        int ky = 0, kx = 0, c = 0;
+        if (kv) {
+            const int tap = k / p.Cin;
+            c = k - tap * p.Cin;
+            ky = tap / p.KW;
+            kx = tap - ky * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kv && mv[i]) {
+                int iy = oy[i] * p.stride + ky - p.pad_t, ix = ox[i] * p.stride + kx - p.pad_l;
+                if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
+                    if (p.ups) { iy >>= 1; ix >>= 1; }
+                    v = *(const f32x4*)(p.x + ((xb[i] + (int64_t)iy * p.W + ix) * p.Cin + c));
+                }
+            }
+            float* d = As + (lr + 32 * i) * CF_LD + kq;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+            const int n = n0 + lr + 32 * i;
+            if (kv && n < p.Cout) wv = *(const f32x4*)(p.w + (int64_t)n * p.Ktot + k);
+            float* e = Bs + (lr + 32 * i) * CF_LD + kq;
+            e[0] = wv[0]; e[1] = wv[1]; e[2] = wv[2]; e[3] = wv[3];
+        }
+        __syncthreads();
+        const float* ar = As + (wm * 32 + (lane & 31)) * CF_LD + (lane >> 5);
+        const float* br = Bs + (wn * 32 + (lane & 31)) * CF_LD + (lane >> 5);
+#pragma unroll
+        for (int s = 0; s < CF_BK / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * s], br[2 * s], acc, 0, 0, 0);
+        __syncthreads();
+    }
+
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n >= p.Cout) return;
+    const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = acc[r] + bv;
+        if (p.act == RSVLD_ACT_SILU) v = v / (1.0f + expf(-v));
+        v *= p.alpha;
+        if (p.res != nullptr) v += p.beta * p.res[m * p.Cout + n];
+        p.out[m * p.Cout + n] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- GroupNorm
+// statistics: grid (chunks, groups, B); partial (sum, sum of squares) in fp64 -> ws[b][g][chunk][2]; merged in chunk order
+__global__ __launch_bounds__(256) void gn_f32_partial_kernel(const float* __restrict__ x, double* __restrict__ ws, int64_t HW,
+                                                             int C, int cpg, int64_t pix_per_chunk) {
+    const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z, nchunk = gridDim.x, groups = gridDim.y;
+    const int64_t p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
+    const float* xb = x + ((int64_t)b * HW) * C + (int64_t)g * cpg;
+    double s = 0.0, ss = 0.0;
+    const int64_t total = (p1 - p0) * cpg;
+    for (int64_t e = threadIdx.x; e < total; e += 256) {
+        const int64_t pix = p0 + e / cpg;
+        const int c = (int)(e % cpg);
+        const double v = (double)xb[pix * C + c];
+        s += v;
+        ss += v * v;
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* o = ws + (((int64_t)b * groups + g) * nchunk + chunk) * 2;
+        o[0] = sh[0][0];
+        o[1] = sh[1][0];
+    }
+}
+
+__global__ void gn_f32_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean_var, int nchunk, int total,
+                                       double inv_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (b, g)
+    if (i >= total) return;
+    double s = 0.0, ss = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+        s += ws[((int64_t)i * nchunk + c) * 2];
+        ss += ws[((int64_t)i * nchunk + c) * 2 + 1];
+    }
+    const double mean = s * inv_count;
+    double var = ss * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_var[2 * i] = (float)mean;
+    mean_var[2 * i + 1] = (float)var;
+}
+
+__global__ __launch_bounds__(256) void gn_f32_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           const float* __restrict__ mean_var, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int64_t HW, int C, int cpg, int groups,
+                                                           float eps, int silu, int64_t total4) {
+    const int C4 = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / C4;
+        const int c = (int)(i - pix * C4) * 4;
+        const int64_t b = pix / HW;
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            const float mean = mean_var[(b * groups + g) * 2], var = mean_var[(b * groups + g) * 2 + 1];
+            float t = (v[e] - mean) * (1.0f / sqrtf(var + eps)) * gamma[c + e] + beta[c + e];
+            if (silu) t = t / (1.0f + expf(-t));
+            o[e] = t;
+        }
+        *(f32x4*)(y + i * 4) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- attention
+// One workgroup = 32 query rows, 4 waves.  Key tiles of 32.  S^T = K Q^T (rows = keys, column = the lane's query row),
+// contraction over d split across the waves by 32-wide blocks (wave w owns blocks w, w+4, ...), partial S^T summed through LDS so
+// that every wave holds the SAME full tile and takes identical softmax decisions; O^T[d][q] accumulates per wave for its own
+// d-blocks.  P^T is consumed straight from the score registers: the contraction index of the second MFMA is ordered like the
+// score registers (kk = 2s + h  ->  key (s&3) + 8(s>>2) + 4h), so V rows are fetched in that order and no shuffle is needed.
+struct AttnF32Args {
+    const float* q; const float* k; const float* v; float* out;
+    int Nq, Nk, D;
+    int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+    float scale;
+};
+constexpr int AF_MAXBLK = 4;   // d-blocks per wave: D <= 4 waves x 4 x 32 = 512
+
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
+    extern __shared__ float af_smem[];
+    const int D = p.D, LDK = D + 1, nblk = D >> 5;
+    float* Ks = af_smem;                 // [32][D + 1]
+    float* red = af_smem + 32 * LDK;     // [4][16][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 32, head = blockIdx.y, b = blockIdx.z;
+    const float* Qb = p.q + (int64_t)b * p.q_bs + (int64_t)head * D;
+    const float* Kb = p.k + (int64_t)b * p.k_bs + (int64_t)head * D;
+    const float* Vb = p.v + (int64_t)b * p.v_bs + (int64_t)head * D;
+    const int qrow = min(q0 + l31, p.Nq - 1);
+
+    // Q fragments of this wave's d-blocks: B operand, B[k = d][col = q] = Q[q][d]
+    float qf[AF_MAXBLK][16];
+#pragma unroll
+    for (int j = 0; j < AF_MAXBLK; ++j) {
+        const int blk = w + 4 * j;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) qf[j][s] = blk < nblk ? Qb[(int64_t)qrow * p.q_ts + blk * 32 + 2 * s + h] : 0.f;
+    }
+    f32x16 oacc[AF_MAXBLK];
+#pragma unroll
+    for (int j = 0; j < AF_MAXBLK; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (p.Nk + 31) >> 5;
+    for (int t = 0; t < nt; ++t) {
+        const int key0 = t * 32;
+        // ---- K tile -> LDS (rows past Nk: zeros, their scores are masked below)
+        for (int e = tid; e < 32 * (D >> 2); e += 256) {
+            const int row = e / (D >> 2), c4 = (e - row * (D >> 2)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key0 + row < p.Nk) v = *(const f32x4*)(Kb + (int64_t)(key0 + row) * p.k_ts + c4);
+            float* d = Ks + row * LDK + c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+        __syncthreads();
+        // ---- partial S^T over this wave's d-blocks
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < AF_MAXBLK; ++j) {
+            const int blk = w + 4 * j;
+            if (blk < nblk) {
+                const float* kr = Ks + l31 * LDK + blk * 32 + h;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * s], qf[j][s], sacc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = sacc[r];
+        __syncthreads();
+        // ---- full tile in every wave (same summation order everywhere), online softmax in the lane's query column
+        float sc[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) +
+                      red[(3 * 16 + r) * 64 + lane];
+            s *= p.scale;
+            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key >= p.Nk) s = -INFINITY;
+            sc[r] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);            // finite: every tile holds at least one valid key
+        const float alpha = expf(m_run - m_new);         // 0 on the first tile
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = expf(sc[r] - m_new);
+            rs += sc[r];
+        }
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        // ---- O^T[d][q] = alpha O^T + V^T P^T for this wave's d-blocks; V rows straight from global memory (coalesced along d)
+#pragma unroll
+        for (int j = 0; j < AF_MAXBLK; ++j) {
+            const int blk = w + 4 * j;
+            if (blk < nblk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int key = min(key0 + (s & 3) + 8 * (s >> 2) + 4 * h, p.Nk - 1);   // clamped rows carry P = 0
+                    const float vv = Vb[(int64_t)key * p.v_ts + blk * 32 + l31];
+                    oacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[s], oacc[j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // Ks / red are rewritten by the next tile
+    }
+
+    if (q0 + l31 >= p.Nq) return;
+    const float inv = 1.0f / l_run;
+    float* Ob = p.out + (int64_t)b * p.o_bs + (int64_t)head * D + (int64_t)(q0 + l31) * p.o_ts;
+#pragma unroll
+    for (int j = 0; j < AF_MAXBLK; ++j) {
+        const int blk = w + 4 * j;
+        if (blk < nblk) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = oacc[j][4 * g + e] * inv;
+                *(f32x4*)(Ob + blk * 32 + 8 * g + 4 * h) = o;   // rows (reg&3) + 8 (reg>>2) + 4 h of the block
+            }
+        }
+    }
+}
+
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t HW, int Cdst,
+                                        int c_off, int zero_pad, float scale, int64_t total_pix) {
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= total_pix) return;
+    const int64_t b = pix / HW, r = pix - b * HW;
+    float* d = dst + pix * Cdst;
+    if (zero_pad) {
+        for (int c = 0; c < Cdst; ++c) {
+            const int cs = c - c_off;
+            d[c] = (cs >= 0 && cs < C) ? src[(b * C + cs) * HW + r] * scale : 0.f;
+        }
+    } else {
+        for (int c = 0; c < C; ++c) d[c_off + c] = src[(b * C + c) * HW + r] * scale;
+    }
+}
+
+static int gn_f32_chunks(int64_t HW) {
+    int64_t n = (HW + 4095) / 4096;
+    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+}
+
+}  // namespace
+
+extern "C" int rsvld_conv2d_nhwc_f32(const rsvld_conv_desc* d, void* stream) {
+    if (d == nullptr || d->x == nullptr || d->w == nullptr || d->out == nullptr) return RSVLD_EINVAL;
+    if (d->dtype != RSVLD_F32) return RSVLD_EINVAL;
+    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || d->act == RSVLD_ACT_GEGLU) return RSVLD_EUNSUPPORTED;
+    if (d->Cin % 8 != 0 || d->Cout % 8 != 0 || d->B < 1 || d->H < 1 || d->W < 1 || d->KH < 1 || d->KW < 1 || d->stride < 1)
+        return RSVLD_EINVAL;
+    if (d->Ho < 1 || d->Wo < 1) return RSVLD_EINVAL;   // taps outside the (up-sampled) image read zeros, whatever Ho / Wo say
+    ConvF32Args a;
+    a.x = (const float*)d->x; a.w = (const float*)d->w; a.bias = d->bias; a.res = (const float*)d->residual; a.out = (float*)d->out;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride;
+    a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.ups = d->upsample ? 1 : 0; a.act = d->act;
+    a.alpha = d->alpha; a.beta = d->beta;
+    a.Ktot = d->KH * d->KW * d->Cin;
+    a.M = (int64_t)d->B * d->Ho * d->Wo;
+    const int64_t gm = cdiv64(a.M, 64);
+    if (gm > 0x7fffffffLL) return RSVLD_EINVAL;
+    dim3 grid((unsigned)gm, (unsigned)((d->Cout + 63) / 64));
+    hipLaunchKernelGGL(conv_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return rsvld_check_launch();
+}
+
+extern "C" int64_t rsvld_groupnorm_f32_ws_bytes(int B, int HW, int C, int groups) {
+    (void)C;
+    if (B < 1 || HW < 1 || groups < 1) return 0;
+    return (int64_t)B * groups * gn_f32_chunks(HW) * 2 * (int64_t)sizeof(double);
+}
+
+extern "C" int rsvld_groupnorm_stats_f32(const float* x, float* mean_var, int B, int HW, int C, int groups, void* ws,
+                                         void* stream) {
+    if (x == nullptr || mean_var == nullptr || ws == nullptr || B < 1 || HW < 1 || C < 1 || groups < 1 || C % groups != 0)
+        return RSVLD_EINVAL;
+    const int nchunk = gn_f32_chunks(HW), cpg = C / groups;
+    const int64_t ppc = cdiv64(HW, nchunk);
+    hipLaunchKernelGGL(gn_f32_partial_kernel, dim3(nchunk, groups, B), dim3(256), 0, (hipStream_t)stream, x, (double*)ws,
+                       (int64_t)HW, C, cpg, ppc);
+    const int total = B * groups;
+    hipLaunchKernelGGL(gn_f32_finalize_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, (const double*)ws,
+                       mean_var, nchunk, total, 1.0 / ((double)HW * cpg));
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_groupnorm_apply_f32(const float* x, float* y, const float* mean_var, const float* gamma, const float* beta,
+                                         int B, int HW, int C, int groups, float eps, int silu, void* stream) {
+    if (x == nullptr || y == nullptr || mean_var == nullptr || gamma == nullptr || beta == nullptr || B < 1 || HW < 1 ||
+        C % 4 != 0 || groups < 1 || C % groups != 0)
+        return RSVLD_EINVAL;
+    const int64_t total4 = (int64_t)B * HW * (C / 4);
+    int64_t blocks = cdiv64(total4, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(gn_f32_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, mean_var, gamma, beta,
+                       (int64_t)HW, C, C / groups, groups, eps, silu, total4);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int Nq, int Nk,
+                                   int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
+                                   int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride, int64_t o_batch_stride,
+                                   int64_t o_tok_stride, float scale, void* stream) {
+    if (q == nullptr || k == nullptr || v == nullptr || out == nullptr || B < 1 || heads < 1 || Nq < 1 || Nk < 1) return RSVLD_EINVAL;
+    if (D < 32 || D % 32 != 0 || D > 128 * AF_MAXBLK) return RSVLD_EUNSUPPORTED;
+    if ((q_tok_stride | k_tok_stride | v_tok_stride | o_tok_stride | q_batch_stride | k_batch_stride | v_batch_stride |
+         o_batch_stride) % 4 != 0)
+        return RSVLD_EINVAL;   // 16-byte vector accesses
+    AttnF32Args a;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.Nq = Nq; a.Nk = Nk; a.D = D;
+    a.q_bs = q_batch_stride; a.q_ts = q_tok_stride; a.k_bs = k_batch_stride; a.k_ts = k_tok_stride;
+    a.v_bs = v_batch_stride; a.v_ts = v_tok_stride; a.o_bs = o_batch_stride; a.o_ts = o_tok_stride;
+    a.scale = scale;
+    const int smem = (32 * (D + 1) + 4 * 16 * 64) * (int)sizeof(float);   // 81 KiB at D = 512
+    const void* kern = (const void*)attn_f32_kernel;
+    static const hipError_t attr = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (32 * 513 + 4096) * 4);
+    if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    dim3 grid((unsigned)((Nq + 31) / 32), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), smem, (hipStream_t)stream, a);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_nchw_f32_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cdst, int c_off,
+                                          int zero_pad, float scale, void* stream) {
+    if (src == nullptr || dst == nullptr || B < 1 || C < 1 || H < 1 || W < 1 || c_off < 0 || c_off + C > Cdst) return RSVLD_EINVAL;
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
+                       (int64_t)H * W, Cdst, c_off, zero_pad, scale, total);
+    return rsvld_check_launch();
+}

@@ -4,6 +4,9 @@ torch is used here only for device memory (allocation through its caching alloca
 current HIP stream; every computation is a kernel of librsvld_hip.so.  Activations are NHWC
 16-bit tensors ``[B, H, W, C]`` with ``C % 8 == 0``; tokens ``[B, N, C]`` are the same thing with
 ``H = 1``.  Every function raises if the tensor is not on a GPU: there is no CPU path.
+
+fp32 activations select the fp32-operand family (csrc/f32.hip, the VAE under ``ae_dtype: fp32``): ``conv2d``,
+``group_norm*``, ``attention`` and ``nchw_to_nhwc`` dispatch on the tensor's dtype; everything else is 16-bit only.
 """
 import contextlib
 import ctypes as C
@@ -192,6 +195,9 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     per-tile per-channel (sum, sumsq) of the output from its epilogue and attaches them to the returned tensor
     (``_gn_part``), so the consumer's ``norm=`` needs no statistics pass at all."""
     _need_gpu(x, x2, pc.w, rowvec, residual)
+    if x.dtype == torch.float32:
+        return _conv2d_f32(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
+                           act=act, alpha=alpha, beta=beta, norm=norm)
     B, H, W, Cin = x.shape
     Cin2 = 0 if x2 is None else x2.shape[-1]
     if Cin + Cin2 != pc.cin_p:
@@ -288,6 +294,43 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     return out
 
 
+def _conv2d_f32(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm):
+    """fp32 NHWC convolution with fp32 packed weights (rsvld_conv2d_nhwc_f32); a ``norm=`` GroupNorm runs first, unfused."""
+    if x2 is not None or rowvec is not None or act == L.ACT_GEGLU:
+        raise L.RsvldError("conv2d (fp32): two-source input, row vectors and GEGLU exist in the 16-bit family only")
+    if pc.w.dtype != torch.float32:
+        raise L.RsvldError("conv2d (fp32): weights must be packed in fp32 (the owning network's compute_dtype)")
+    if norm is not None:
+        gamma, nbeta, groups, eps, silu = norm
+        x = group_norm(x, gamma, nbeta, groups, eps, silu=silu)
+    B, H, W, Cin = x.shape
+    if Cin != pc.cin_p:
+        raise L.RsvldError(f"conv2d: input channels {Cin} != packed {pc.cin_p}")
+    if pad is None:
+        pad = pc.kh // 2
+    pt, pl, pb, pr = (pad,) * 4 if isinstance(pad, int) else pad
+    Hin, Win = (2 * H, 2 * W) if upsample else (H, W)
+    Ho = (Hin + pt + pb - pc.kh) // stride + 1
+    Wo = (Win + pl + pr - pc.kw) // stride + 1
+    out = torch.empty((B, Ho, Wo, pc.cout_p), device=x.device, dtype=torch.float32)
+    if not x.is_contiguous():
+        raise L.RsvldError("conv2d: inputs must be contiguous NHWC")
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()
+                                 or residual.dtype != torch.float32):
+        raise L.RsvldError("conv2d (fp32): residual must be fp32 and match the output shape")
+    d = L.ConvDesc(
+        x=x.data_ptr(), x2=None, w=pc.w.data_ptr(), bias=None if pc.bias is None else pc.bias.data_ptr(), rowvec=None,
+        residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
+        B=B, H=H, W=W, Cin=Cin, Cin2=0, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo,
+        upsample=int(upsample), dtype=L.F32, out_f32=1, act=act, alpha=alpha, beta=beta, rowvec_stride=0, plan_div=1, tune=0)
+    flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
+    nbytes = 4.0 * (x.numel() + pc.w.numel() + out.numel() + (0 if residual is None else residual.numel()))
+    _launch("conv_f32", flops, nbytes, lambda: L.check(L.load().rsvld_conv2d_nhwc_f32(C.byref(d), _stream()),
+                                                       "rsvld_conv2d_nhwc_f32"))
+    out._nhwc = True     # an fp32 4-d tensor is otherwise taken for NCHW by the VAE's input adapter
+    return out
+
+
 def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0):
     """``[..., Cin] -> [..., Cout]`` on token-major tensors (a 1x1 conv over rows)."""
     shp = x.shape
@@ -307,6 +350,10 @@ def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=
         if mod_shift.stride(-2) != mod_stride or mod_scale1p.stride(-1) != 1 or mod_shift.stride(-1) != 1:
             raise L.RsvldError("group_norm: modulation tensors must share a row stride and be channel-contiguous")
     _need_gpu(x, x2, gamma, beta)
+    if x.dtype == torch.float32:
+        if x2 is not None or mod_scale1p is not None:
+            raise L.RsvldError("group_norm (fp32): two-source input and ZeroSFT modulation exist in the 16-bit family only")
+        return group_norm_apply(x, group_norm_stats(x, groups), gamma, beta, groups, eps, silu=silu)
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
     lib = L.load()
@@ -326,6 +373,14 @@ def group_norm_stats(x, groups, *, x2=None):
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
     lib = L.load()
+    if x.dtype == torch.float32:
+        if x2 is not None or not x.is_contiguous():
+            raise L.RsvldError("group_norm_stats (fp32): one contiguous NHWC tensor expected")
+        ws = torch.empty(lib.rsvld_groupnorm_f32_ws_bytes(B, H * W, C1, groups), device=x.device, dtype=torch.uint8)
+        st = torch.empty((B, groups, 2), device=x.device, dtype=torch.float32)
+        _launch("groupnorm_stats_f32", 0.0, 4.0 * x.numel(), lambda: L.check(
+            lib.rsvld_groupnorm_stats_f32(_ptr(x), _ptr(st), B, H * W, C1, groups, _ptr(ws), _stream()), "rsvld_groupnorm_stats_f32"))
+        return st
     ws = torch.empty(lib.rsvld_groupnorm_ws_bytes(B, H * W, C1 + C2, groups), device=x.device, dtype=torch.uint8)
     st = torch.empty((B, groups, 2), device=x.device, dtype=torch.float32)
     L.check(lib.rsvld_groupnorm_stats(_ptr(x), _ptr(x2), _ptr(st), B, H * W, C1, C2, groups, _dt(x), _ptr(ws),
@@ -338,6 +393,13 @@ def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False)
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((B, H, W, C1 + C2), device=x.device, dtype=x.dtype)
+    if x.dtype == torch.float32:
+        if x2 is not None or not x.is_contiguous():
+            raise L.RsvldError("group_norm_apply (fp32): one contiguous NHWC tensor expected")
+        _launch("groupnorm_apply_f32", 0.0, 8.0 * x.numel(), lambda: L.check(L.load().rsvld_groupnorm_apply_f32(
+            _ptr(x), _ptr(y), _ptr(stats), _ptr(gamma), _ptr(beta), B, H * W, C1, groups, eps, int(silu), _stream()),
+            "rsvld_groupnorm_apply_f32"))
+        return y
     L.check(L.load().rsvld_groupnorm_apply(_ptr(x), _ptr(x2), _ptr(y), _ptr(stats), _ptr(gamma), _ptr(beta), None,
                                            None, 0, B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _stream()),
             "rsvld_groupnorm_apply")
@@ -371,6 +433,14 @@ def attention(q, k, v, heads, scale=None):
     lib = L.load()
     flops = 4.0 * B * heads * Nq * Nk * D
     nbytes = (q.shape[0] * Nq * HD * 2 + 2 * B * Nk * HD) * q.element_size()
+    if q.dtype == torch.float32:
+        if k.dtype != torch.float32 or v.dtype != torch.float32:
+            raise L.RsvldError("attention (fp32): q, k, v must all be fp32")
+        _launch(f"attention_f32_d{D}", flops, nbytes, lambda: L.check(
+            lib.rsvld_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
+                                    q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                    out.stride(0), out.stride(1), scale, _stream()), "rsvld_attention_f32"))
+        return out
     ws_bytes = lib.rsvld_attention_ws_bytes(B, heads, Nq, Nk, D, _PLAN_DIV)   # split-KV partials (D = 512, small grids)
     ws = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8) if ws_bytes > 0 else None
     _launch(f"attention_d{D}", flops, nbytes, lambda: L.check(
@@ -403,7 +473,7 @@ def sinusoidal(t, dim, kind):
 
 # ----------------------------------------------------------------------------- layout / elementwise
 def nchw_to_nhwc(src, dtype, c_dst=None, c_off=0, out=None, scale=1.0):
-    """fp32 NCHW (* scale) -> 16-bit NHWC with channels padded to ``c_dst`` (default: next multiple of 8)."""
+    """fp32 NCHW (* scale) -> 16-bit (or fp32) NHWC with channels padded to ``c_dst`` (default: next multiple of 8)."""
     _need_gpu(src)
     B, Cc, H, W = src.shape
     src = src.contiguous().float()
@@ -413,6 +483,11 @@ def nchw_to_nhwc(src, dtype, c_dst=None, c_off=0, out=None, scale=1.0):
         zero = 1
     else:
         c_dst, zero = out.shape[-1], 0
+    if out.dtype == torch.float32:
+        L.check(L.load().rsvld_nchw_f32_to_nhwc_f32(_ptr(src), _ptr(out), B, Cc, H, W, c_dst, c_off, zero, scale, _stream()),
+                "rsvld_nchw_f32_to_nhwc_f32")
+        out._nhwc = True     # an fp32 4-d tensor is otherwise taken for NCHW by the VAE's input adapter
+        return out
     L.check(L.load().rsvld_nchw_f32_to_nhwc(_ptr(src), _ptr(out), B, Cc, H, W, c_dst, c_off, zero, scale, _DT[out.dtype],
                                             _stream()), "rsvld_nchw_f32_to_nhwc")
     return out

@@ -30,7 +30,8 @@ class AutoencoderKL(HipNet):
             self.load_state_dict(sd.get("state_dict", sd), strict=False)
 
     def set_compute_dtype(self, dt):
-        dt = torch.bfloat16 if dt in (torch.bfloat16, torch.float32) else dt
+        """bf16 (the reference's default), fp16 (tests only: real SDXL-VAE activations overflow it) or fp32 (``ae_dtype:
+        fp32``: the fp32-operand kernel family, csrc/f32.hip)."""
         for m in (self, self.encoder, self.decoder, getattr(self, "denoise_encoder", None)):
             if m is not None and m.compute_dtype != dt:
                 m.compute_dtype = dt

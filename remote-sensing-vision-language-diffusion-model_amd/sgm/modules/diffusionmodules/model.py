@@ -4,7 +4,8 @@ Parameter containers named like sgm/modules/diffusionmodules/model.py (ResnetBlo
 Up/Downsample :55-88, MemoryEfficientAttnBlock :201-262 == AttnBlock parameter-wise,
 Encoder :482-596, Decoder :599-743), so ``first_stage_model.*`` checkpoint keys load unchanged and
 ``utils.tilevae.VAEHook`` finds the attributes it walks (:405-499).  bf16 storage (the reference
-refuses fp16 here, SR_model.py:28-29), fp32 accumulate / statistics:
+refuses fp16 here, SR_model.py:28-29), fp32 accumulate / statistics; with ``compute_dtype = torch.float32``
+(``ae_dtype: fp32``) the same code runs on the fp32-operand kernel family (csrc/f32.hip, unfused GroupNorm):
 
   ResnetBlock   GN(eps 1e-6)+swish -> Conv3x3 -> GN+swish -> Conv3x3 (+ x or nin_shortcut(x) in the epilogue)
   Downsample    the asymmetric (0,1,0,1) zero pad is a property of the gather, not a padded copy
@@ -125,7 +126,13 @@ class _VAEHalf(HipNet):
         if not x.is_cuda:
             raise RsvldError("the VAE runs on the GPU only")
         if x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and x.shape[-1] % 8 == 0:
+            if self.compute_dtype == torch.float32:
+                raise RsvldError("a 16-bit NHWC tensor was handed to the fp32 VAE")
             return x if x.dtype == self.compute_dtype else x.to(self.compute_dtype)
+        if x.dtype == torch.float32 and getattr(x, "_nhwc", False):   # produced by the fp32 kernel family: already NHWC
+            if self.compute_dtype != torch.float32:
+                raise RsvldError("an fp32 NHWC tensor was handed to the 16-bit VAE")
+            return x
         return ops.nchw_to_nhwc(x, self.compute_dtype)
 
 

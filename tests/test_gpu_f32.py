@@ -1,0 +1,167 @@
+"""GPU parity of the fp32-operand kernel family (csrc/f32.hip, ``ae_dtype: fp32``) against plain torch fp32 on the CPU:
+convolution variants the VAE uses, GroupNorm (+SiLU) with own and with supplied statistics, attention at the VAE's head
+dimension, and the tiled VAE (VAEHook) against the reference-generated goldens (the untiled VAE and the pipeline with an
+fp32 VAE: tests/test_gpu_s2.py).
+Tolerances: fp32 MFMA arithmetic in a different summation order -> a few 1e-6 of the tensor's range (asserted at 2e-5)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import s2_common as S
+
+pytestmark = pytest.mark.gpu
+REL = 2e-5
+
+
+def _cmp(got, want, rel, what):
+    want = want.float() if torch.is_tensor(want) else torch.tensor(want).float()
+    got = got.float().cpu()
+    s = float(want.abs().max())
+    e = float((got - want).abs().max())
+    print(f"{what}: max|d| = {e:.3e} (range {s:.2f})")
+    assert e <= rel * max(s, 1e-6), f"{what}: max|d| = {e:.3e}, range {s:.3e}"
+    return e
+
+
+def _nhwc(x, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(dev)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, stride, pad (int or (t, l, b, r)), upsample, residual, silu
+    (2, 64, 64, 24, 20, 3, 1, 1, False, False, False),
+    (1, 8, 128, 16, 16, 3, 1, 1, False, False, False),          # conv_in: 3 channels padded to 8
+    (2, 128, 128, 17, 13, 3, 2, (0, 0, 1, 1), False, False, False),   # Downsample: F.pad (0,1,0,1) + stride 2, ragged M
+    (1, 128, 256, 9, 11, 1, 1, 0, False, True, False),          # nin_shortcut / proj_out with residual
+    (1, 128, 8, 32, 32, 3, 1, 1, False, False, False),          # conv_out: 3 channels padded to 8
+    (1, 256, 256, 6, 5, 3, 1, 1, True, False, False),           # Upsample: nearest x2 folded into the gather
+    (1, 72, 40, 10, 10, 3, 1, 1, False, True, True),            # channel counts that are multiples of 8 only; SiLU epilogue
+    (3, 512, 1536, 4, 4, 1, 1, 0, False, False, False),         # fused q|k|v projection
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_f32(cuda, case):
+    from rsvld_amd import _lib as L, ops
+    B, Cin, Cout, H, W, k, stride, pad, up, use_res, silu = case
+    g = torch.Generator().manual_seed(abs(hash(case)) % 1000)
+    cin_real = 3 if Cin == 8 else Cin
+    cout_real = 3 if Cout == 8 else Cout
+    x = torch.randn(B, cin_real, H, W, generator=g)
+    w = torch.randn(cout_real, cin_real, k, k, generator=g) / math.sqrt(cin_real * k * k)
+    b = torch.randn(cout_real, generator=g) * 0.1
+    pc = ops.pack_conv(w, b, torch.float32, cuda)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    if isinstance(pad, tuple):
+        pt, pl, pb, pr = pad
+        want = F.conv2d(F.pad(xin, (pl, pr, pt, pb)), w, b, stride=stride)
+    else:
+        want = F.conv2d(xin, w, b, stride=stride, padding=pad)
+    if silu:
+        want = F.silu(want)
+    res = torch.randn(want.shape, generator=g) if use_res else None
+    if use_res:
+        want = want + res
+    xd = ops.nchw_to_nhwc(x.to(cuda), torch.float32)
+    assert xd.shape[-1] == Cin and getattr(xd, "_nhwc", False)
+    got = ops.conv2d(xd, pc, stride=stride, pad=pad, upsample=up, residual=None if res is None else _nhwc(res, cuda),
+                     act=L.ACT_SILU if silu else L.ACT_NONE)
+    assert got.dtype == torch.float32 and got.shape == (B, want.shape[2], want.shape[3], Cout)
+    _cmp(got[..., :cout_real].permute(0, 3, 1, 2), want, REL, f"conv_f32 {case}")
+    if cout_real != Cout:
+        assert float(got[..., cout_real:].abs().max()) == 0.0   # padded output channels stay zero
+
+
+@pytest.mark.parametrize("shape,silu", [((2, 128, 19, 23), True), ((1, 512, 8, 8), False), ((1, 32, 70, 66), True),
+                                        ((1, 256, 130, 70), True)])
+def test_group_norm_f32(cuda, shape, silu):
+    """own statistics, statistics-only, and apply with supplied statistics (the tiled VAE's cross-tile path)"""
+    from rsvld_amd import ops
+    B, Cc, H, W = shape
+    g = torch.Generator().manual_seed(Cc + H)
+    x = torch.randn(shape, generator=g) * 3.0 + 0.7
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    want = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    if silu:
+        want = F.silu(want)
+    xd = _nhwc(x, cuda)
+    got = ops.group_norm(xd, gamma.to(cuda), beta.to(cuda), 32, 1e-6, silu=silu)
+    _cmp(got.permute(0, 3, 1, 2), want, REL, f"group_norm_f32 {shape}")
+    st = ops.group_norm_stats(xd, 32).cpu()
+    xg = x.view(B, 32, -1)
+    _cmp(st[..., 0], xg.mean(-1), 1e-6, "  mean")
+    _cmp(st[..., 1], xg.var(-1, unbiased=False), 1e-5, "  biased variance")
+    st2 = torch.stack([torch.randn(B, 32, generator=g), torch.rand(B, 32, generator=g) + 0.5], -1)
+    mean = st2[..., 0].repeat_interleave(Cc // 32, 1)[:, :, None, None]
+    var = st2[..., 1].repeat_interleave(Cc // 32, 1)[:, :, None, None]
+    want2 = (x - mean) / torch.sqrt(var + 1e-6) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    got2 = ops.group_norm_apply(xd, st2.to(cuda), gamma.to(cuda), beta.to(cuda), 32, 1e-6, silu=False)
+    _cmp(got2.permute(0, 3, 1, 2), want2, REL, "  apply with supplied statistics")
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,D", [(1, 1, 200, 200, 512), (2, 1, 64, 64, 128), (1, 2, 45, 77, 64), (1, 1, 33, 1000, 512),
+                                             (1, 1, 1024, 1024, 512)])
+def test_attention_f32(cuda, B, heads, Nq, Nk, D):
+    """q, k, v are slices of one fused projection output (token stride 3*heads*D), like the VAE's AttnBlock"""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(Nq + D)
+    if Nq == Nk:
+        qkv = torch.randn(B, Nq, 3 * heads * D, generator=g)
+        q, k, v = qkv[..., :heads * D], qkv[..., heads * D:2 * heads * D], qkv[..., 2 * heads * D:]
+        qd, kd, vd = (t for t in torch.split(qkv.to(cuda), heads * D, dim=-1))
+    else:
+        q, k, v = torch.randn(B, Nq, heads * D, generator=g), torch.randn(B, Nk, heads * D, generator=g), torch.randn(B, Nk, heads * D, generator=g)
+        qd, kd, vd = q.to(cuda), k.to(cuda), v.to(cuda)
+    sp = lambda t, n: t.reshape(B, n, heads, D).transpose(1, 2)
+    want = F.scaled_dot_product_attention(sp(q, Nq), sp(k, Nk), sp(v, Nk)).transpose(1, 2).reshape(B, Nq, heads * D)
+    got = ops.attention(qd, kd, vd, heads)
+    assert got.dtype == torch.float32
+    _cmp(got, want, REL, f"attention_f32 B{B} h{heads} {Nq}x{Nk} d{D}")
+
+
+def _vae(cuda):
+    from test_tilevae import _build
+    fs, sd = _build()
+    fs.to(cuda)
+    fs.set_compute_dtype(torch.float32)
+    return fs, sd
+
+
+def test_vaehook_f32_vs_reference_golden(cuda, golden_dir):
+    """Tiled VAE (cross-tile GroupNorm) in fp32 against the reference's VAEHook output (bf16: 1.5e-2, fp16: 2.3e-3 of range)."""
+    from oracle import seeded
+    from rsvld_amd import ops
+    from rsvld_amd.utils.tilevae import VAEHook
+    fs, _ = _vae(cuda)
+    z = np.load(os.path.join(golden_dir, "tilevae_golden.npz"))
+    img = seeded.synthetic_image((1, 3, 256, 192), seed=90, smooth=3).to(cuda)
+    enc = fs.encoder
+    enc.original_forward = enc.forward
+    enc.forward = VAEHook(enc, 96, is_decoder=False)
+    _cmp(ops.nhwc_to_nchw(enc.forward(img)), z["enc.out"], 5e-5, "tiled encoder (fp32)")
+    dec = fs.decoder
+    dec.original_forward = dec.forward
+    dec.forward = VAEHook(dec, 12, is_decoder=True)
+    zin = ops.conv2d(ops.nchw_to_nhwc(S.rnd((1, 4, 40, 28), 91).to(cuda), torch.float32), fs.pk(fs.post_quant_conv), pad=0)
+    _cmp(ops.nhwc_to_nchw(dec.forward(zin), channels=3), z["dec.out"], 5e-5, "tiled decoder (fp32)")
+    small = seeded.synthetic_image((1, 3, 64, 64), seed=3, smooth=2).to(cuda)
+    assert torch.equal(enc.forward(small), enc.original_forward(small))
+
+
+def test_fp32_family_rejects_what_it_does_not_have(cuda):
+    from rsvld_amd import _lib as L, ops
+    x = torch.zeros(1, 4, 4, 8, device=cuda)
+    pc16 = ops.pack_conv(torch.zeros(8, 8, 1, 1), None, torch.bfloat16, cuda)
+    with pytest.raises(L.RsvldError):
+        ops.conv2d(x, pc16, pad=0)                      # 16-bit weights with fp32 activations
+    pc = ops.pack_conv(torch.zeros(8, 16, 1, 1), None, torch.float32, cuda, cin_split=(8, 8))
+    with pytest.raises(L.RsvldError):
+        ops.conv2d(x, pc, x2=x, pad=0)                  # two-source input is 16-bit only
+    with pytest.raises(L.RsvldError):
+        ops.layer_norm(x, torch.ones(8, device=cuda), torch.zeros(8, device=cuda))   # no fp32 LayerNorm: 16-bit expected

@@ -133,6 +133,12 @@ def test_vae_and_colorfix_vs_reference_golden(model, cuda, golden_dir):
     fs.set_compute_dtype(torch.float16)
     _cmp(_n(fs.moments(img)), z["moments"], 4e-3, "VAE moments (fp16)")
     _cmp(m.decode_first_stage(S.rnd((1, 4, 8, 8), 81).to(cuda)), z["decoded"], 2.5e-3, "VAE decode (fp16)")
+    fs.set_compute_dtype(torch.float32)      # ae_dtype: fp32 -> the fp32-operand kernel family (csrc/f32.hip)
+    mom = fs.moments(img)
+    assert mom.dtype == torch.float32
+    _cmp(_n(mom), z["moments"], 2e-5, "VAE moments (fp32)")
+    _cmp(m.decode_first_stage(S.rnd((1, 4, 8, 8), 81).to(cuda)), z["decoded"], 2e-5, "VAE decode (fp32)")
+    _cmp(m.encode_first_stage_with_denoise(img, use_sample=False), z["z_denoise"], 2e-5, "denoise-encoder mode (fp32)")
     fs.set_compute_dtype(torch.bfloat16)
     a, b = S.rnd((2, 3, 48, 40), 82).to(cuda), (S.rnd((2, 3, 48, 40), 83, 0.5) + 0.2).to(cuda)
     _cmp(colorfix.wavelet_reconstruction(a, b), z["wavelet"], 1e-6, "wavelet_reconstruction")
@@ -146,12 +152,14 @@ def test_vae_and_colorfix_vs_reference_golden(model, cuda, golden_dir):
 
 # end-to-end bounds per VAE compute type: (max|d|, mean|d|) = 2 x measured on an output of range 2.2-2.4.  bf16 is the
 # reference's ae_dtype (SR_model.py:28-33) and dominates the error (its decode alone is 1e-2 x range); with the VAE in
-# fp16 what is left is the fp16 UNet/ControlNet over 6 steps.  north_star's 1e-3 is an fp32-vs-fp32 figure: the reference's
+# fp16 or fp32 (ae_dtype: fp32, the fp32-operand kernel family: measured 2.9e-3 / 4.2e-4) what is left is the fp16
+# UNet/ControlNet over 6 steps.  north_star's 1e-3 is an fp32-vs-fp32 figure: the reference's
 # own GPU path (autocast bf16 VAE + fp16 UNet) sits at the same distance from its CPU path.
-PIPE_BOUNDS = {"bf16": (7e-2, 1e-2), "fp16": (1.2e-2, 2e-3)}
+PIPE_BOUNDS = {"bf16": (7e-2, 1e-2), "fp16": (1.2e-2, 2e-3), "fp32": (6e-3, 9e-4)}
+VAE_DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 
-@pytest.mark.parametrize("vae", ["bf16", "fp16"])
+@pytest.mark.parametrize("vae", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("tag", ["nocache", "cache"])
 def test_just_sampling_vs_reference_golden(model, cuda, golden_dir, tag, vae):
     """The whole Stage-2 pipeline with the reference's RNG order (CPU generator), 6 steps.  The cache trace
@@ -172,7 +180,7 @@ def test_just_sampling_vs_reference_golden(model, cuda, golden_dir, tag, vae):
     RS.get_can_use_cache_multi = spy
     try:
         m.noise_source = "cpu"
-        m.first_stage_model.set_compute_dtype(torch.float16 if vae == "fp16" else torch.bfloat16)
+        m.first_stage_model.set_compute_dtype(VAE_DT[vae])
         torch.manual_seed(7)
         thr = opt["img_threshold"] if tag == "cache" else 0.0
         out = m.just_sampling(img, [""], p_p="", n_p="", img_threshold=thr, dec_img=opt["dec_img"], num_steps=opt["num_steps"],

@@ -162,7 +162,7 @@ def test_stage2_error_budget(model, cuda, golden_dir):
     """Per-stage error budget of just_sampling, each stage TEACHER-FORCED with the CPU oracle's input so that the terms
     do not compound: VAE denoise-encode, VAE decode, VAE encode(sample), one guided denoiser call (ControlNet + UNet +
     CFG), the Euler update, final VAE decode, Wavelet colour fix.  Printed in units of each tensor's range and bounded
-    at ~2 x the measured value, for the VAE in bf16 (reference policy) and in fp16."""
+    at ~2 x the measured value, for the VAE in bf16 (reference policy), in fp16 and in fp32 (``ae_dtype: fp32``)."""
     from oracle import s2_oracle as O, seeded
     from rsvld_amd import ops
     from rsvld_amd.sgm.modules.diffusionmodules.guiders import LinearCFG
@@ -184,7 +184,7 @@ def test_stage2_error_budget(model, cuda, golden_dir):
     fin_o = O.decode(sd, eul_o * 0.1)
     wav_o = O.wavelet_reconstruction(fin_o, x1_o)
     budget = {}
-    for vae, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+    for vae, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16), ("fp32", torch.float32)):
         m.first_stage_model.set_compute_dtype(dt)
         m._posterior_noise = lambda shape: noise
         try:
@@ -215,3 +215,5 @@ def test_stage2_error_budget(model, cuda, golden_dir):
         assert v < 3e-2, (k, v)
     for k, v in budget["fp16"].items():
         assert v < 5e-3, (k, v)
+    for k, v in budget["fp32"].items():
+        assert v < 3e-5, (k, v)
