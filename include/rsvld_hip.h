@@ -273,11 +273,12 @@ int rsvld_concat_c(const void* a, const void* b, void* out, int64_t rows, int C1
                    int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * fp32-operand family: the VAE under ``ae_dtype: fp32`` (models/SR_model.py:28-33 runs it without autocast;
- * sgm/modules/diffusionmodules/model.py:55-262,482-743).  fp32 NHWC activations (C % 8 == 0), fp32 K-major weights,
+ * fp32-operand family: the VAE under ``ae_dtype: fp32`` and the UNet / ControlNet under ``diffusion_dtype: fp32``
+ * (models/SR_model.py:28-33 runs them without autocast; sgm/modules/diffusionmodules/model.py:55-262,482-743,
+ * openaimodel.py:102-350, sgm/modules/attention.py:84-486, models/modules/SR_modules.py:59-149).  fp32 NHWC activations (C % 8 == 0), fp32 K-major weights,
  * fp32 MFMA (v_mfma_f32_32x32x2_f32).  Accuracy mode: simple LDS tiling, 1/16 of the 16-bit matrix rate.
  * ------------------------------------------------------------------------------------- */
-/* rsvld_conv2d_nhwc with dtype = RSVLD_F32: x, w, residual, out are fp32; x2 / rowvec / GEGLU unsupported;
+/* rsvld_conv2d_nhwc with dtype = RSVLD_F32: x, x2, w, residual, out are fp32 (same formula, same epilogues incl. GEGLU);
  * out_f32, plan_div and tune are ignored (the plan never depends on the batch). */
 int rsvld_conv2d_nhwc_f32(const rsvld_conv_desc* d, void* stream);
 /* GroupNorm on fp32 NHWC [B,HW,C]: statistics (mean, biased variance) per (image, group) through fp64 partial sums
@@ -285,6 +286,7 @@ int rsvld_conv2d_nhwc_f32(const rsvld_conv_desc* d, void* stream);
 int64_t rsvld_groupnorm_f32_ws_bytes(int B, int HW, int C, int groups);
 int rsvld_groupnorm_stats_f32(const float* x, float* mean_var, int B, int HW, int C, int groups, void* ws, void* stream);
 int rsvld_groupnorm_apply_f32(const float* x, float* y, const float* mean_var, const float* gamma, const float* beta,
+                              const float* mod_scale1p, const float* mod_shift, int mod_stride,
                               int B, int HW, int C, int groups, float eps, int silu, void* stream);
 /* rsvld_attention on fp32 tensors (same addressing; D % 32 == 0, D <= 512; scores never materialised) */
 int rsvld_attention_f32(const float* q, const float* k, const float* v, float* out,
@@ -294,6 +296,13 @@ int rsvld_attention_f32(const float* q, const float* k, const float* v, float* o
                         int64_t v_batch_stride, int64_t v_tok_stride,
                         int64_t o_batch_stride, int64_t o_tok_stride,
                         float scale, void* stream);
+/* fp32 forms of rsvld_layernorm, rsvld_concat_c, rsvld_axpby and rsvld_absdiff_sums (the Stage-2 networks under
+ * ``diffusion_dtype: fp32``; sgm/modules/attention.py:376-486, models/modules/SR_modules.py:59-149, DFBCache.py:98-112) */
+int rsvld_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                        void* stream);
+int rsvld_concat_c_f32(const float* a, const float* b, float* out, int64_t rows, int C1, int C2, void* stream);
+int rsvld_axpby_f32(const float* a, const float* b, float* out, int64_t n, float sa, float sb, void* stream);
+int rsvld_absdiff_sums_f32(const float* a, const float* b, float* out, int rows, int64_t n_per_row, void* stream);
 /* rsvld_nchw_f32_to_nhwc with an fp32 destination */
 int rsvld_nchw_f32_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W,
                                int Cdst, int c_off, int zero_pad, float scale, void* stream);

@@ -1,9 +1,11 @@
-// f32.hip — the fp32-operand kernel family behind ``ae_dtype: fp32`` (reference: models/SR_model.py:28-33 — the VAE
-// runs without autocast).  Everything the VAE needs, on fp32 NHWC tensors with fp32 weights:
+// f32.hip — the fp32-operand kernel family behind ``ae_dtype: fp32`` / ``diffusion_dtype: fp32`` (reference:
+// models/SR_model.py:28-33 — no autocast; also what the reference's CPU path computes).  Everything the VAE and the Stage-2
+// networks need, on fp32 NHWC tensors with fp32 weights:
 //   conv_f32_kernel        implicit-GEMM convolution / 1x1 on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate)
 //   gn_f32_*               GroupNorm statistics (fp64 partial sums, fixed merge order) and apply (+SiLU)
 //   attn_f32_kernel        flash-style attention (scores never materialised), any head dim that is a multiple of 32 up to 512
 //   nchw_to_nhwc_f32       layout conversion
+//   layernorm / concat / axpby / absdiff   the remaining ops of the Stage-2 UNet + ControlNet under ``diffusion_dtype: fp32``
 // This is the ACCURACY mode of the library, not the fast path: simple LDS tiling, no LDS-DMA pipelines.  The fp32 matrix
 // rate of gfx950 is 1/16 of the 16-bit rate, so the reference's default (bf16 VAE) stays the benchmarked configuration.
 #include "rsvld_common.h"
@@ -16,8 +18,8 @@ namespace {
 // MFMA 32x32x2 f32 operand map: lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31];
 // D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 struct ConvF32Args {
-    const float* x; const float* w; const float* bias; const float* res; float* out;
-    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, ups, act;
+    const float* x; const float* x2; const float* w; const float* bias; const float* rowvec; const float* res; float* out;
+    int B, H, W, Cin, Cin2, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, ups, act, rv_stride;
     float alpha, beta;
     int Ktot;
     int64_t M;
@@ -57,11 +59,15 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args p) {
         const int k = k0 + kq;
         const bool kv = k < p.Ktot;          // Ktot % 8 == 0: a quad is inside or outside as a whole
         int ky = 0, kx = 0, c = 0;
+        const float* src = p.x;
+        int cs = p.Cin;
         if (kv) {
-            const int tap = k / p.Cin;
-            c = k - tap * p.Cin;
+            const int ct = p.Cin + p.Cin2;
+            const int tap = k / ct;
+            c = k - tap * ct;
             ky = tap / p.KW;
             kx = tap - ky * p.KW;
+            if (c >= p.Cin) { src = p.x2; c -= p.Cin; cs = p.Cin2; }   // [x | x2] channel concatenation, never materialised
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args p) {
                 int iy = oy[i] * p.stride + ky - p.pad_t, ix = ox[i] * p.stride + kx - p.pad_l;
                 if (iy >= 0 && iy < Hin && ix >= 0 && ix < Win) {
                     if (p.ups) { iy >>= 1; ix >>= 1; }
-                    v = *(const f32x4*)(p.x + ((xb[i] + (int64_t)iy * p.W + ix) * p.Cin + c));
+                    v = *(const f32x4*)(src + ((xb[i] + (int64_t)iy * p.W + ix) * cs + c));
                 }
             }
             float* d = As + (lr + 32 * i) * CF_LD + kq;
@@ -90,13 +96,21 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args p) {
     }
 
     const int n = n0 + wn * 32 + (lane & 31);
-    if (n >= p.Cout) return;
-    const float bv = p.bias != nullptr ? p.bias[n] : 0.f;
+    const bool nv = n < p.Cout;            // Cout % 8 == 0: lanes 2j and 2j+1 are valid together (GEGLU pairs)
+    const float bv = (nv && p.bias != nullptr) ? p.bias[n] : 0.f;
+    const int64_t HoWo = (int64_t)p.Ho * p.Wo;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= p.M) continue;
+        const bool ok = nv && m < p.M;
         float v = acc[r] + bv;
+        if (ok && p.rowvec != nullptr) v += p.rowvec[(m / HoWo) * p.rv_stride + n];
+        if (p.act == RSVLD_ACT_GEGLU) {    // weights packed value / gate interleaved: channel 2j = value, 2j+1 = gate
+            const float gate = __shfl_xor(v, 1);
+            if (ok && !(n & 1)) p.out[m * (p.Cout >> 1) + (n >> 1)] = p.alpha * v * (0.5f * gate * (1.0f + erff(gate * 0.70710678118654752f)));
+            continue;
+        }
+        if (!ok) continue;
         if (p.act == RSVLD_ACT_SILU) v = v / (1.0f + expf(-v));
         v *= p.alpha;
         if (p.res != nullptr) v += p.beta * p.res[m * p.Cout + n];
@@ -156,8 +170,9 @@ __global__ void gn_f32_finalize_kernel(const double* __restrict__ ws, float* __r
 
 __global__ __launch_bounds__(256) void gn_f32_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            const float* __restrict__ mean_var, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int64_t HW, int C, int cpg, int groups,
-                                                           float eps, int silu, int64_t total4) {
+                                                           const float* __restrict__ beta, const float* __restrict__ mod_scale1p,
+                                                           const float* __restrict__ mod_shift, int64_t mod_stride, int64_t HW, int C,
+                                                           int cpg, int groups, float eps, int silu, int64_t total4) {
     const int C4 = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t pix = i / C4;
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(256) void gn_f32_apply_kernel(const float* __restri
             const float mean = mean_var[(b * groups + g) * 2], var = mean_var[(b * groups + g) * 2 + 1];
             float t = (v[e] - mean) * (1.0f / sqrtf(var + eps)) * gamma[c + e] + beta[c + e];
             if (silu) t = t / (1.0f + expf(-t));
+            if (mod_scale1p != nullptr) t = t * (1.0f + mod_scale1p[pix * mod_stride + c + e]) + mod_shift[pix * mod_stride + c + e];
             o[e] = t;
         }
         *(f32x4*)(y + i * 4) = o;
@@ -323,6 +339,67 @@ __global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ src, float* __
     }
 }
 
+// LayerNorm over the last dim: one wave per row, two passes over the row (mean, then centred variance), fp32
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + row * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / (float)C;
+        float ss = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; ss += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+        for (int c = lane; c < C; c += 64) y[row * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+__global__ void concat_c_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t rows,
+                                    int C1q, int C2q) {
+    const int Cq = C1q + C2q;
+    const int64_t total = rows * Cq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Cq;
+        const int c = (int)(i - r * Cq);
+        ((f32x4*)o)[i] = c < C1q ? ((const f32x4*)a)[r * C1q + c] : ((const f32x4*)b)[r * C2q + (c - C1q)];
+    }
+}
+
+__global__ void axpby_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n, float sa,
+                                 float sb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        o[i] = a[i] * sa + b[i] * sb;
+}
+
+// per row: (sum |a - b|, sum |a|), fp64 accumulation, one workgroup per row (fixed reduction tree: deterministic)
+__global__ __launch_bounds__(1024) void absdiff_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out, int64_t n) {
+    const int64_t row = blockIdx.x;
+    double sd = 0.0, sa = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float av = a[row * n + i];
+        sd += (double)fabsf(av - b[row * n + i]);
+        sa += (double)fabsf(av);
+    }
+    __shared__ double sh[2][1024];
+    sh[0][threadIdx.x] = sd;
+    sh[1][threadIdx.x] = sa;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[2 * row] = (float)sh[0][0];
+        out[2 * row + 1] = (float)sh[1][0];
+    }
+}
+
 static int gn_f32_chunks(int64_t HW) {
     int64_t n = (HW + 4095) / 4096;
     return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
@@ -333,16 +410,19 @@ static int gn_f32_chunks(int64_t HW) {
 extern "C" int rsvld_conv2d_nhwc_f32(const rsvld_conv_desc* d, void* stream) {
     if (d == nullptr || d->x == nullptr || d->w == nullptr || d->out == nullptr) return RSVLD_EINVAL;
     if (d->dtype != RSVLD_F32) return RSVLD_EINVAL;
-    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || d->act == RSVLD_ACT_GEGLU) return RSVLD_EUNSUPPORTED;
+    if ((d->x2 != nullptr) != (d->Cin2 > 0) || d->Cin2 % 8 != 0) return RSVLD_EINVAL;
+    if (d->act == RSVLD_ACT_GEGLU && (d->Cout % 16 != 0 || d->residual != nullptr)) return RSVLD_EINVAL;
     if (d->Cin % 8 != 0 || d->Cout % 8 != 0 || d->B < 1 || d->H < 1 || d->W < 1 || d->KH < 1 || d->KW < 1 || d->stride < 1)
         return RSVLD_EINVAL;
     if (d->Ho < 1 || d->Wo < 1) return RSVLD_EINVAL;   // taps outside the (up-sampled) image read zeros, whatever Ho / Wo say
     ConvF32Args a;
-    a.x = (const float*)d->x; a.w = (const float*)d->w; a.bias = d->bias; a.res = (const float*)d->residual; a.out = (float*)d->out;
-    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride;
+    a.x = (const float*)d->x; a.x2 = (const float*)d->x2; a.w = (const float*)d->w; a.bias = d->bias; a.rowvec = d->rowvec;
+    a.res = (const float*)d->residual; a.out = (float*)d->out;
+    a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.Ho = d->Ho; a.Wo = d->Wo; a.ups = d->upsample ? 1 : 0; a.act = d->act;
     a.alpha = d->alpha; a.beta = d->beta;
-    a.Ktot = d->KH * d->KW * d->Cin;
+    a.Ktot = d->KH * d->KW * (d->Cin + d->Cin2);
     a.M = (int64_t)d->B * d->Ho * d->Wo;
     const int64_t gm = cdiv64(a.M, 64);
     if (gm > 0x7fffffffLL) return RSVLD_EINVAL;
@@ -372,15 +452,17 @@ extern "C" int rsvld_groupnorm_stats_f32(const float* x, float* mean_var, int B,
 }
 
 extern "C" int rsvld_groupnorm_apply_f32(const float* x, float* y, const float* mean_var, const float* gamma, const float* beta,
-                                         int B, int HW, int C, int groups, float eps, int silu, void* stream) {
+                                         const float* mod_scale1p, const float* mod_shift, int mod_stride, int B, int HW, int C,
+                                         int groups, float eps, int silu, void* stream) {
     if (x == nullptr || y == nullptr || mean_var == nullptr || gamma == nullptr || beta == nullptr || B < 1 || HW < 1 ||
-        C % 4 != 0 || groups < 1 || C % groups != 0)
+        C % 4 != 0 || groups < 1 || C % groups != 0 || (mod_scale1p == nullptr) != (mod_shift == nullptr))
         return RSVLD_EINVAL;
     const int64_t total4 = (int64_t)B * HW * (C / 4);
     int64_t blocks = cdiv64(total4, 256);
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(gn_f32_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, mean_var, gamma, beta,
-                       (int64_t)HW, C, C / groups, groups, eps, silu, total4);
+                       mod_scale1p, mod_shift, (int64_t)(mod_stride > 0 ? mod_stride : C), (int64_t)HW, C, C / groups, groups, eps, silu,
+                       total4);
     return rsvld_check_launch();
 }
 
@@ -413,5 +495,36 @@ extern "C" int rsvld_nchw_f32_to_nhwc_f32(const float* src, float* dst, int B, i
     const int64_t total = (int64_t)B * H * W;
     hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
                        (int64_t)H * W, Cdst, c_off, zero_pad, scale, total);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                                   void* stream) {
+    if (x == nullptr || y == nullptr || gamma == nullptr || beta == nullptr || rows < 1 || C < 1) return RSVLD_EINVAL;
+    int64_t blocks = cdiv64(rows, 4);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, rows, C, eps);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_concat_c_f32(const float* a, const float* b, float* out, int64_t rows, int C1, int C2, void* stream) {
+    if (a == nullptr || b == nullptr || out == nullptr || rows < 1 || C1 < 4 || C2 < 4 || C1 % 4 != 0 || C2 % 4 != 0) return RSVLD_EINVAL;
+    int64_t blocks = cdiv64(rows * ((C1 + C2) / 4), 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(concat_c_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, rows, C1 / 4, C2 / 4);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_axpby_f32(const float* a, const float* b, float* out, int64_t n, float sa, float sb, void* stream) {
+    if (a == nullptr || b == nullptr || out == nullptr || n < 1) return RSVLD_EINVAL;
+    int64_t blocks = cdiv64(n, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(axpby_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n, sa, sb);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_absdiff_sums_f32(const float* a, const float* b, float* out, int rows, int64_t n_per_row, void* stream) {
+    if (a == nullptr || b == nullptr || out == nullptr || rows < 1 || n_per_row < 1) return RSVLD_EINVAL;
+    hipLaunchKernelGGL(absdiff_f32_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, a, b, out, n_per_row);
     return rsvld_check_launch();
 }

@@ -30,11 +30,7 @@ class SR_backbone(DiffusionEngine):
         assert (ae_dtype in ["fp32", "fp16", "bf16"]) and (diffusion_dtype in ["fp32", "fp16", "bf16"])
         if ae_dtype == "fp16":
             raise RuntimeError("fp16 cause NaN in AE")
-        if diffusion_dtype == "fp32":
-            # the UNet / ControlNet kernels take 16-bit operands (fp32 accumulate); only the VAE has an fp32-operand family.
-            # Loud, not silently downgraded: the reference's shipped configuration is fp16 (juggernautXL.yaml, infer.py:61).
-            raise NotImplementedError("diffusion_dtype='fp32' has no kernel path on this build; use diffusion_dtype: fp16 or bf16")
-        # ae_dtype "fp32" runs the VAE on the fp32-operand kernel family (csrc/f32.hip): the reference's no-autocast VAE
+        # "fp32" (either one) runs that network on the fp32-operand kernel family (csrc/f32.hip): the reference without autocast
         self.ae_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[ae_dtype]
         self.model.dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[diffusion_dtype]
         self.first_stage_model.set_compute_dtype(self.ae_dtype)

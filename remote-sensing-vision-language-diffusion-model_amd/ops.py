@@ -5,8 +5,9 @@ current HIP stream; every computation is a kernel of librsvld_hip.so.  Activatio
 16-bit tensors ``[B, H, W, C]`` with ``C % 8 == 0``; tokens ``[B, N, C]`` are the same thing with
 ``H = 1``.  Every function raises if the tensor is not on a GPU: there is no CPU path.
 
-fp32 activations select the fp32-operand family (csrc/f32.hip, the VAE under ``ae_dtype: fp32``): ``conv2d``,
-``group_norm*``, ``attention`` and ``nchw_to_nhwc`` dispatch on the tensor's dtype; everything else is 16-bit only.
+fp32 activations select the fp32-operand family (csrc/f32.hip): ``conv2d`` /
+``linear``, ``group_norm*``, ``layer_norm``, ``attention``, ``concat_c``, ``axpby``, ``absdiff_sums`` and ``nchw_to_nhwc``
+dispatch on the tensor's dtype (the VAE under ``ae_dtype: fp32``, the UNet / ControlNet under ``diffusion_dtype: fp32``).
 """
 import contextlib
 import ctypes as C
@@ -296,33 +297,39 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
 
 def _conv2d_f32(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm):
     """fp32 NHWC convolution with fp32 packed weights (rsvld_conv2d_nhwc_f32); a ``norm=`` GroupNorm runs first, unfused."""
-    if x2 is not None or rowvec is not None or act == L.ACT_GEGLU:
-        raise L.RsvldError("conv2d (fp32): two-source input, row vectors and GEGLU exist in the 16-bit family only")
     if pc.w.dtype != torch.float32:
         raise L.RsvldError("conv2d (fp32): weights must be packed in fp32 (the owning network's compute_dtype)")
     if norm is not None:
         gamma, nbeta, groups, eps, silu = norm
-        x = group_norm(x, gamma, nbeta, groups, eps, silu=silu)
+        x, x2 = group_norm(x, gamma, nbeta, groups, eps, x2=x2, silu=silu), None
     B, H, W, Cin = x.shape
-    if Cin != pc.cin_p:
-        raise L.RsvldError(f"conv2d: input channels {Cin} != packed {pc.cin_p}")
+    Cin2 = 0 if x2 is None else x2.shape[-1]
+    if Cin + Cin2 != pc.cin_p:
+        raise L.RsvldError(f"conv2d: input channels {Cin}+{Cin2} != packed {pc.cin_p}")
     if pad is None:
         pad = pc.kh // 2
     pt, pl, pb, pr = (pad,) * 4 if isinstance(pad, int) else pad
     Hin, Win = (2 * H, 2 * W) if upsample else (H, W)
     Ho = (Hin + pt + pb - pc.kh) // stride + 1
     Wo = (Win + pl + pr - pc.kw) // stride + 1
-    out = torch.empty((B, Ho, Wo, pc.cout_p), device=x.device, dtype=torch.float32)
-    if not x.is_contiguous():
-        raise L.RsvldError("conv2d: inputs must be contiguous NHWC")
+    c_out = pc.cout_p // 2 if act == L.ACT_GEGLU else pc.cout_p
+    out = torch.empty((B, Ho, Wo, c_out), device=x.device, dtype=torch.float32)
+    if not x.is_contiguous() or (x2 is not None and (not x2.is_contiguous() or x2.dtype != torch.float32)):
+        raise L.RsvldError("conv2d (fp32): inputs must be contiguous fp32 NHWC")
     if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()
                                  or residual.dtype != torch.float32):
         raise L.RsvldError("conv2d (fp32): residual must be fp32 and match the output shape")
+    rv_stride = 0
+    if rowvec is not None:
+        if tuple(rowvec.shape) != (B, pc.cout_p) or rowvec.dtype != torch.float32 or rowvec.stride(1) != 1:
+            raise L.RsvldError("conv2d: rowvec must be fp32 [B, Cout] with unit inner stride")
+        rv_stride = rowvec.stride(0) if B > 1 else pc.cout_p
     d = L.ConvDesc(
-        x=x.data_ptr(), x2=None, w=pc.w.data_ptr(), bias=None if pc.bias is None else pc.bias.data_ptr(), rowvec=None,
+        x=x.data_ptr(), x2=None if x2 is None else x2.data_ptr(), w=pc.w.data_ptr(),
+        bias=None if pc.bias is None else pc.bias.data_ptr(), rowvec=None if rowvec is None else rowvec.data_ptr(),
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
-        B=B, H=H, W=W, Cin=Cin, Cin2=0, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo,
-        upsample=int(upsample), dtype=L.F32, out_f32=1, act=act, alpha=alpha, beta=beta, rowvec_stride=0, plan_div=1, tune=0)
+        B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo,
+        upsample=int(upsample), dtype=L.F32, out_f32=1, act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=1, tune=0)
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
     nbytes = 4.0 * (x.numel() + pc.w.numel() + out.numel() + (0 if residual is None else residual.numel()))
     _launch("conv_f32", flops, nbytes, lambda: L.check(L.load().rsvld_conv2d_nhwc_f32(C.byref(d), _stream()),
@@ -350,10 +357,11 @@ def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=
         if mod_shift.stride(-2) != mod_stride or mod_scale1p.stride(-1) != 1 or mod_shift.stride(-1) != 1:
             raise L.RsvldError("group_norm: modulation tensors must share a row stride and be channel-contiguous")
     _need_gpu(x, x2, gamma, beta)
-    if x.dtype == torch.float32:
-        if x2 is not None or mod_scale1p is not None:
-            raise L.RsvldError("group_norm (fp32): two-source input and ZeroSFT modulation exist in the 16-bit family only")
-        return group_norm_apply(x, group_norm_stats(x, groups), gamma, beta, groups, eps, silu=silu)
+    if x.dtype == torch.float32:       # fp32 family: the two-source form concatenates first; statistics, then apply (+ modulation)
+        if x2 is not None:
+            x = concat_c(x, x2)
+        return group_norm_apply(x, group_norm_stats(x, groups), gamma, beta, groups, eps, silu=silu,
+                                mod_scale1p=mod_scale1p, mod_shift=mod_shift)
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
     lib = L.load()
@@ -388,17 +396,27 @@ def group_norm_stats(x, groups, *, x2=None):
     return st
 
 
-def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False):
+def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None):
+    """``mod_*`` (ZeroSFT modulation) with supplied statistics exists in the fp32 family only."""
     _need_gpu(x, x2, stats, gamma, beta)
+    if mod_scale1p is not None and x.dtype != torch.float32:
+        raise L.RsvldError("group_norm_apply: modulation with supplied statistics is an fp32-family feature (use group_norm)")
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((B, H, W, C1 + C2), device=x.device, dtype=x.dtype)
     if x.dtype == torch.float32:
         if x2 is not None or not x.is_contiguous():
             raise L.RsvldError("group_norm_apply (fp32): one contiguous NHWC tensor expected")
+        mod_stride = 0
+        if mod_scale1p is not None:
+            mod_stride = mod_scale1p.stride(-2)
+            if (mod_shift.stride(-2) != mod_stride or mod_scale1p.stride(-1) != 1 or mod_shift.stride(-1) != 1
+                    or mod_scale1p.dtype != torch.float32 or mod_shift.dtype != torch.float32):
+                raise L.RsvldError("group_norm: modulation tensors must be fp32, share a row stride and be channel-contiguous")
         _launch("groupnorm_apply_f32", 0.0, 8.0 * x.numel(), lambda: L.check(L.load().rsvld_groupnorm_apply_f32(
-            _ptr(x), _ptr(y), _ptr(stats), _ptr(gamma), _ptr(beta), B, H * W, C1, groups, eps, int(silu), _stream()),
-            "rsvld_groupnorm_apply_f32"))
+            _ptr(x), _ptr(y), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(mod_scale1p), _ptr(mod_shift), mod_stride,
+            B, H * W, C1, groups, eps, int(silu), _stream()), "rsvld_groupnorm_apply_f32"))
+        y._nhwc = True
         return y
     L.check(L.load().rsvld_groupnorm_apply(_ptr(x), _ptr(x2), _ptr(y), _ptr(stats), _ptr(gamma), _ptr(beta), None,
                                            None, 0, B, H * W, C1, C2, groups, eps, int(silu), _dt(x), _stream()),
@@ -411,6 +429,12 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y = torch.empty_like(x)
+    if x.dtype == torch.float32:
+        if not x.is_contiguous():
+            raise L.RsvldError("layer_norm (fp32): contiguous rows expected")
+        _launch("layernorm_f32", 0.0, 8.0 * x.numel(), lambda: L.check(L.load().rsvld_layernorm_f32(
+            _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, _stream()), "rsvld_layernorm_f32"))
+        return y
     L.check(L.load().rsvld_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, _dt(x), _stream()),
             "rsvld_layernorm")
     return y
@@ -508,6 +532,13 @@ def nhwc_to_nchw(src, channels=None, c_off=0):
 def axpby(a, b, sa=1.0, sb=1.0):
     _need_gpu(a, b)
     out = torch.empty_like(a)
+    if a.dtype == torch.float32:
+        if b.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()) or a.numel() != b.numel():
+            raise L.RsvldError("axpby (fp32): two contiguous fp32 tensors of one size expected")
+        L.check(L.load().rsvld_axpby_f32(_ptr(a), _ptr(b), _ptr(out), a.numel(), sa, sb, _stream()), "rsvld_axpby_f32")
+        if a.dim() == 4:
+            out._nhwc = True
+        return out
     L.check(L.load().rsvld_axpby(_ptr(a), _ptr(b), _ptr(out), a.numel(), sa, sb, _dt(a), _stream()), "rsvld_axpby")
     return out
 
@@ -596,8 +627,13 @@ def absdiff_sums(a, b):
     rows = a.shape[0]
     n = a.numel() // rows
     lib = L.load()
-    ws = torch.empty(lib.rsvld_absdiff_ws_bytes(rows, n), device=a.device, dtype=torch.uint8)
     out = torch.empty((rows, 2), device=a.device, dtype=torch.float32)
+    if a.dtype == torch.float32:
+        if b.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()) or a.numel() != b.numel():
+            raise L.RsvldError("absdiff_sums (fp32): two contiguous fp32 tensors of one size expected")
+        L.check(lib.rsvld_absdiff_sums_f32(_ptr(a), _ptr(b), _ptr(out), rows, n, _stream()), "rsvld_absdiff_sums_f32")
+        return out
+    ws = torch.empty(lib.rsvld_absdiff_ws_bytes(rows, n), device=a.device, dtype=torch.uint8)
     L.check(lib.rsvld_absdiff_sums(_ptr(a), _ptr(b), _ptr(out), rows, n, _dt(a), _ptr(ws), _stream()),
             "rsvld_absdiff_sums")
     return out
@@ -644,6 +680,13 @@ def concat_c(a, b):
     _need_gpu(a, b)
     rows = a.numel() // a.shape[-1]
     out = torch.empty((*a.shape[:-1], a.shape[-1] + b.shape[-1]), device=a.device, dtype=a.dtype)
+    if a.dtype == torch.float32:
+        if b.dtype != torch.float32 or not (a.is_contiguous() and b.is_contiguous()):
+            raise L.RsvldError("concat_c (fp32): two contiguous fp32 tensors expected")
+        L.check(L.load().rsvld_concat_c_f32(_ptr(a), _ptr(b), _ptr(out), rows, a.shape[-1], b.shape[-1], _stream()), "rsvld_concat_c_f32")
+        if a.dim() == 4:
+            out._nhwc = True
+        return out
     L.check(L.load().rsvld_concat_c(_ptr(a), _ptr(b), _ptr(out), rows, a.shape[-1], b.shape[-1], _dt(a), _stream()),
             "rsvld_concat_c")
     return out

@@ -60,9 +60,7 @@ class DiscreteDenoiserWithControl(DiscreteDenoiser):
         c_noise = self.possibly_quantize_c_noise(c_noise)            # int64 table index [N]
         if float(c_in.min()) != float(c_in.max()):
             raise NotImplementedError("per-sample sigmas inside one batch are not produced by RestoreEDMSampler")
-        net_dtype = getattr(network, "dtype", torch.float16)
-        if net_dtype == torch.float32:
-            net_dtype = torch.float16
+        net_dtype = getattr(network, "dtype", torch.float16)      # fp32 = the fp32-operand kernel family (diffusion_dtype: fp32)
         x_in = ops.nchw_to_nhwc(input, net_dtype, scale=float(c_in[0]))
         out = network(x_in, c_noise.to(input.device, torch.float32), cond, control_scale, fbcache_mode, partial_info)
         if "stage1" in fbcache_mode:

@@ -4,7 +4,7 @@
 and then the UNet, like the reference — with one structural difference: on an ``*_stage2`` call
 the reference re-runs the ControlNet and throws the result away (the UNet takes ``control`` from
 ``partial_info``, SR_modules.py:694); here the ControlNet is not launched at all in that case.
-``dtype`` is assigned by SR_backbone (SR_model.py:41) and selects the 16-bit compute type.
+``dtype`` is assigned by SR_backbone (SR_model.py:41) and selects the compute type (fp16 / bf16 storage, or fp32 operands).
 Inputs may be fp32 NCHW (reference layout; converted once) or already-packed 16-bit NHWC.
 Full outputs are the UNet's fp32 NHWC epsilon ``[N,H,W,8]`` (4 channels + padding); the denoiser
 turns them back into fp32 NCHW."""
@@ -28,11 +28,18 @@ class ControlWrapper(nn.Module):
         self.control_model = control_model
 
     def _compute_dtype(self):
-        return torch.bfloat16 if self.dtype == torch.bfloat16 else torch.float16
+        """fp16 / bf16: the 16-bit kernel family; fp32 (``diffusion_dtype: fp32``): the fp32-operand family (csrc/f32.hip)."""
+        return self.dtype if self.dtype in (torch.bfloat16, torch.float32) else torch.float16
 
     def _nhwc(self, t, dt):
         if t.dtype in (torch.float16, torch.bfloat16) and t.dim() == 4 and t.shape[-1] % 8 == 0:
+            if dt == torch.float32:
+                raise RsvldError("a 16-bit NHWC tensor was handed to the fp32 network")
             return t if t.dtype == dt else t.to(dt)
+        if t.dtype == torch.float32 and getattr(t, "_nhwc", False):
+            if dt != torch.float32:
+                raise RsvldError("an fp32 NHWC tensor was handed to the 16-bit network")
+            return t
         return ops.nchw_to_nhwc(t, dt)
 
     def forward(self, x, t, c, control_scale=1, fbcache_mode="none", partial_info=None, **kwargs):

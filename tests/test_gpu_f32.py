@@ -1,7 +1,8 @@
 """GPU parity of the fp32-operand kernel family (csrc/f32.hip, ``ae_dtype: fp32``) against plain torch fp32 on the CPU:
 convolution variants the VAE uses, GroupNorm (+SiLU) with own and with supplied statistics, attention at the VAE's head
-dimension, and the tiled VAE (VAEHook) against the reference-generated goldens (the untiled VAE and the pipeline with an
-fp32 VAE: tests/test_gpu_s2.py).
+dimension, the Stage-2 network forms (two-source conv, row vector, GEGLU, LayerNorm, modulated GroupNorm, cache sums) and the
+tiled VAE (VAEHook) against the reference-generated goldens.  The untiled VAE, every Stage-2 block, both networks and the
+whole pipeline in fp32: tests/test_gpu_s2.py (``fp32`` / ``allfp32`` parameters).
 Tolerances: fp32 MFMA arithmetic in a different summation order -> a few 1e-6 of the tensor's range (asserted at 2e-5)."""
 import math
 import os
@@ -154,14 +155,65 @@ def test_vaehook_f32_vs_reference_golden(cuda, golden_dir):
     assert torch.equal(enc.forward(small), enc.original_forward(small))
 
 
-def test_fp32_family_rejects_what_it_does_not_have(cuda):
+def test_conv2d_f32_two_source_rowvec_geglu(cuda):
+    """the Stage-2 network forms: [x | x2] channel concatenation, per-image row vector (time embedding), GEGLU epilogue, alpha"""
+    from rsvld_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(11)
+    B, C1, C2, Cout, H, W = 2, 64, 40, 96, 9, 7
+    x1, x2 = torch.randn(B, C1, H, W, generator=g), torch.randn(B, C2, H, W, generator=g)
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt(9 * (C1 + C2))
+    b, rv = torch.randn(Cout, generator=g) * 0.1, torch.randn(B, Cout, generator=g)
+    pc = ops.pack_conv(w, b, torch.float32, cuda, cin_split=(C1, C2))
+    want = F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1) + rv[:, :, None, None]
+    got = ops.conv2d(_nhwc(x1, cuda), pc, x2=_nhwc(x2, cuda), pad=1, rowvec=rv.to(cuda))
+    _cmp(got.permute(0, 3, 1, 2), want, REL, "conv_f32 two-source + rowvec")
+    rows, Cin, inner = 300, 64, 128                      # GEGLU: Linear(Cin, 2*inner) -> value * gelu(gate), then * alpha
+    x = torch.randn(rows, Cin, generator=g)
+    wl, bl = torch.randn(2 * inner, Cin, generator=g) / 8, torch.randn(2 * inner, generator=g) * 0.1
+    y = F.linear(x, wl, bl)
+    want = y[:, :inner] * F.gelu(y[:, inner:])
+    pcg = ops.pack_conv(wl, bl, torch.float32, cuda, geglu=True)
+    _cmp(ops.linear(x.to(cuda), pcg, act=L.ACT_GEGLU), want, REL, "linear_f32 GEGLU")
+    wo = torch.randn(Cin, inner, generator=g) / 11
+    res = torch.randn(rows, Cin, generator=g)
+    pco = ops.pack_conv(wo, None, torch.float32, cuda)
+    _cmp(ops.linear(want.to(cuda), pco, residual=res.to(cuda), alpha=0.7), 0.7 * F.linear(want, wo) + res, REL, "linear_f32 alpha + residual")
+
+
+def test_small_ops_f32(cuda):
+    """LayerNorm, GroupNorm over [x | x2] with ZeroSFT modulation, concat, axpby, the cache's similarity sums"""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(3, 50, 640, generator=g) * 2 + 0.3
+    ga, be = torch.randn(640, generator=g), torch.randn(640, generator=g)
+    _cmp(ops.layer_norm(x.to(cuda), ga.to(cuda), be.to(cuda), 1e-5), F.layer_norm(x, (640,), ga, be, 1e-5), REL, "layernorm_f32")
+    B, C1, C2, H, W = 2, 64, 32, 6, 5
+    a, b = torch.randn(B, C1, H, W, generator=g), torch.randn(B, C2, H, W, generator=g) + 1.0
+    gam, bet = torch.randn(C1 + C2, generator=g), torch.randn(C1 + C2, generator=g)
+    gb = torch.randn(B, H, W, 2 * (C1 + C2), generator=g)
+    n = F.group_norm(torch.cat([a, b], 1), 32, gam, bet, eps=1e-5)
+    want = n * (1 + gb[..., :C1 + C2].permute(0, 3, 1, 2)) + gb[..., C1 + C2:].permute(0, 3, 1, 2)
+    gbd = gb.to(cuda)
+    got = ops.group_norm(_nhwc(a, cuda), gam.to(cuda), bet.to(cuda), 32, 1e-5, x2=_nhwc(b, cuda),
+                         mod_scale1p=gbd[..., :C1 + C2], mod_shift=gbd[..., C1 + C2:])
+    _cmp(got.permute(0, 3, 1, 2), want, REL, "group_norm_f32 two-source + modulation")
+    cat = ops.concat_c(_nhwc(a, cuda), _nhwc(b, cuda))
+    assert torch.equal(cat.cpu(), torch.cat([a, b], 1).permute(0, 2, 3, 1))
+    u, v = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    _cmp(ops.axpby(u.to(cuda), v.to(cuda), 0.7, 0.3), 0.7 * u + 0.3 * v, 1e-6, "axpby_f32")
+    p, q = torch.randn(4, 20000, generator=g), torch.randn(4, 20000, generator=g)
+    sums = ops.absdiff_sums(p.to(cuda), q.to(cuda)).cpu()
+    _cmp(sums[:, 0], (p - q).abs().double().sum(1).float(), 1e-6, "absdiff_sums_f32 |a-b|")
+    _cmp(sums[:, 1], p.abs().double().sum(1).float(), 1e-6, "absdiff_sums_f32 |a|")
+
+
+def test_fp32_family_rejects_mixed_precision(cuda):
     from rsvld_amd import _lib as L, ops
     x = torch.zeros(1, 4, 4, 8, device=cuda)
     pc16 = ops.pack_conv(torch.zeros(8, 8, 1, 1), None, torch.bfloat16, cuda)
     with pytest.raises(L.RsvldError):
         ops.conv2d(x, pc16, pad=0)                      # 16-bit weights with fp32 activations
-    pc = ops.pack_conv(torch.zeros(8, 16, 1, 1), None, torch.float32, cuda, cin_split=(8, 8))
     with pytest.raises(L.RsvldError):
-        ops.conv2d(x, pc, x2=x, pad=0)                  # two-source input is 16-bit only
+        ops.geglu(torch.zeros(4, 16, device=cuda))      # the stand-alone GEGLU kernel is 16-bit only (fp32: conv epilogue)
     with pytest.raises(L.RsvldError):
-        ops.layer_norm(x, torch.ones(8, device=cuda), torch.zeros(8, device=cuda))   # no fp32 LayerNorm: 16-bit expected
+        ops.axpby(x, x.to(torch.float16))
