@@ -71,6 +71,9 @@ def stage1_input(image_ids, lr_side, scale):
     return torch.nn.functional.interpolate(lr, scale_factor=scale, mode="bicubic", align_corners=False).clamp(-1, 1)
 
 
+PRECISION = "default"     # --precision
+
+
 def build_stage1(T):
     """The shipped Stage-1 option file (configs/sr_sr3.json) through the product's own factory
     (sr3_model.create_model, infer.py:96-103), seeded default init, ``T``-step 'val' schedule."""
@@ -83,6 +86,8 @@ def build_stage1(T):
     model = create_model(opt)
     sched = dict(opt["model"]["beta_schedule"]["val"], n_timestep=T)
     model.set_new_noise_schedule(sched, schedule_phase="val")
+    if PRECISION == "fp32":
+        model.netG.denoise_fn.set_compute_dtype("fp32")
     return model.netG, opt
 
 
@@ -108,6 +113,8 @@ def build_stage2(dev, tile_vae):
             if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
                 p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
     m.to(dev).eval()
+    if PRECISION == "fp32":
+        m.set_precision("fp32", "fp32")
     if tile_vae:   # SR_model.py:95-125: encoder tiles of 512 px, decoder tiles of 64 latent px, cross-tile GroupNorm
         m.init_tile_vae(512, 64)
     return m
@@ -373,7 +380,7 @@ def bench_headline(args, dev, rank, world):
         line = {
             "metric": METRIC, "value": round(value, 6), "unit": "img/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 (UNets, fp32 accumulate), bf16 (VAE)", "data": "synthetic",
+            "dtype": "f32" if PRECISION == "fp32" else "f16 (UNets, fp32 accumulate), bf16 (VAE)", "data": "synthetic",
             "config": {
                 "workload": (f"BASELINE configs[3]/[4] shape = the metric's configuration: {args.lr_side}x{args.lr_side} -> {side}x{side} "
                              f"x{args.scale} SR, one image per GPU per pass: Stage 1 SR3 {T} ancestral DDPM steps at {side}^2 + 8-bit "
@@ -455,7 +462,7 @@ def bench_stage2(args, dev, rank, world):
     line = {"metric": "Stage-2 images/sec (secondary workload)", "value": round(args.batch * world * args.steps / dt, 4),
             "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 (UNet/ControlNet), bf16 (VAE)", "data": "synthetic",
+            "dtype": "f32" if PRECISION == "fp32" else "f16 (UNet/ControlNet), bf16 (VAE)", "data": "synthetic",
             "config": {"workload": f"Stage 2 only, {side}x{side} input (latent {L}), batch {args.batch}/GPU, {args.ddpm_steps} EDM steps, "
                                    f"per-image feature-cache threshold {thr}, Wavelet, "
                                    f"{'tiled VAE (512 / 64)' if args.tile_vae else 'untiled VAE'}, full juggernautXL.yaml sizes",
@@ -505,7 +512,7 @@ def bench_stage1(args, dev, rank, world):
     line = {"metric": f"Stage-1 (SR3) {args.lr_side}->{side} x{args.scale} images/sec @{T} steps (BASELINE configs[1], secondary workload)",
             "value": round(args.batch * world * args.steps / dt, 4), "unit": "img/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if PRECISION == "fp32" else "f16", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: Stage-1 (SR3) only, {args.lr_side}->{side} x{args.scale} SR, "
                                    f"batch {args.batch}/GPU, {T} ancestral DDPM steps, seeded random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "hipgraph": bool(net.use_graph),
@@ -552,10 +559,15 @@ def main():
     ap.add_argument("--s2-threshold", type=float, default=None, help="feature-cache threshold (headline: 0 = off; c3/s2: 0.3)")
     ap.add_argument("--tile-vae", action="store_true", help="s2: VAEHook tiling (needed from 2048x2048 up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="default", choices=["default", "fp32"],
+                    help="fp32: both stages on the fp32-operand kernel family (the reference's CPU-path precision); secondary "
+                         "measurement only -- the metric is quoted on the reference's GPU policy (fp16 UNets, bf16 VAE)")
     ap.add_argument("--no-graph", action="store_true", help="c2: launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--pmc-pass", action="store_true", help="c4: one iteration of each stage + the fixed part and nothing "
                                                              "else (the process rocprofv3 --pmc counts)")
     args = ap.parse_args()
+    global PRECISION
+    PRECISION = args.precision
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))

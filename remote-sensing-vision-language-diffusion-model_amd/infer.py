@@ -54,8 +54,9 @@ class PipelineConfig:
     linear_s_stage2: bool = False
     spt_linear_cfg: float = 4.0
     spt_linear_s_stage2: float = 0.0
-    ae_dtype: str = "bf16"
-    diff_dtype: str = "fp16"
+    ae_dtype: str = "bf16"            # applied to the loaded Stage-2 model (the reference carries the two fields but never reads
+    diff_dtype: str = "fp16"          # them); "fp32" = the fp32-operand kernel family: the reference's CPU result to ~1e-5
+    sr3_dtype: str = "fp16"           # own field: Stage-1 UNet compute type; "fp32" = the reference's own Stage-1 precision
     no_llava: bool = False
     caption: str = ""                 # when non-empty it is used as the caption and LLaVA is not loaded
     prompt_yaml: str = str(_HERE / "prompts" / "prompt_config.yaml")
@@ -90,6 +91,7 @@ class SuperResolutionPipeline:
     def _load_sr3_model(self):
         opt = Logger.parse(SR3.SR3_Config())
         self.sr3_model = create_model(opt)
+        self.sr3_model.netG.denoise_fn.set_compute_dtype(self.cfg.sr3_dtype)
         sched = dict(opt["model"]["beta_schedule"]["val"])
         if self.cfg.sr3_steps > 0:
             sched["n_timestep"] = self.cfg.sr3_steps
@@ -105,6 +107,7 @@ class SuperResolutionPipeline:
         if self.refinement_model is None:
             raise RuntimeError(f"{self.cfg.model_yaml}: SR_CKPT is null, there are no pretrained weights to refine with")
         self.refinement_model.to(self.cfg.sr_model_device)
+        self.refinement_model.set_precision(self.cfg.ae_dtype, self.cfg.diff_dtype)
         if self.cfg.use_tile_vae:
             self.refinement_model.init_tile_vae(self.cfg.encoder_tile_size, self.cfg.decoder_tile_size)
 
@@ -173,10 +176,12 @@ def main(argv=None):
     p.add_argument("--llava_path", type=str, default="lmms-lab/llama3-llava-next-8b")
     p.add_argument("--llava_adapter", type=str, default="./CKPT_PTH/Llava-next")
     p.add_argument("--use_tile_vae", action="store_true")
+    p.add_argument("--fp32", action="store_true", help="both stages on the fp32-operand kernels (reference CPU-path precision; slow)")
     a = p.parse_args(argv)
     cfg = PipelineConfig(input_img=a.input_img, output_dir=a.output_dir, upscale_factor=a.upscale_factor, seed=a.seed,
                          img_threshold=a.img_threshold, edm_steps=a.edm_steps, sr3_steps=a.sr3_steps, caption=a.caption,
-                         no_llava=a.no_llava, llava_path=a.llava_path, llava_adapter=a.llava_adapter, use_tile_vae=a.use_tile_vae)
+                         no_llava=a.no_llava, llava_path=a.llava_path, llava_adapter=a.llava_adapter, use_tile_vae=a.use_tile_vae,
+                         **(dict(ae_dtype="fp32", diff_dtype="fp32", sr3_dtype="fp32") if a.fp32 else {}))
     SuperResolutionPipeline(cfg).process()
 
 

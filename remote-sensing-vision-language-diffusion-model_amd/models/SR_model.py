@@ -27,16 +27,21 @@ class SR_backbone(DiffusionEngine):
         self.first_stage_model.denoise_encoder = copy.deepcopy(self.first_stage_model.encoder)
         self.sampler_config = kwargs["sampler_config"]
 
-        assert (ae_dtype in ["fp32", "fp16", "bf16"]) and (diffusion_dtype in ["fp32", "fp16", "bf16"])
-        if ae_dtype == "fp16":
-            raise RuntimeError("fp16 cause NaN in AE")
-        # "fp32" (either one) runs that network on the fp32-operand kernel family (csrc/f32.hip): the reference without autocast
-        self.ae_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[ae_dtype]
-        self.model.dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[diffusion_dtype]
-        self.first_stage_model.set_compute_dtype(self.ae_dtype)
+        self.set_precision(ae_dtype, diffusion_dtype)
         self.p_p, self.n_p = p_p, n_p
         self.noise_source = "device"
         self.upscale, self.min_size = 1, 256
+
+    def set_precision(self, ae_dtype, diffusion_dtype):
+        """The reference fixes both in the constructor (SR_model.py:28-33); here they can also be switched on a loaded model.
+        "fp32" (either one) runs that network on the fp32-operand kernel family (csrc/f32.hip) -- the reference without
+        autocast, i.e. what its CPU path computes; "bf16" / "fp16" run the fast 16-bit kernels (fp32 accumulation)."""
+        assert (ae_dtype in ["fp32", "fp16", "bf16"]) and (diffusion_dtype in ["fp32", "fp16", "bf16"])
+        if ae_dtype == "fp16":
+            raise RuntimeError("fp16 cause NaN in AE")
+        self.ae_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[ae_dtype]
+        self.model.dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[diffusion_dtype]
+        self.first_stage_model.set_compute_dtype(self.ae_dtype)
 
     # ---- first stage ------------------------------------------------------------------------
     @torch.no_grad()

@@ -18,6 +18,9 @@ def define_G(opt):
         in_channel=u["in_channel"], out_channel=u["out_channel"], norm_groups=u["norm_groups"],
         inner_channel=u["inner_channel"], channel_mults=u["channel_multiplier"], attn_res=u["attn_res"],
         res_blocks=u["res_blocks"], dropout=u["dropout"], image_size=model_opt["diffusion"]["image_size"])
+    # own extension: the reference runs Stage 1 in plain fp32 (no autocast); this build defaults to fp16 storage + fp32
+    # accumulation (the fast 16-bit kernels) and offers the fp32-operand kernel family as "fp32" (csrc/f32.hip)
+    model.set_compute_dtype(u.get("compute_dtype", "fp16"))
     netG = diffusion.GaussianDiffusion(
         model, image_size=model_opt["diffusion"]["image_size"], channels=model_opt["diffusion"]["channels"],
         loss_type="l1", conditional=model_opt["diffusion"]["conditional"],

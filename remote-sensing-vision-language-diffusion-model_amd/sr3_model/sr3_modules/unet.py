@@ -156,6 +156,16 @@ class UNet(nn.Module):
         self._pk = None
         self.pack_version += 1
 
+    def set_compute_dtype(self, dt):
+        """fp16 (default) / bf16: 16-bit storage, fp32 accumulation; fp32: the fp32-operand kernel family (what the reference's
+        own Stage 1 computes in: it runs without autocast)."""
+        dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}.get(dt, dt)
+        if dt not in (torch.float16, torch.bfloat16, torch.float32):
+            raise ValueError(f"compute_dtype {dt!r}: fp16, bf16 or fp32")
+        if dt != self.compute_dtype:
+            self.compute_dtype = dt
+            self.invalidate_packed()
+
     def load_state_dict(self, *a, **k):
         self.invalidate_packed()
         return super().load_state_dict(*a, **k)

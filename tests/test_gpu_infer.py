@@ -14,7 +14,10 @@ import s2_common as S
 pytestmark = pytest.mark.gpu
 
 
-def test_pipeline_cli_flow(cuda, tmp_path):
+@pytest.mark.parametrize("prec", ["default", "fp32"])
+def test_pipeline_cli_flow(cuda, tmp_path, prec):
+    """``fp32``: PipelineConfig(ae_dtype / diff_dtype / sr3_dtype = "fp32") = the CLI's --fp32: both stages on the fp32-operand
+    kernel family; same files, same sizes."""
     from PIL import Image
     from rsvld_amd import infer
     cfg = yaml.safe_load(open(S.YAML.replace("juggernautXL.yaml", "juggernautXL_cached.yaml")))
@@ -32,8 +35,12 @@ def test_pipeline_cli_flow(cuda, tmp_path):
     lr.save(tmp_path / "tile.png")
     pc = infer.PipelineConfig(input_img=str(tmp_path / "tile.png"), output_dir=str(tmp_path / "out"), model_yaml=str(ypath),
                               allow_random_init=True, no_llava=True,
-                              upscale_factor=2, min_size=128, edm_steps=3, sr3_steps=3, seed=1, img_threshold=0.3)
+                              upscale_factor=2, min_size=128, edm_steps=3, sr3_steps=3, seed=1, img_threshold=0.3,
+                              **(dict(ae_dtype="fp32", diff_dtype="fp32", sr3_dtype="fp32") if prec == "fp32" else {}))
     pipe = infer.SuperResolutionPipeline(pc)
+    want_dt = torch.float32 if prec == "fp32" else torch.float16
+    assert pipe.sr3_model.netG.denoise_fn.compute_dtype == want_dt and pipe.refinement_model.model.dtype == want_dt
+    assert pipe.refinement_model.first_stage_model.compute_dtype == (torch.float32 if prec == "fp32" else torch.bfloat16)
     # zero-initialised output convs would make Stage 2 a no-op: give them small seeded weights
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
