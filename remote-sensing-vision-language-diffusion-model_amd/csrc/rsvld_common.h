@@ -21,11 +21,22 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // Operand maps (cdna_hip_programming.md §3): lane l holds A[row l&31][k = 8*(l>>5)+j] and
 // B[k = 8*(l>>5)+j][col l&31]; D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 template <typename T> struct Mfma;
+#ifndef RSVLD_MFMA16_TIMING
+#define RSVLD_MFMA16_TIMING 0   // diagnostic builds only (results WRONG, timing only): the same FLOPs issued as two 16x16x32 MFMAs
+#endif
 template <> struct Mfma<f16> {
     typedef f16x8 v8;
     typedef f16x4 v4;
     static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) {
+#if RSVLD_MFMA16_TIMING
+        f32x4 c0 = {c[0], c[1], c[2], c[3]}, c2 = {c[8], c[9], c[10], c[11]};
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c2, 0, 0, 0);
+        c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[8] = c2[0]; c[9] = c2[1]; c[10] = c2[2]; c[11] = c2[3];
+        return c;
+#else
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
     }
 };
 template <> struct Mfma<bf16> {
