@@ -299,6 +299,7 @@ def bench_headline(args, dev, rank, world):
     full = args.workload == "c4full"
     side = args.lr_side * args.scale
     latent = side // 8
+    is_metric_cfg = (args.lr_side, args.scale, T) == (512, 8, 50)      # the configuration BASELINE.json's metric is quoted on
     t0 = time.perf_counter()
     net, _ = build_stage1(T)
     net.use_graph = False            # launches are ms-long at 4096^2; eager keeps the per-launch HIP events usable
@@ -378,11 +379,14 @@ def bench_headline(args, dev, rank, world):
         roof = roofline_of(summ, "r02_c4_pmc_traffic.json")
         tf_img = (S1_TF_PER_IMAGE_STEP.get(side, 0) + S2_TF_PER_IMAGE_STEP.get(latent, 0)) * T
         line = {
-            "metric": METRIC, "value": round(value, 6), "unit": "img/s", "n_gpus": world, "steps": K, "warmup": W,
+            "metric": METRIC if is_metric_cfg else f"two-stage SR images/sec @{T} steps, {args.lr_side}px x{args.scale} (secondary workload)",
+            "value": round(value, 6), "unit": "img/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if PRECISION == "fp32" else "f16 (UNets, fp32 accumulate), bf16 (VAE)", "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE configs[3]/[4] shape = the metric's configuration: {args.lr_side}x{args.lr_side} -> {side}x{side} "
+                "workload": ((f"BASELINE configs[3]/[4] shape = the metric's configuration: " if is_metric_cfg else
+                              "BASELINE configs[2] shape (Stage 1 + Stage 2, cached text embeds): " if (args.lr_side, args.scale) == (512, 4)
+                              else "two-stage pipeline: ") + f"{args.lr_side}x{args.lr_side} -> {side}x{side} "
                              f"x{args.scale} SR, one image per GPU per pass: Stage 1 SR3 {T} ancestral DDPM steps at {side}^2 + 8-bit "
                              f"hand-off + Stage 2 {T} EDM steps at latent {latent} (ControlNet + UNet, CFG pair, feature cache "
                              f"{'OFF (threshold 0): uniform work per iteration' if thr <= 0 else thr}), tiled VAE 512/64, Wavelet colour "
