@@ -376,7 +376,8 @@ def bench_headline(args, dev, rank, world):
         torch.cuda.synchronize()
         ops.set_profiler(None)
         summ = prof.summary()
-        roof = roofline_of(summ, "r02_c4_pmc_traffic.json")
+        pmc = "r02_c4_pmc_traffic.json" if is_metric_cfg else "none (PMC passes exist for the metric's configuration only)"
+        roof = roofline_of(summ, pmc)
         tf_img = (S1_TF_PER_IMAGE_STEP.get(side, 0) + S2_TF_PER_IMAGE_STEP.get(latent, 0)) * T
         line = {
             "metric": METRIC if is_metric_cfg else f"two-stage SR images/sec @{T} steps, {args.lr_side}px x{args.scale} (secondary workload)",
@@ -402,7 +403,7 @@ def bench_headline(args, dev, rank, world):
                 "phases_ms": {k: round(v * 1e3, 1) for k, v in a.items()},
                 "timed_region_s": round(dt, 2), "model_build_s": round(build_s, 1), "finite": finite,
                 "algorithmic_tflops_whole_image": round(tf_img / (T * it1 + T * it2 + fx), 1),
-                "mfma_busy_instrumented_pass_pmc": mfma_busy_of_pass(summ, "r02_c4_pmc_traffic.json"),
+                "mfma_busy_instrumented_pass_pmc": mfma_busy_of_pass(summ, pmc),
                 "feature_cache": "off" if thr <= 0 else thr},
             "roofline": roof}
     if rank == 0:
