@@ -19,6 +19,7 @@ class HipNet(nn.Module):
     def __init__(self):
         super().__init__()
         self._pk = {}
+        self._pk_other = {}      # packed weights of the compute dtypes this network was switched away from
 
     # ---- cache invalidation whenever the fp32 master parameters move or change.  ``pack_version`` counts them: captured
     # hipGraphs hold raw pointers into the packed tensors and key themselves on it.
@@ -26,6 +27,17 @@ class HipNet(nn.Module):
 
     def invalidate_packed(self):
         self._pk = {}
+        self._pk_other = {}
+        self.pack_version += 1
+
+    def set_compute_dtype(self, dt):
+        """Switch the operand type (fp16 / bf16: 16-bit kernels, fp32: the fp32-operand family).  The packed weights of the
+        previous type are kept, so switching back and forth (precision A/B runs, tests) packs each type once."""
+        if dt == self.compute_dtype:
+            return
+        self._pk_other[self.compute_dtype] = self._pk
+        self.compute_dtype = dt
+        self._pk = self._pk_other.pop(dt, {})
         self.pack_version += 1
 
     def load_state_dict(self, *a, **k):

@@ -32,10 +32,10 @@ class AutoencoderKL(HipNet):
     def set_compute_dtype(self, dt):
         """bf16 (the reference's default), fp16 (tests only: real SDXL-VAE activations overflow it) or fp32 (``ae_dtype:
         fp32``: the fp32-operand kernel family, csrc/f32.hip)."""
-        for m in (self, self.encoder, self.decoder, getattr(self, "denoise_encoder", None)):
-            if m is not None and m.compute_dtype != dt:
-                m.compute_dtype = dt
-                m.invalidate_packed()
+        for m in (self.encoder, self.decoder, getattr(self, "denoise_encoder", None)):
+            if m is not None:
+                HipNet.set_compute_dtype(m, dt)
+        HipNet.set_compute_dtype(self, dt)
 
     def moments(self, x, encoder=None):
         """posterior parameters, fp32 NHWC ``[B, h, w, 8]`` (mean | logvar)."""

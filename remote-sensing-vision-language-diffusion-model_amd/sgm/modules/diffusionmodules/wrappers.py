@@ -47,9 +47,7 @@ class ControlWrapper(nn.Module):
             raise RsvldError("ControlWrapper runs on the GPU only")
         dt = self._compute_dtype()
         for net in (self.diffusion_model, self.control_model):
-            if net.compute_dtype != dt:          # the packed 16-bit weights are per dtype
-                net.compute_dtype = dt
-                net.invalidate_packed()
+            net.set_compute_dtype(dt)            # packed weights are per dtype (kept across switches)
         context = c.get("crossattn", None)
         if context is not None and context.dtype != dt:
             cached = getattr(self, "_ctx_cast", None)

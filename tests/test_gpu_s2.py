@@ -46,14 +46,12 @@ def _diffusion_dtype(m, dt):
     try:
         w.dtype = dt
         for net in (w.diffusion_model, w.control_model):
-            net.compute_dtype = dt
-            net.invalidate_packed()
+            net.set_compute_dtype(dt)
         yield
     finally:
         w.dtype = old
         for net in (w.diffusion_model, w.control_model):
-            net.compute_dtype = old
-            net.invalidate_packed()
+            net.set_compute_dtype(old)
 
 
 # tolerance scale per diffusion dtype: fp16 bounds are stated per check; fp32 (different summation order only) 3e-5 x range
@@ -84,6 +82,7 @@ def test_ops_vs_reference_golden(model, cuda, golden_dir, prec):
 def _ops_vs_golden(m, cuda, golden_dir, prec):
     from rsvld_amd import ops
     unet = m.model.diffusion_model
+    assert unet.compute_dtype == prec
     z = np.load(os.path.join(golden_dir, "s2_networks.npz"))
     emb, ctx = S.rnd((2, 1280), 50, 0.5).to(cuda), S.rnd((2, 77, 64), 51).to(cuda, prec)
     rows = unet.emb_rows(emb)
@@ -291,12 +290,22 @@ def test_tile_blend_kernels(cuda):
         ops.tile_blend_accumulate(a, c, tile.to(cuda), w.to(cuda), 9, 17)      # window past the bottom edge
 
 
-def test_tiled_restore_edm_sampler_vs_oracle(model, cuda):
+@pytest.mark.parametrize("prec", [torch.float16, torch.float32], ids=["fp16", "fp32"])
+def test_tiled_restore_edm_sampler_vs_oracle(model, cuda, prec):
     """TiledRestoreEDMSampler (latent 24x24, tile 16, stride 8 -> 4 overlapping tiles, 2 steps, churn + restore pull +
-    linear CFG) against the CPU restatement with the same draws.  2e-2 x range: fp16 UNet/ControlNet vs fp32 oracle."""
+    linear CFG) against the CPU restatement with the same draws.  fp16 UNet/ControlNet vs the fp32 oracle: 6e-3 x range;
+    with ``diffusion_dtype: fp32`` the tile loop / mask / blend logic agrees with the restatement to 3e-5."""
+    m, sd = model
+    with _diffusion_dtype(m, prec):
+        _tiled_sampler_vs_oracle(m, sd, cuda, _R(prec, 6e-3))
+
+
+_TILED_WANT = {}     # the CPU restatement takes ~30 s on the box's host: computed once for both precisions
+
+
+def _tiled_sampler_vs_oracle(m, sd, cuda, bound):
     from oracle import s2_oracle as O
     from rsvld_amd.sgm.util import instantiate_from_config
-    m, sd = model
     table = O.legacy_ddpm_sigmas(1000, append_zero=False, flip=True)
     cd, ucd = S.cond_dicts()
     zc, x0, xc = S.rnd((1, 4, 24, 24), 301, 0.5), S.rnd((1, 4, 24, 24), 302), S.rnd((1, 4, 24, 24), 303, 0.5)
@@ -304,8 +313,10 @@ def test_tiled_restore_edm_sampler_vs_oracle(model, cuda):
     opt = dict(s_churn=5, s_noise=1.003, restore_cfg=2.0, scale=4.0, scale_min=7.5, control_scale=1.0)
     draws = [S.rnd((1, 4, 24, 24), 310 + i) for i in range(2)]
     it = iter(draws)
-    want = O.tiled_restore_edm(sd, table, x0, sigmas, {**cd, "control": zc}, {**ucd, "control": zc}, xc, opt,
-                               lambda shape: next(it), 16, 8)
+    if "want" not in _TILED_WANT:
+        _TILED_WANT["want"] = O.tiled_restore_edm(sd, table, x0, sigmas, {**cd, "control": zc}, {**ucd, "control": zc}, xc, opt,
+                                                  lambda shape: next(it), 16, 8)
+    want = _TILED_WANT["want"]
     cfg = {"target": "rsvld_amd.sgm.modules.diffusionmodules.sampling.TiledRestoreEDMSampler",
            "params": {"tile_size": 16, "tile_stride": 8, "num_steps": 2, "restore_cfg": 2.0, "s_churn": 5, "s_noise": 1.003,
                       "discretization_config": {"target": "rsvld_amd.sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
@@ -321,7 +332,7 @@ def test_tiled_restore_edm_sampler_vs_oracle(model, cuda):
 
     got = sampler(denoiser, x0.to(cuda), dev({**cd, "control": zc}), uc=dev({**ucd, "control": zc}), x_center=xc.to(cuda))
     assert got.shape == (1, 4, 24, 24)
-    _cmp(got, want, 6e-3, "tiled sampler, 2 steps x 4 tiles")                         # measured 2.6e-3 x range
+    _cmp(got, want, bound, "tiled sampler, 2 steps x 4 tiles")                        # fp16: measured 2.6e-3 x range
     with pytest.raises(ValueError):
         sampler(denoiser, x0[:, :, :8, :8].to(cuda), dev({**cd, "control": zc[:, :, :8, :8]}), uc=dev({**ucd, "control": zc[:, :, :8, :8]}))
 
