@@ -37,6 +37,9 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
+#ifndef G_ABL
+#define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue
+#endif
 constexpr int G_NST = 4;
 constexpr int G_SMEM = G_NST * G_STAGE;
 
@@ -182,6 +185,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         }
     }
 
+#if G_ABL & 2
+    if (p.M > 0) return;   // diagnostic build: no epilogue at all (the accumulators stay live for the compiler)
+#endif
     // ---- epilogue through LDS (the ring is dead after the last barrier): a lane owns one output row and, per register
     // quad, four consecutive channels, i.e. 8-byte pieces 512 B apart -- stored like that the 128 KiB tile leaves the
     // CU in 16-byte fragments (measured: 17 us per tile, more than the K loop of a K = 640 layer).  So: bias / SiLU /
@@ -235,6 +241,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             for (int row = tid / row_chunks; row < 256; row += rows_per_pass) {
                 const int m = m0 + row;
                 if (m >= p.M) break;
+#if G_ABL & 1
+                if (p.M > 0) break;   // diagnostic build: the tile is staged in LDS but neither stored nor joined with the residual
+#endif
                 u32x4 v = *(const u32x4*)(smem + c_off(row, chunk));
                 if (p.residual != nullptr) {
                     float f[8], rf[8];
@@ -274,8 +283,8 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     a.M = (int)M; a.N = d->Cout; a.K = d->Cin;
     a.N_out = d->act == RSVLD_ACT_GEGLU ? d->Cout / 2 : d->Cout;
     a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
-    dim3 grid((unsigned)((M + 255) / 256), (unsigned)((d->Cout + 255) / 256));
     hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)((d->Cout + 255) / 256));
     auto go = [&](auto kern) -> int {
         static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM);
         if (attr != hipSuccess) return RSVLD_ELAUNCH;
