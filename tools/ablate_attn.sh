@@ -5,7 +5,8 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/remote-sensing-vision-language-diffusion-model_amd/csrc
 mkdir -p $ROOT/tools/ablate
-# MACRO=A5B_ABL (d = 512 kernel; list 1 4 5) or MACRO=A6B_ABL (d = 64 kernel; list 1 2 8 9 11)
+# MACRO=A5B_ABL (d = 512 kernel; list 1 4 5) or MACRO=A6B_ABL (d = 64 kernel; bits: 1 no exp, 2 no in-loop DMA / barrier, 8 no running
+# max / row sum, 16 no V fragment reads, 32 no K fragment reads; lists used: "1 2 8 9 11" and "16 32 48 50 59")
 MACRO=${MACRO:-A5B_ABL}
 LIST=${LIST:-"1 4 5"}
 for N in $LIST; do
