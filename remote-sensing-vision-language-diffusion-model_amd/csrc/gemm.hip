@@ -41,7 +41,8 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue
 #endif
 constexpr int G_NST = 4;
-constexpr int G_SMEM = G_NST * G_STAGE;
+constexpr int G_RING = G_NST * G_STAGE;
+constexpr int G_SMEM = G_RING + 1024;   // + the tile's 256 bias values (fp32), fetched once while the ring fills
 
 // 64-B rows: 16-B slot s of row r sits at s ^ ((r>>2)&3): conflict-free ds_read_b128 (brute-forced, see conv_halo.hip)
 __device__ __forceinline__ int g_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
@@ -150,7 +151,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue: three tiles in flight, tile 0 landed for everybody
+    // ---- prologue: three tiles in flight, tile 0 landed for everybody; the tile's bias row goes to LDS beside the ring (the
+    // epilogue read it from global memory once per accumulator quad: a dependent L2 round trip at the head of every output burst)
+    if (tid < 64) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        const int n = n0 + tid * 4;
+        if (p.bias != nullptr && n < p.N) bv = *(const f32x4*)(p.bias + n);   // N % 8 == 0: a quad is inside or outside as a whole
+        *(f32x4*)(smem + G_RING + tid * 16) = bv;
+    }
     dma_tile(0);
     if (nk > 1) dma_tile(1);
     if (nk > 2) dma_tile(2);
@@ -205,10 +213,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = wn * 64 + ni * 32 + 8 * g + 4 * lh;   // tile column of the quad
-                const int n = n0 + col;
                 float v[4] = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
-                if (p.bias != nullptr && n < p.N) {
-                    const f32x4 bv = *(const f32x4*)(p.bias + n);
+                {
+                    const f32x4 bv = *(const f32x4*)(smem + G_RING + col * 4);   // zeros without a bias / past N
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += bv[e];
                 }
@@ -238,22 +245,36 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int rows_per_pass = 512 / row_chunks;
         const int nn = n_out0 + chunk * 8;
         if (nn < p.N_out) {
-            for (int row = tid / row_chunks; row < 256; row += rows_per_pass) {
-                const int m = m0 + row;
-                if (m >= p.M) break;
-#if G_ABL & 1
-                if (p.M > 0) break;   // diagnostic build: the tile is staged in LDS but neither stored nor joined with the residual
-#endif
-                u32x4 v = *(const u32x4*)(smem + c_off(row, chunk));
-                if (p.residual != nullptr) {
-                    float f[8], rf[8];
-                    unpack8<T>(v, f);
-                    unpack8<T>(*(const u32x4*)((const T*)p.residual + (int64_t)m * p.N_out + nn), rf);
+            // four rows per step: the LDS reads and the residual loads of all four are in flight before the first add
+            // (one row at a time every store waited for its own residual load: 16 dependent round trips per thread)
+            for (int row0 = tid / row_chunks; row0 < 256; row0 += 4 * rows_per_pass) {
+                u32x4 v[4], rv[4];
+                bool ok[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
-                    v = pack8<T>(f);
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + i * rows_per_pass;
+                    ok[i] = row < 256 && m0 + row < p.M;
+#if G_ABL & 1
+                    ok[i] = ok[i] && p.M < 0;   // diagnostic build: the tile is staged in LDS but neither stored nor joined with the residual
+#endif
+                    if (ok[i]) {
+                        v[i] = *(const u32x4*)(smem + c_off(row, chunk));
+                        if (p.residual != nullptr) rv[i] = *(const u32x4*)((const T*)p.residual + (int64_t)(m0 + row) * p.N_out + nn);
+                    }
                 }
-                *(u32x4*)((T*)p.out + (int64_t)m * p.N_out + nn) = v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!ok[i]) continue;
+                    if (p.residual != nullptr) {
+                        float f[8], rf[8];
+                        unpack8<T>(v[i], f);
+                        unpack8<T>(rv[i], rf);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
+                        v[i] = pack8<T>(f);
+                    }
+                    *(u32x4*)((T*)p.out + (int64_t)(m0 + row0 + i * rows_per_pass) * p.N_out + nn) = v[i];
+                }
             }
         }
         (void)n_tile_out;

@@ -19,8 +19,9 @@ for (M, K, N, act) in SHAPES:
     w = torch.randn(N, K) / K ** 0.5
     pc = ops.pack_conv(w, torch.zeros(N), torch.float16, dev, geglu=(act == 2))
     wt = w.to(dev, torch.float16)
+    res_t = torch.randn(M, N, device=dev, dtype=torch.float16) if (os.environ.get("RESIDUAL") and act == 0) else None   # to_out / FF2 / proj_out
     def ours():
-        return ops.linear(x, pc, act=act)
+        return ops.linear(x, pc, act=act, residual=res_t)
     def lib():
         return x @ wt.t()
     res = []
