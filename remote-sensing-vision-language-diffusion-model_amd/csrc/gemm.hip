@@ -205,6 +205,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const bool geglu = p.act == RSVLD_ACT_GEGLU;
     const int row_chunks = geglu ? 16 : 32;                 // 16-byte chunks per tile row
     auto c_off = [&](int row, int chunk) { return row * (row_chunks * 16) + ((chunk ^ (row & (row_chunks - 1))) << 4); };
+    // The residual pieces this thread will add on the way out (rows tid/32 + 16 i, its 16-byte chunk) are requested NOW, so
+    // that their HBM round trip runs under the staging pass and its barrier instead of after them (the fragment registers
+    // are dead here).  Never together with GEGLU (checked on the host).
+    const bool has_res = p.residual != nullptr;
+    u32x4 rv[16];
+    if (has_res) {
+        const int nn = n0 + (tid & 31) * 8;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + (tid >> 5) + 16 * i;
+            rv[i] = (m < p.M && nn < p.N_out && !(G_ABL & 1)) ? *(const u32x4*)((const T*)p.residual + (int64_t)m * p.N_out + nn)
+                                                              : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int row = grp * 128 + mi * 32 + l31;
@@ -244,37 +258,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int chunk = tid & (row_chunks - 1);
         const int rows_per_pass = 512 / row_chunks;
         const int nn = n_out0 + chunk * 8;
-        if (nn < p.N_out) {
-            // four rows per step: the LDS reads and the residual loads of all four are in flight before the first add
-            // (one row at a time every store waited for its own residual load: 16 dependent round trips per thread)
-            for (int row0 = tid / row_chunks; row0 < 256; row0 += 4 * rows_per_pass) {
-                u32x4 v[4], rv[4];
-                bool ok[4];
+        if (has_res) {            // row_chunks = 32, 16 rows per thread, compile-time indices into rv[]
+            if (nn < p.N_out) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = row0 + i * rows_per_pass;
-                    ok[i] = row < 256 && m0 + row < p.M;
-#if G_ABL & 1
-                    ok[i] = ok[i] && p.M < 0;   // diagnostic build: the tile is staged in LDS but neither stored nor joined with the residual
-#endif
-                    if (ok[i]) {
-                        v[i] = *(const u32x4*)(smem + c_off(row, chunk));
-                        if (p.residual != nullptr) rv[i] = *(const u32x4*)((const T*)p.residual + (int64_t)(m0 + row) * p.N_out + nn);
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (tid >> 5) + 16 * i;
+                    if (m0 + row >= p.M || ((G_ABL & 1) && p.M > 0)) continue;
+                    float f[8], rf[8];
+                    unpack8<T>(*(const u32x4*)(smem + c_off(row, chunk)), f);
+                    unpack8<T>(rv[i], rf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
+                    *(u32x4*)((T*)p.out + (int64_t)(m0 + row) * p.N_out + nn) = pack8<T>(f);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (!ok[i]) continue;
-                    if (p.residual != nullptr) {
-                        float f[8], rf[8];
-                        unpack8<T>(v[i], f);
-                        unpack8<T>(rv[i], rf);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
-                        v[i] = pack8<T>(f);
-                    }
-                    *(u32x4*)((T*)p.out + (int64_t)(m0 + row0 + i * rows_per_pass) * p.N_out + nn) = v[i];
-                }
+            }
+        } else if (nn < p.N_out) {
+            for (int row = tid / row_chunks; row < 256; row += rows_per_pass) {
+                if (m0 + row >= p.M || ((G_ABL & 1) && p.M > 0)) break;
+                *(u32x4*)((T*)p.out + (int64_t)(m0 + row) * p.N_out + nn) = *(const u32x4*)(smem + c_off(row, chunk));
             }
         }
         (void)n_tile_out;
