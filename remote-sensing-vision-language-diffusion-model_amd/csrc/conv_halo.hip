@@ -80,8 +80,21 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
     float st_s[8], st_q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { st_s[e] = 0.f; st_q[e] = 0.f; }
+    constexpr int RPT = EPI_ROWS / RPP;        // rows each thread stores per pass
 #pragma unroll
     for (int pass = 0; pass < EPI_PASSES; ++pass) {
+        // The residual pieces of this pass are requested BEFORE the staging writes and their barrier, so that the HBM round trip
+        // runs under them (one row at a time every store waited for its own residual load; same change as in gemm.hip).
+        u32x4 rres[RPT];
+        if (p.residual != nullptr && n < p.Cout) {
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int prow = pass * EPI_ROWS + rr + j * RPP;
+                const int y = y0 + (prow >> 5), x = x0 + (prow & 31);
+                rres[j] = (y < p.H && x < p.W) ? *(const u32x4*)((const T*)p.residual + (((int64_t)img * p.H + y) * p.W + x) * p.Cout_out + n)
+                                               : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
         if (pass > 0) __syncthreads();
         if ((wm * TM * 32) / EPI_ROWS == pass) {
 #pragma unroll
@@ -98,7 +111,9 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
         }
         __syncthreads();
         if (n < p.Cout) {
-            for (int row = rr; row < EPI_ROWS; row += RPP) {
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int row = rr + j * RPP;
                 const int prow = pass * EPI_ROWS + row;
                 const int y = y0 + (prow >> 5), x = x0 + (prow & 31);
                 if (y >= p.H || x >= p.W) continue;
@@ -121,7 +136,7 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
                 for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
                 if (p.residual != nullptr) {
                     float rf[8];
-                    unpack8<T>(*(const u32x4*)((const T*)p.residual + m * p.Cout_out + n), rf);
+                    unpack8<T>(rres[j], rf);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += p.beta * rf[e];
                 }

@@ -24,6 +24,7 @@ for (B, H, W, C1, C2, Co) in SHAPES:
     w = torch.randn(Co, C1 + C2, 3, 3) / (3 * (C1 + C2) ** 0.5)
     pc = ops.pack_conv(w, torch.zeros(Co), torch.float16, dev)
     gamma, beta = torch.ones(C1 + C2, device=dev), torch.zeros(C1 + C2, device=dev)
+    res_t = torch.randn(B, H, W, Co, device=dev, dtype=torch.float16) if os.environ.get("RESIDUAL") else None   # ResBlock second conv
     flops = 2.0 * B * H * W * Co * (C1 + C2) * 9
     row = f"B{B} {H}x{W} Cin{C1}+{C2} Cout{Co}: "
     for label, norm in (("plain", None), ("gn+silu", (gamma, beta, 32, 1e-5, True))):
@@ -32,13 +33,13 @@ for (B, H, W, C1, C2, Co) in SHAPES:
             lib = ops.L.load()
             ab = None
         for _ in range(3):
-            y = ops.conv2d(x, pc, x2=x2, pad=1, norm=norm)
+            y = ops.conv2d(x, pc, x2=x2, pad=1, norm=norm, residual=res_t)
         torch.cuda.synchronize()
         # time only the conv kernel launches via the launch profiler
         prof = ops.LaunchProfiler()
         ops.set_profiler(prof)
         for _ in range(reps):
-            y = ops.conv2d(x, pc, x2=x2, pad=1, norm=norm)
+            y = ops.conv2d(x, pc, x2=x2, pad=1, norm=norm, residual=res_t)
         ops.set_profiler(None)
         agg = prof.summary()
         ms = sum(r["ms"] for k, r in agg.items() if k.startswith("conv_")) / reps
