@@ -291,6 +291,23 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
     // ---- epilogue: accumulators -> LDS out tile Ct[pixel][cout] (fp32, row stride BN+4)
     constexpr int CT_STRIDE = BN + 4;
     float* Ct = (float*)smem_all;
+    constexpr int CPR = BN / 8;               // 8-channel chunks per tile row
+    constexpr int RPP = 256 * KS / CPR;       // rows per pass
+    constexpr int RPT = (BM + RPP - 1) / RPP; // rows each thread stores
+    const int cc = (int)threadIdx.x % CPR;
+    const int rr = (int)threadIdx.x / CPR;
+    const int n = n0 + cc * 8;
+    // the residual pieces this thread will add on the way out are requested before the staging pass (their HBM round trip
+    // runs under it; same change as in gemm.hip / conv_halo.hip)
+    u32x4 rres[RPT];
+    if (p.residual != nullptr && n < p.Cout && p.act != RSVLD_ACT_GEGLU) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int row = rr + j * RPP;
+            const int64_t m = m0 + row;
+            rres[j] = (row < BM && m < p.M) ? *(const u32x4*)((const T*)p.residual + m * p.Cout_out + n) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
 #pragma unroll
     for (int g2 = 0; g2 < KS; ++g2) {    // K groups add their partial tiles one after the other (fixed order)
         if (kg == g2) {
@@ -310,19 +327,16 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
         __syncthreads();
     }
 
-    constexpr int CPR = BN / 8;               // 8-channel chunks per tile row
-    constexpr int RPP = 256 * KS / CPR;       // rows per pass
-    const int cc = (int)threadIdx.x % CPR;
-    const int rr = (int)threadIdx.x / CPR;
-    const int n = n0 + cc * 8;
     if (n >= p.Cout) return;
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = (p.bias != nullptr && n + e < p.Cout) ? p.bias[n + e] : 0.f;
 
-    for (int row = rr; row < BM; row += RPP) {
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int row = rr + j * RPP;
         const int m = m0 + row;
-        if (m >= p.M) break;
+        if (row >= BM || m >= p.M) break;
         const f32x4 v0 = *(const f32x4*)(Ct + row * CT_STRIDE + cc * 8);
         const f32x4 v1 = *(const f32x4*)(Ct + row * CT_STRIDE + cc * 8 + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -352,9 +366,8 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
         if (p.residual != nullptr) {
-            const u32x4 rres = *(const u32x4*)((const T*)p.residual + (int64_t)m * p.Cout_out + n);
             float rf[8];
-            unpack8<T>(rres, rf);
+            unpack8<T>(rres[j], rf);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += p.beta * rf[e];
         }
