@@ -38,7 +38,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_ABL
-#define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue
+#define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue, 4 three K steps
 #endif
 constexpr int G_NST = 4;
 constexpr int G_RING = G_NST * G_STAGE;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         tile_m = t - tile_n * nmt;
     }
     const int m0 = tile_m * 256, n0 = tile_n * 256;
-    const int nk = p.K >> 5;
+    const int nk = (G_ABL & 4) ? 3 : (p.K >> 5);   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
     const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T);
 
     // ---- DMA roles: wave w fills rows 32w .. 32w+31 of X and of W: two wave-instructions of 16 rows x 64 B each.
