@@ -98,6 +98,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  If this library were loaded before torch, the
+    # loader would bind it to the system copy under /opt/rocm and the process would hold two HIP runtimes -- kernels launched
+    # through one on streams and pointers owned by the other fail with hipErrorInvalid* (seen as RSVLD_ELAUNCH).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RsvldError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

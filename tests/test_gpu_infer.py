@@ -131,3 +131,14 @@ def test_pipeline_with_live_caption_end_to_end(cuda, tmp_path):
     assert isinstance(seen["caption"], str) and len(seen["caption"]) > 0          # the live caption reached Stage 2
     assert [os.path.basename(o) for o in outs] == ["tile_final_0.png"]
     assert np.asarray(Image.open(outs[0])).std() > 1.0
+
+
+def test_build_then_smoke_in_one_process(cuda):
+    """__graft_entry__.build() followed by smoke() in ONE fresh process: build() loads librsvld_hip.so before anything has
+    touched the GPU, and the library must then share torch's HIP runtime (rsvld_amd._lib.load imports torch first; loaded the
+    other way round the process held two HIP runtimes and the first launch failed with RSVLD_ELAUNCH)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "smoke: SR3 p_sample" in r.stdout, (r.stdout + r.stderr)[-2000:]
