@@ -294,7 +294,7 @@ def cpu_baseline_headline(m, params, T, side, latent):
 
 # --------------------------------------------------------------------------------------------- headline: c4 / c4full
 def bench_headline(args, dev, rank, world):
-    from rsvld_amd import ops, parallel
+    from rsvld_amd import measure, ops, parallel
     T, K, W = args.ddpm_steps, args.steps, args.warmup
     full = args.workload == "c4full"
     side = args.lr_side * args.scale
@@ -315,11 +315,13 @@ def bench_headline(args, dev, rank, world):
         """Stage 1 -> hand-off -> Stage 2 -> uint8 -> all-gather; ``n_iter`` sampler iterations per stage (None = all)."""
         torch.manual_seed(42 + img_id)                      # per-image RNG streams: results do not depend on the GPU count
         ph.start()
-        sr = net.super_resolution(cond, continous=True, _max_steps=n_iter, _stamp=ph)[-1:]
+        with measure.hooks(net, stamp=ph, max_steps=n_iter):
+            sr = net.super_resolution(cond, continous=True)[-1:]
         u8 = parallel.to_uint8(sr)                          # utils/tensor2img.py:4-21: the 8-bit hand-off
         lq = u8.float() / 127.5 - 1.0                       # models/util.py:132-156 (4096 is a multiple of 64)
         ph("handoff")
-        out = m.just_sampling(lq, [""], **dict(S2_KW, img_threshold=thr, num_steps=T), _max_steps=n_iter, _stamp=ph)
+        with measure.hooks(m, stamp=ph, max_steps=n_iter):
+            out = m.just_sampling(lq, [""], **dict(S2_KW, img_threshold=thr, num_steps=T))
         gathered = parallel.gather_images(parallel.to_uint8(out), world)   # one RCCL all-gather of finished uint8 images
         ph("gather")
         return gathered
@@ -367,6 +369,20 @@ def bench_headline(args, dev, rank, world):
         value = world / (T * it1 + T * it2 + fx)
     finite = bool(torch.isfinite(out.float()).all())
 
+    # ---- data-parallel self-check (outside the timed region): every rank runs ONE iteration per stage + the fixed part on
+    # its image and the results are gathered; rank 0 then computes the LAST rank's image by itself, the way a 1-rank job
+    # would, and compares it bit for bit with what that rank contributed (per-image seeds: infer_dir.py:198-200 sharding must
+    # not change an image)
+    dp_check = None
+    if world > 1 and not full:
+        chk = one_image(rank, cond, 1, Phases())
+        if rank == 0:
+            probe = world - 1
+            ref = _local_pass(net, m, image_inputs(probe), T, thr, 1, seed=42 + probe)
+            dp_check = {"image": probe, "iterations_per_stage": 1,
+                        "bit_identical_to_single_rank_run": bool(torch.equal(chk[probe].cpu(), ref[0].cpu()))}
+        barrier(world)
+
     line = None
     if rank == 0:
         # ---- roofline: one extra instrumented pass (2 iterations per stage + the fixed part), not part of `value`
@@ -404,26 +420,30 @@ def bench_headline(args, dev, rank, world):
                 "timed_region_s": round(dt, 2), "model_build_s": round(build_s, 1), "finite": finite,
                 "algorithmic_tflops_whole_image": round(tf_img / (T * it1 + T * it2 + fx), 1),
                 "mfma_busy_instrumented_pass_pmc": mfma_busy_of_pass(summ, pmc),
-                "feature_cache": "off" if thr <= 0 else thr},
+                "feature_cache": "off" if thr <= 0 else thr, "dp_self_check": dp_check},
             "roofline": roof}
     if rank == 0:
         line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_headline(m, params, T, side, latent)
         print(json.dumps(line), flush=True)
 
 
-def _local_pass(net, m, cond, T, thr, n_iter):
-    """Collective-free pass on the calling rank (the instrumented roofline pass)."""
-    from rsvld_amd import parallel
-    sr = net.super_resolution(cond, continous=True, _max_steps=n_iter)[-1:]
+def _local_pass(net, m, cond, T, thr, n_iter, seed=None):
+    """Collective-free pass on the calling rank (the instrumented roofline pass; the data-parallel self-check)."""
+    from rsvld_amd import measure, parallel
+    if seed is not None:
+        torch.manual_seed(seed)
+    with measure.hooks(net, max_steps=n_iter):
+        sr = net.super_resolution(cond, continous=True)[-1:]
     lq = parallel.to_uint8(sr).float() / 127.5 - 1.0
-    return parallel.to_uint8(m.just_sampling(lq, [""], **dict(S2_KW, img_threshold=thr, num_steps=T), _max_steps=n_iter))
+    with measure.hooks(m, max_steps=n_iter):
+        return parallel.to_uint8(m.just_sampling(lq, [""], **dict(S2_KW, img_threshold=thr, num_steps=T)))
 
 
 # --------------------------------------------------------------------------------------------- Stage 2 only: s2 / c3
 def bench_stage2(args, dev, rank, world):
     """Secondary workloads (not the contract line).  ``c3`` = BASELINE configs[2]: Stage 2 on 2048^2 inputs (latent 256),
     batch 8 per GPU, 50 EDM steps, per-image feature cache 0.3, Wavelet, tiled VAE.  ``s2``: any size / batch."""
-    from rsvld_amd import ops
+    from rsvld_amd import measure, ops
     if args.workload == "c3":
         args.s2_side, args.batch, args.tile_vae = 2048, (8 if "--batch" not in sys.argv else args.batch), True
         if "--s2-threshold" not in sys.argv:
@@ -458,7 +478,8 @@ def bench_stage2(args, dev, rank, world):
         return
     prof = ops.LaunchProfiler()
     ops.set_profiler(prof)
-    m.just_sampling(img, [""] * args.batch, **dict(kw, _max_steps=2))
+    with measure.hooks(m, max_steps=2):
+        m.just_sampling(img, [""] * args.batch, **kw)
     torch.cuda.synchronize()
     ops.set_profiler(None)
     summ = prof.summary()

@@ -63,7 +63,6 @@ class PipelineConfig:
     base_model_device: str = "cuda:0" # the reference puts LLaVA on a second GPU (cuda:1); one MI355X holds everything
     llava_path: str = "lmms-lab/llama3-llava-next-8b"
     llava_adapter: str = "./CKPT_PTH/Llava-next"
-    llava_seed: int = 0
     use_tile_vae: bool = False
     encoder_tile_size: int = 512
     decoder_tile_size: int = 64
@@ -136,7 +135,9 @@ class SuperResolutionPipeline:
         dev = self.cfg.base_model_device
         views = LN.process_images([sr_image], self.llava_image_processor, self.llava_model.config)
         views = [v.to(dtype=torch.float16, device=dev) for v in views]
-        seed = self.cfg.llava_seed if self.cfg.seed < 0 else self.cfg.seed
+        # a fixed --seed makes the caption reproducible too (sampled inside a forked generator: Stage 2's noise draws do not
+        # depend on how many tokens were sampled); --seed < 0 means "random run": the caption samples from the current state
+        seed = None if self.cfg.seed < 0 else self.cfg.seed
         return LN.get_img_describe(image_tensor=views, image=sr_image, model=self.llava_model, tokenizer=self.llava_tokenizer,
                                    prompt=img_prompt, max_new_tokens=256, device=dev, seed=seed)[0]
 

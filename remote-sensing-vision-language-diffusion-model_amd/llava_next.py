@@ -337,26 +337,57 @@ def merge_lora(model, adapter_dir):
     return merged
 
 
+def resolve_model_dir(model_path):
+    """A local directory as is; a hub id (``lmms-lab/llama3-llava-next-8b``, models/util.py:112-114) through the local
+    Hugging Face cache only -- this build never fetches from the network."""
+    if os.path.isdir(model_path):
+        return model_path
+    try:
+        from huggingface_hub import snapshot_download
+        return snapshot_download(model_path, local_files_only=True)
+    except Exception as exc:   # not cached (LocalEntryNotFoundError), malformed id, hub library absent
+        raise FileNotFoundError(
+            f"load_llava: {model_path!r} is neither a directory nor a snapshot in the local Hugging Face cache "
+            f"({type(exc).__name__}); download the checkpoint first, or skip the captioner with --no_llava / --caption") from exc
+
+
 def load_llava(device="cuda", model_path=DEFAULT_MODEL, adapter_path=DEFAULT_ADAPTER, dtype=torch.float16):
     """-> (tokenizer, model, image_processor), the tuple of models/util.py:111-117.  SDPA attention (flash-attn does not
-    exist on this platform and is not needed); the adapter is applied by ``peft`` when installed, else merged here."""
-    from transformers import AutoTokenizer, CLIPImageProcessor
-    cfg_cls = _llama_config_cls()
-    config = cfg_cls.from_pretrained(model_path)
-    config._attn_implementation = "sdpa"
-    tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
-    model = build_model(config)
+    exist on this platform and is not needed); the adapter is applied by ``peft`` when installed, else merged here.
+    The skeleton is built on the meta device (no 32 GB fp32 random init of an 8 B model on the host) and EVERY parameter
+    and buffer must then come from the checkpoint: a tensor no shard supplies raises instead of staying random."""
     import glob
 
     import safetensors.torch
-    shards = sorted(glob.glob(os.path.join(model_path, "*.safetensors")))
+    from transformers import AutoTokenizer, CLIPImageProcessor
+    model_dir = resolve_model_dir(model_path)
+    cfg_cls = _llama_config_cls()
+    config = cfg_cls.from_pretrained(model_dir)
+    config._attn_implementation = "sdpa"
+    tokenizer = AutoTokenizer.from_pretrained(model_dir, use_fast=False)
+    shards = sorted(glob.glob(os.path.join(model_dir, "*.safetensors")))
     if not shards:
-        raise FileNotFoundError(f"load_llava: no *.safetensors under {model_path!r} (download the checkpoint there first; "
+        raise FileNotFoundError(f"load_llava: no *.safetensors under {model_dir!r} (download the checkpoint there first; "
                                 f"this build does not fetch from the network)")
+    with torch.device("meta"):
+        model = build_model(config)
+    wanted = set(model.state_dict().keys())
+    loaded = set()
     for sh in shards:
-        res = model.load_state_dict(normalise_checkpoint_keys(safetensors.torch.load_file(sh), model), strict=False)
-        if res.unexpected_keys:
-            raise RuntimeError(f"load_llava: unexpected keys in {sh}: {res.unexpected_keys[:5]}")
+        sd = normalise_checkpoint_keys(safetensors.torch.load_file(sh), model)
+        extra = [k for k in sd if k not in wanted]
+        if extra:
+            raise RuntimeError(f"load_llava: unexpected keys in {sh}: {extra[:5]}")
+        model.load_state_dict({k: v.to(dtype) if v.is_floating_point() else v for k, v in sd.items()}, strict=False, assign=True)
+        loaded.update(sd.keys())
+    # buffers that are derived, not stored (rotary inv_freq, CLIP position_ids) are re-created below; everything else
+    # the checkpoint must hold
+    missing = sorted(k for k in wanted - loaded if not k.endswith(("inv_freq", "position_ids")))
+    if missing:
+        raise RuntimeError(f"load_llava: {len(missing)} tensors of the model are in no shard of {model_dir!r} and would stay "
+                           f"uninitialised, e.g. {missing[:5]} (vision tower / mm_projector / image_newline must be in the "
+                           f"checkpoint, as in lmms-lab/llama3-llava-next-8b)")
+    _materialise_derived_buffers(model)
     if adapter_path is not None:
         if not os.path.isdir(adapter_path):
             raise FileNotFoundError(f"load_llava: adapter directory {adapter_path!r} does not exist")
@@ -370,20 +401,51 @@ def load_llava(device="cuda", model_path=DEFAULT_MODEL, adapter_path=DEFAULT_ADA
     return tokenizer, model, image_processor
 
 
+def _materialise_derived_buffers(model):
+    """After a meta-device construction: re-create the buffers a checkpoint does not store (non-persistent ones) on the CPU."""
+    for mod in model.modules():
+        for name, buf in list(mod._buffers.items()):
+            if buf is None or not buf.is_meta:
+                continue
+            if name == "position_ids":
+                mod._buffers[name] = torch.arange(buf.shape[-1]).expand(buf.shape).clone()
+            elif name in ("inv_freq", "original_inv_freq"):
+                fn = getattr(mod, "rope_init_fn", None)
+                if fn is not None:
+                    inv, _ = fn(mod.config, "cpu")
+                else:
+                    base, dim = getattr(mod, "base", 10000.0), buf.shape[0] * 2
+                    inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+                mod._buffers[name] = inv.to(torch.float32)
+            else:
+                raise RuntimeError(f"load_llava: buffer {name!r} of {type(mod).__name__} is neither in the checkpoint nor derivable")
+
+
 def get_img_describe(image_tensor, image, model, tokenizer, prompt, conv_templates=conv_templates,
                      image_token_index=IMAGE_TOKEN_INDEX, conv_template="llava_llama_3", num_beams=1, temperature=0.2,
                      do_sample=True, max_new_tokens=512, device="cuda", seed=None):
-    """models/util.py:17-66 -> ``[caption]``.  ``seed`` (an addition): seeds the CPU and device generators right before
-    sampling, which makes the caption a function of (image, prompt, weights, seed)."""
+    """models/util.py:17-66 -> ``[caption]``.  ``seed`` (an addition) makes the caption a function of (image, prompt,
+    weights, seed): sampling then runs inside ``torch.random.fork_rng`` with the CPU and the model's device generator seeded
+    THERE, so the caller's generators -- which Stage 2 draws its noise from right afterwards, and in the reference live on
+    another device (infer.py:145-166: LLaVA on cuda:1) -- are exactly where they were, however many tokens were sampled.
+    ``seed=None`` samples from the current generator state without touching any seed."""
     if conv_template != "llava_llama_3":
         raise NotImplementedError("the pipeline's captioner is the Llama-3 LLaVA-NeXT (conv_template 'llava_llama_3')")
     system = getattr(conv_templates[conv_template], "system", LLAMA3_SYSTEM)
     text = llama3_prompt(tokenizer, prompt, system)
     input_ids = tokenizer_image_token(text, tokenizer, image_token_index, return_tensors="pt").unsqueeze(0).to(device)
-    if seed is not None:
-        torch.manual_seed(seed)
-    with torch.inference_mode():
-        out = model.generate(input_ids, images=image_tensor, image_sizes=[image.size], do_sample=do_sample,
-                             temperature=temperature, num_beams=num_beams, max_new_tokens=max_new_tokens,
-                             return_dict_in_generate=True, output_scores=True)
+
+    def run():
+        with torch.inference_mode():
+            return model.generate(input_ids, images=image_tensor, image_sizes=[image.size], do_sample=do_sample,
+                                  temperature=temperature, num_beams=num_beams, max_new_tokens=max_new_tokens,
+                                  return_dict_in_generate=True, output_scores=True)
+
+    if seed is None:
+        out = run()
+    else:
+        mdev = next(model.parameters()).device
+        with torch.random.fork_rng(devices=[mdev] if mdev.type == "cuda" else []):
+            torch.manual_seed(seed)
+            out = run()
     return [tokenizer.decode(out[0][0].cpu().tolist(), skip_special_tokens=True).lstrip()]

@@ -31,6 +31,7 @@ class SR_backbone(DiffusionEngine):
         self.p_p, self.n_p = p_p, n_p
         self.noise_source = "device"
         self.upscale, self.min_size = 1, 256
+        self._measure = None   # (stamp, max_steps) while bench.py measures (rsvld_amd.measure.hooks), else None
 
     def set_precision(self, ae_dtype, diffusion_dtype):
         """The reference fixes both in the constructor (SR_model.py:28-33); here they can also be switched on a loaded model.
@@ -143,9 +144,9 @@ class SR_backbone(DiffusionEngine):
         sp.restore_cfg, sp.s_churn, sp.s_noise = restoration_scale, s_churn, s_noise
         self.sampler = instantiate_from_config(self.sampler_config)
 
-        # measurement hooks (bench.py): ``_stamp(name)`` is called at every phase border, ``_max_steps`` truncates the
-        # sampler loop (the per-image fixed part still runs in full)
-        _stamp, _max_steps = kwargs.get("_stamp"), kwargs.get("_max_steps")
+        # measurement (bench.py, through rsvld_amd.measure.hooks -- not reachable from the call signature): ``stamp(name)``
+        # is called at every phase border, ``max_steps`` truncates the sampler loop (the per-image fixed part runs in full)
+        _stamp, _max_steps = self._measure if self._measure is not None else (None, None)
 
         def stamp(name):
             if _stamp is not None:
@@ -169,8 +170,10 @@ class SR_backbone(DiffusionEngine):
         sampler.noise_fn = self._randn_like   # per-step churn draws follow the same generator choice
         z, s_in, sigmas, num_sigmas, c_img, uc_img = sampler.init_loop(noised_z, c_img, uc=uc_img, num_steps=num_steps)
         x_center_cur = z_stage1
-        if N > 1 and img_threshold > 0:
-            # the cache decides PER IMAGE: one threshold per image; sampler.step then returns a list
+        if len(x) > 1 and num_samples == 1 and img_threshold > 0:
+            # a batch of independent images: the cache decides PER IMAGE, one threshold per image, and
+            # sampler.step returns a list.  ``num_samples > 1`` (ONE image repeated, :231-235) keeps the reference's
+            # behaviour instead: one decision over the whole stacked [2 * num_samples, ...] tensor (DFBCache.py:98-112)
             img_threshold = [float(img_threshold)] * N
         stamp("sampler_init")
         self.cache_trace = []

@@ -70,10 +70,10 @@ def run_sharded(process, n_images, rank, world):
     for its images i = rank, rank + world, ...; ONE all-gather of the finished uint8 images; -> ``[n_images, C, H, W]``
     in image order on every rank.  ``process`` must derive all of its randomness from ``i`` (per-image seeds), so the
     result does not depend on the number of ranks."""
+    if n_images < world:                             # checked on EVERY rank before any work or collective: all raise together
+        raise ValueError(f"run_sharded: {world} ranks for {n_images} images (a rank without an image cannot join the gather)")
     mine = [process(i) for i in shard_indices(n_images, rank, world)]
     per = -(-n_images // world)
-    if not mine:
-        raise ValueError("run_sharded: more ranks than images")
     while len(mine) < per:                           # equal shapes for the collective: pad with a copy, dropped by unshard
         mine.append(mine[-1])
     return unshard(gather_images(torch.stack(mine), world), n_images, world)

@@ -75,11 +75,22 @@ class ConcatTimestepEmbedderND(AbstractEmbModel):
         return emb.reshape(b, dims * self.outdim)
 
 
-class FrozenCLIPEmbedder(AbstractEmbModel):
-    """encoders/modules.py:436-499: HuggingFace CLIP text transformer; ``layer`` in {last, pooled, hidden}.
+def _freeze(module):
+    module.eval()
+    for q in module.parameters():
+        q.requires_grad_(False)
+    return module
 
-    ``version`` (or ``CKPT_PTH.SDXL_CLIP1_PATH`` when that module exists, as in the reference) names the checkpoint
-    for ``from_pretrained``; ``tokenizer`` / ``transformer`` may be passed in instead."""
+
+class FrozenCLIPEmbedder(AbstractEmbModel):
+    """CLIP-L text tower of the conditioner (yaml: ``layer: hidden, layer_idx: 11``; reference encoders/modules.py:436-499,
+    whose constructor signature and attribute names -- ``tokenizer``, ``transformer`` = checkpoint prefix -- are kept).
+
+    One forward of a HuggingFace ``CLIPTextModel`` on the 77-token padded prompt; what comes back is selected by a tiny
+    table instead of a branch ladder: ``last`` = final-norm states, ``pooled`` = the pooled vector as a length-1 sequence,
+    ``hidden`` = hidden state ``layer_idx`` of the ``[embeddings, block 1 .. block 12]`` list.  ``always_return_pooled``
+    appends the pooled vector.  ``version`` (or ``CKPT_PTH.SDXL_CLIP1_PATH`` when that module exists) names the checkpoint;
+    ``tokenizer`` / ``transformer`` may be injected (the offline parity tests do)."""
 
     LAYERS = ["last", "pooled", "hidden"]
 
@@ -88,62 +99,53 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
         super().__init__()
         if layer not in self.LAYERS:
             raise ValueError(f"layer must be one of {self.LAYERS}")
+        if layer == "hidden" and (layer_idx is None or abs(layer_idx) > 12):
+            raise ValueError("layer='hidden' needs 0 <= |layer_idx| <= 12")
         if tokenizer is None or transformer is None:
             from transformers import CLIPTextModel, CLIPTokenizer
             try:
-                from CKPT_PTH import SDXL_CLIP1_PATH
+                from CKPT_PTH import SDXL_CLIP1_PATH as src
             except ImportError:
-                SDXL_CLIP1_PATH = None
-            src = version if SDXL_CLIP1_PATH is None else SDXL_CLIP1_PATH
-            tokenizer = CLIPTokenizer.from_pretrained(src) if tokenizer is None else tokenizer
-            transformer = CLIPTextModel.from_pretrained(src) if transformer is None else transformer
-        self.tokenizer = tokenizer
-        self.transformer = transformer
-        self.device = device
-        self.max_length = max_length
+                src = version
+            tokenizer = tokenizer or CLIPTokenizer.from_pretrained(src)
+            transformer = transformer or CLIPTextModel.from_pretrained(src)
+        self.tokenizer, self.transformer = tokenizer, transformer
+        self.device, self.max_length = device, max_length
+        self.layer, self.layer_idx, self.return_pooled = layer, layer_idx, always_return_pooled
         if freeze:
             self.freeze()
-        self.layer = layer
-        self.layer_idx = layer_idx
-        self.return_pooled = always_return_pooled
-        if layer == "hidden":
-            if layer_idx is None or not 0 <= abs(layer_idx) <= 12:
-                raise ValueError("layer='hidden' needs 0 <= |layer_idx| <= 12")
 
     def freeze(self):
-        self.transformer = self.transformer.eval()
-        for param in self.parameters():
-            param.requires_grad = False
+        _freeze(self)
 
     @torch.no_grad()
     def forward(self, text):
-        enc = self.tokenizer(text, truncation=True, max_length=self.max_length, return_length=True,
-                             return_overflowing_tokens=False, padding="max_length", return_tensors="pt")
-        tokens = enc["input_ids"].to(self.device)
-        outputs = self.transformer(input_ids=tokens, output_hidden_states=self.layer == "hidden")
-        if self.layer == "last":
-            z = outputs.last_hidden_state
-        elif self.layer == "pooled":
-            z = outputs.pooler_output[:, None, :]
-        else:
-            z = outputs.hidden_states[self.layer_idx]
-        if self.return_pooled:
-            return z, outputs.pooler_output
-        return z
+        ids = self.tokenizer(text, padding="max_length", truncation=True, max_length=self.max_length,
+                             return_tensors="pt")["input_ids"].to(self.device)
+        res = self.transformer(input_ids=ids, output_hidden_states=(self.layer == "hidden"))
+        pick = {"last": lambda: res.last_hidden_state,
+                "pooled": lambda: res.pooler_output.unsqueeze(1),
+                "hidden": lambda: res.hidden_states[self.layer_idx]}
+        z = pick[self.layer]()
+        return (z, res.pooler_output) if self.return_pooled else z
 
-    def encode(self, text):
-        return self(text)
+    encode = forward
 
 
 class FrozenOpenCLIPEmbedder2(AbstractEmbModel):
-    """encoders/modules.py:502-612: OpenCLIP text transformer; ``layer`` in {last, penultimate}; with ``legacy=False``
-    and ``always_return_pooled=True`` (the yaml's setting) returns (hidden states of that layer WITHOUT ln_final --
-    only ``last`` passes through it for the pooling, :571-576 -- , pooled = ln_final(last)[eot] @ text_projection).
+    """OpenCLIP bigG text tower of the conditioner (yaml: ``layer: penultimate, always_return_pooled: True, legacy: False``;
+    reference encoders/modules.py:502-612, constructor signature and ``model`` = checkpoint prefix kept).
+
+    ``_states(tokens)`` walks the residual blocks ONCE and returns the pair (input of the last block, output of the last
+    block), batch-first.  The selected one is returned as it is -- NOT through ``ln_final``: only the pooled vector is
+    normalised, ``pooled = ln_final(last)[eot] @ text_projection`` with eot = the highest token id of a row (:571-585).
+    ``legacy=True`` (the reference's default, not the yaml's) returns ``ln_final`` of the selected state and has no pooled
+    output.
 
     ``model`` must expose open_clip's text-tower attributes: ``token_embedding``, ``positional_embedding``,
-    ``transformer.resblocks`` (called as ``r(x, attn_mask=...)`` on LND tensors), ``ln_final``, ``text_projection``,
-    ``attn_mask``.  Without ``model`` / ``tokenize`` the ``open_clip`` package builds them (the reference pins the
-    ``laion2b_s39b_b160k`` weights whatever ``version`` says, :524-528)."""
+    ``transformer.resblocks`` (called as ``r(x, attn_mask=...)`` on sequence-first tensors), ``ln_final``,
+    ``text_projection``, ``attn_mask``.  Without ``model`` / ``tokenize`` the ``open_clip`` package builds them (the
+    reference pins the ``laion2b_s39b_b160k`` weights whatever ``version`` says, :524-528)."""
 
     LAYERS = ["pooled", "last", "penultimate"]
 
@@ -152,6 +154,8 @@ class FrozenOpenCLIPEmbedder2(AbstractEmbModel):
         super().__init__()
         if layer not in self.LAYERS:
             raise ValueError(f"layer must be one of {self.LAYERS}")
+        if layer == "pooled":
+            raise NotImplementedError("layer='pooled' is listed but not implemented by the reference either (:545-546)")
         if model is None or tokenize is None:
             try:
                 import open_clip
@@ -159,68 +163,44 @@ class FrozenOpenCLIPEmbedder2(AbstractEmbModel):
                 raise ImportError("FrozenOpenCLIPEmbedder2 needs the open_clip package (or model= / tokenize= passed in); "
                                   "use PreparedConditioner with cached embeddings otherwise") from e
             if model is None:
-                model, _, _ = open_clip.create_model_and_transforms(arch, device=torch.device("cpu"), pretrained="laion2b_s39b_b160k")
+                model = open_clip.create_model_and_transforms(arch, device=torch.device("cpu"), pretrained="laion2b_s39b_b160k")[0]
                 del model.visual
-            tokenize = open_clip.tokenize if tokenize is None else tokenize
-        self.model = model
-        self.tokenize = tokenize
-        self.device = device
-        self.max_length = max_length
-        self.return_pooled = always_return_pooled
+            tokenize = tokenize or open_clip.tokenize
+        self.model, self.tokenize = model, tokenize
+        self.device, self.max_length = device, max_length
+        self.layer, self.legacy, self.return_pooled = layer, legacy, always_return_pooled
+        self.layer_idx = {"last": 0, "penultimate": 1}[layer]
         if freeze:
             self.freeze()
-        self.layer = layer
-        if layer == "last":
-            self.layer_idx = 0
-        elif layer == "penultimate":
-            self.layer_idx = 1
-        else:
-            raise NotImplementedError()
-        self.legacy = legacy
 
     def freeze(self):
-        self.model = self.model.eval()
-        for param in self.parameters():
-            param.requires_grad = False
+        _freeze(self)
+
+    def _states(self, tokens):
+        """-> (penultimate, last), each ``[b, 77, width]``"""
+        tower = self.model
+        h = (tower.token_embedding(tokens) + tower.positional_embedding).transpose(0, 1)      # sequence-first for resblocks
+        *body, head = list(tower.transformer.resblocks)
+        for blk in body:
+            h = blk(h, attn_mask=tower.attn_mask)
+        return h.transpose(0, 1), head(h, attn_mask=tower.attn_mask).transpose(0, 1)
 
     @torch.no_grad()
     def forward(self, text):
-        tokens = self.tokenize(text)
-        z = self.encode_with_transformer(tokens.to(self.device))
-        if not self.return_pooled and self.legacy:
-            return z
-        if self.return_pooled:
-            if self.legacy:
-                raise ValueError("always_return_pooled needs legacy=False")
-            return z[self.layer], z["pooled"]
-        return z[self.layer]
-
-    def encode_with_transformer(self, text):
-        x = self.model.token_embedding(text)          # [b, n_ctx, width]
-        x = x + self.model.positional_embedding
-        x = x.permute(1, 0, 2)                        # NLD -> LND
-        x = self.text_transformer_forward(x, attn_mask=self.model.attn_mask)
+        tokens = self.tokenize(text).to(self.device)
+        penultimate, last = self._states(tokens)
+        z = penultimate if self.layer == "penultimate" else last
         if self.legacy:
-            return self.model.ln_final(x[self.layer])
-        o = self.model.ln_final(x["last"])
-        x["pooled"] = self.pool(o, text)
-        return x
+            if self.return_pooled:
+                raise ValueError("always_return_pooled needs legacy=False")
+            return self.model.ln_final(z)
+        if not self.return_pooled:
+            return z
+        eot = tokens.argmax(dim=-1)
+        rows = torch.arange(tokens.shape[0], device=tokens.device)
+        return z, self.model.ln_final(last)[rows, eot] @ self.model.text_projection
 
-    def pool(self, x, text):   # features at the eot token (the highest id of each sequence)
-        return x[torch.arange(x.shape[0]), text.argmax(dim=-1)] @ self.model.text_projection
-
-    def text_transformer_forward(self, x, attn_mask=None):
-        outputs = {}
-        blocks = self.model.transformer.resblocks
-        for i, r in enumerate(blocks):
-            if i == len(blocks) - 1:
-                outputs["penultimate"] = x.permute(1, 0, 2)   # LND -> NLD
-            x = r(x, attn_mask=attn_mask)
-        outputs["last"] = x.permute(1, 0, 2)
-        return outputs
-
-    def encode(self, text):
-        return self(text)
+    encode = forward
 
 
 class GeneralConditioner(nn.Module):

@@ -31,7 +31,10 @@ def test_config1_stage1_512_batch4_vs_oracle(cuda):
     noises = [torch.randn(4, 3, 512, 512, generator=torch.Generator().manual_seed(50 + i)) for i in range(3)]
     it = iter(noises)
     net._randn = lambda shape, device: next(it).to(device)            # x_T, then one draw per step with t > 0
-    sr = net.super_resolution(cond.to(cuda), continous=True, _max_steps=2)
+    from rsvld_amd import measure
+    net.batch_invariant = False      # this workload's launch plans are tuned on the whole batch
+    with measure.hooks(net, max_steps=2):
+        sr = net.super_resolution(cond.to(cuda), continous=True)
     got = sr[-4:].cpu()
     assert got.shape == (4, 3, 512, 512) and bool(torch.isfinite(got).all())
     # the oracle on image 2 alone, same draws (2 steps at 512^2 = 2 x 1.1 TFLOP on the host cores)
@@ -45,15 +48,10 @@ def test_config1_stage1_512_batch4_vs_oracle(cuda):
     assert err < 1e-3                                                     # measured ~2e-4 (one step: 1.4e-4)
     # per-image identity: image 2 sampled alone
     it = iter([n[2:3] for n in noises])
-    alone = net.super_resolution(cond[2:3].to(cuda), continous=True, _max_steps=2)[-1:].cpu()
+    with measure.hooks(net, max_steps=2):
+        alone = net.super_resolution(cond[2:3].to(cuda), continous=True)[-1:].cpu()
     print("configs[1]: image 2 alone vs inside the batch of 4: max|d| =", float((alone - got[2:3]).abs().max()))
     assert float((alone - got[2:3]).abs().max()) < 2e-3                   # Stage 1 plans launches on the whole batch (not bit-identical by design)
-
-
-@pytest.fixture(scope="module")
-def full_model(cuda):
-    import bench
-    return bench.build_stage2(cuda, True)                                 # full juggernautXL sizes, tiled VAE 512 / 64
 
 
 def test_config2_stage2_2048_batch8_cache_is_per_image(cuda, full_model):
@@ -61,7 +59,8 @@ def test_config2_stage2_2048_batch8_cache_is_per_image(cuda, full_model):
     m = full_model
     B, side = 8, 2048
     img = torch.cat([bench.synthetic_image((1, 3, side, side), seed=1234 + i, smooth=4) for i in range(B)])
-    kw = dict(bench.S2_KW, img_threshold=0.3, num_steps=50, _max_steps=3)
+    from rsvld_amd import measure
+    kw = dict(bench.S2_KW, img_threshold=0.3, num_steps=50)
     g = torch.Generator().manual_seed(7)
     post, xt = torch.randn(B, 4, 256, 256, generator=g), torch.randn(B, 4, 256, 256, generator=g)
     steps = [torch.randn(B, 4, 256, 256, generator=g) for _ in range(3)]
@@ -71,7 +70,8 @@ def test_config2_stage2_2048_batch8_cache_is_per_image(cuda, full_model):
         m._posterior_noise = lambda shape: post[sl]
         m._randn_like = lambda t: next(draws)[sl].to(t.device)
         try:
-            out = m.just_sampling(img[sl].to(cuda), [""] * len(range(B)[sl]), **kw)
+            with measure.hooks(m, max_steps=3):
+                out = m.just_sampling(img[sl].to(cuda), [""] * len(range(B)[sl]), **kw)
             return out.cpu(), [list(s) for s in m.cache_trace]
         finally:
             del m._posterior_noise, m._randn_like

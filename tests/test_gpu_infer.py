@@ -83,6 +83,39 @@ def test_live_llava_caption_on_device(cuda, tmp_path):
     assert pipe.run_stage2_captioning(img) == "a river delta"
 
 
+@pytest.mark.parametrize("n", [0, 1, 2])
+def test_llava_next_on_device_vs_reference_golden(cuda, tmp_path, golden_dir, n):
+    """The caption model ON THE DEVICE (stock PyTorch-ROCm, SDPA) against the vectors the reference's vendored model produced
+    (tests/golden/llava_next.npz): spliced input embeddings and next-token logits in fp32 on the device, and the greedy token
+    ids -- the same pins tests/test_llava_next.py holds on the CPU, so the device path is compared with the reference, not
+    with itself."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import llava_common as C
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModel
+    from rsvld_amd import llava_next as LN
+    z = np.load(os.path.join(golden_dir, "llava_next.npz"))
+    tower_dir = C.save_tiny_clip(str(tmp_path / "clip"))
+    cfg = LN._llama_config_cls()(**C.LLAMA, **C.MM, mm_vision_tower=tower_dir)
+    cfg._attn_implementation = "sdpa"
+    model = LN.build_model(cfg, clip=CLIPVisionModel(CLIPVisionConfig(**C.VISION))).eval()
+    C.name_seeded_state(model, C.WEIGHT_SEED)
+    model.to(device=cuda, dtype=torch.float32)
+    proc = CLIPImageProcessor.from_pretrained(tower_dir)
+    img = C.test_image(C.IMAGE_SIZES[n], 5 + n)
+    images = [x.to(cuda) for x in LN.process_images([img], proc, model.config)]
+    ids = torch.tensor(z["input_ids"]).to(cuda)
+    with torch.no_grad():
+        emb = model.multimodal_embeds(ids, images, [img.size])
+        e_emb = float((emb.cpu() - torch.tensor(z[f"i{n}.embeds"])).abs().max())
+        logits = model(inputs_embeds=emb).logits[0, -1]
+        e_log = float((logits.cpu() - torch.tensor(z[f"i{n}.logits"])).abs().max())
+        greedy = model.generate(ids, images=images, image_sizes=[img.size], do_sample=False, num_beams=1, max_new_tokens=16,
+                                return_dict_in_generate=True, output_scores=True)[0][0]
+    print(f"LLaVA-NeXT on the device, image {n}: embeddings max|d| = {e_emb:.2e}, logits max|d| = {e_log:.2e}")
+    assert e_emb < 2e-5 and e_log < 5e-4
+    assert greedy.cpu().tolist() == z[f"i{n}.greedy"].tolist()
+
+
 def test_pipeline_with_live_caption_end_to_end(cuda, tmp_path):
     """BASELINE configs[3] in miniature: Stage 1 -> uint8 hand-off -> LIVE LLaVA-NeXT caption (tiny seeded model on the device)
     -> Stage 2 with that caption -> PNG, through SuperResolutionPipeline.process() exactly as the CLI runs it."""

@@ -155,6 +155,52 @@ def _pipeline_config1(net, cuda, golden_dir, prec):
     assert float((lsb == 0).mean()) >= 0.98 and int(lsb.max()) <= 1
 
 
+@pytest.mark.parametrize("prec", ["fp16", "fp32"])
+def test_pipeline_t50_vs_reference_golden(sr3, cuda, golden_dir, prec):
+    """The step count the metric is quoted on: the config-1 image through T = 50 ancestral steps (torch seed 0, CPU noise
+    order) against the reference's own 50-step run (tests/golden/gen_steps50_golden.py): the final frame, the 11 kept
+    frames and x_t after t = 40 / 25 / 10, i.e. how the 16-bit error grows along ``x_(t-1) = mean(x_t, eps) + sigma z``
+    (diffusion.py:170-175).  Bounds = 2 x measured."""
+    from oracle import sr3_oracle as O
+    net, _ = sr3
+    net.denoise_fn.set_compute_dtype(prec)
+    probes, orig = {}, net.p_sample
+
+    def spy(x, t, *a, **k):
+        out = orig(x, t, *a, **k)
+        if t in (40, 25, 10):
+            probes[t] = out.cpu()
+        return out
+
+    try:
+        net.set_new_noise_schedule(dict(schedule="linear", n_timestep=50, linear_start=1e-6, linear_end=1e-2), cuda)
+        net.noise_source = "cpu"
+        z = np.load(os.path.join(golden_dir, "sr3_pipeline_t50.npz"))
+        cond = torch.tensor(np.load(os.path.join(golden_dir, "sr3_pipeline_c1.npz"))["cond"])
+        net.p_sample = spy
+        torch.manual_seed(int(z["torch_seed"]))
+        sr = net.super_resolution(cond.to(cuda), continous=True)
+    finally:
+        net.__dict__.pop("p_sample", None)
+        net.denoise_fn.set_compute_dtype("fp16")
+    assert sr.shape == (11, 3, 256, 256)
+    fm = float((sr.mean(dim=(1, 2, 3)).cpu() - torch.tensor(z["frames_mean"])).abs().max())
+    drift = {t: _err(probes[t], z[f"x_after_t{t}"]) for t in (40, 25, 10)}
+    final, want = sr[-1:].cpu(), torch.tensor(z["final"])
+    d = (final - want).abs()
+    lsb = np.abs(O.tensor2img_u8(final).astype(int) - O.tensor2img_u8(want).astype(int))
+    print(f"Stage 1, T = 50 [{prec}]: max|d| after t=40/25/10 = {drift[40]:.3e} / {drift[25]:.3e} / {drift[10]:.3e}; final max|d| = "
+          f"{float(d.max()):.3e}, mean|d| = {float(d.mean()):.3e}; kept-frame means {fm:.3e}; uint8 equal = "
+          f"{float((lsb == 0).mean()):.4f}, max LSB diff = {int(lsb.max())}")
+    if prec == "fp32":
+        assert float(d.max()) < 1e-4 and float(d.mean()) < 1e-5 and int(lsb.max()) <= 1
+        return
+    assert float(d.max()) < S1_T50_MAX and float(d.mean()) < S1_T50_MEAN and int(lsb.max()) <= S1_T50_LSB
+
+
+S1_T50_MAX, S1_T50_MEAN, S1_T50_LSB = 4e-3, 4e-4, 1      # fp16, 50 steps (10 steps: 9.9e-4 / 1.0e-4)
+
+
 def test_unet_forward_vs_oracle_fresh_input(sr3, cuda):
     """Same check against the travelling CPU oracle on an input no fixture holds (batch 2, 48x80)."""
     from oracle import seeded, sr3_oracle as O

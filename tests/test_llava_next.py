@@ -99,5 +99,55 @@ def test_merge_lora_equals_explicit_adapter(setup, tmp_path):
 
 def test_load_llava_fails_loudly_without_a_checkpoint(setup, tmp_path):
     LN = setup[0]
-    with pytest.raises(Exception):
+    with pytest.raises(FileNotFoundError, match="--no_llava"):      # not a directory, not in the local hub cache
         LN.load_llava(device="cpu", model_path=str(tmp_path / "nothing-here"))
+
+
+def _save_checkpoint(model, tok, cfg, path, drop=()):
+    import safetensors.torch
+    os.makedirs(path, exist_ok=True)
+    cfg.save_pretrained(path)
+    tok.save_pretrained(path)
+    sd = {k: v.detach().clone().contiguous() for k, v in model.state_dict().items() if not any(d in k for d in drop)}
+    keys = sorted(sd)
+    safetensors.torch.save_file({k: sd[k] for k in keys[: len(keys) // 2]}, os.path.join(path, "model-00001-of-00002.safetensors"))
+    safetensors.torch.save_file({k: sd[k] for k in keys[len(keys) // 2:]}, os.path.join(path, "model-00002-of-00002.safetensors"))
+    return path
+
+
+def test_load_llava_from_shards_reproduces_the_model_and_rejects_incomplete_checkpoints(setup, tmp_path):
+    """load_llava builds the skeleton on the meta device and assigns every tensor from the shards: the loaded model must give
+    the golden logits, and a checkpoint that lacks image_newline / the projector / a tower weight must raise instead of
+    leaving that tensor at a random value."""
+    LN, model, tok, proc, z = setup
+    good = _save_checkpoint(model, tok, model.config, str(tmp_path / "good"))
+    tok2, loaded, _ = LN.load_llava(device="cpu", model_path=good, adapter_path=None, dtype=torch.float32)
+    img = C.test_image(C.IMAGE_SIZES[0], 5)
+    px = LN.process_images([img], proc, loaded.config)
+    with torch.no_grad():
+        emb = loaded.multimodal_embeds(torch.tensor(z["input_ids"]), [x for x in px], [img.size])
+        logits = loaded(inputs_embeds=emb).logits[0, -1]
+    assert float((logits - torch.tensor(z["i0.logits"])).abs().max()) < 1e-4
+    assert not any(p_.is_meta for p_ in loaded.parameters()) and not any(b.is_meta for b in loaded.buffers())
+    for drop in ("image_newline", "mm_projector.2", "vision_tower.vision_tower"):
+        bad = _save_checkpoint(model, tok, model.config, str(tmp_path / ("bad_" + drop.replace(".", "_"))), drop=(drop,))
+        with pytest.raises(RuntimeError, match="in no shard"):
+            LN.load_llava(device="cpu", model_path=bad, adapter_path=None, dtype=torch.float32)
+
+
+def test_caption_sampling_leaves_the_callers_generator_alone(setup):
+    """Stage 2 draws its noise right after the caption pass: the seeded sampling runs in a forked generator, so the
+    caller's stream is where it was however many tokens were sampled; seed=None does not reseed anything."""
+    LN, model, tok, proc, _ = setup
+    img = C.test_image(C.IMAGE_SIZES[0], 5)
+    images = [x for x in LN.process_images([img], proc, model.config)]
+    torch.manual_seed(123)
+    want = torch.randn(4)
+    torch.manual_seed(123)
+    LN.get_img_describe(images, img, model, tok, C.QUESTION, max_new_tokens=8, device="cpu", seed=3)
+    assert torch.equal(torch.randn(4), want)
+    torch.manual_seed(5)
+    a = LN.get_img_describe(images, img, model, tok, C.QUESTION, max_new_tokens=8, device="cpu", seed=None)
+    torch.manual_seed(5)
+    b = LN.get_img_describe(images, img, model, tok, C.QUESTION, max_new_tokens=8, device="cpu", seed=None)
+    assert a == b

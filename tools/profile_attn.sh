@@ -11,6 +11,10 @@ export TMPDIR=/tmp
 out=$R/gpurun_out
 log=$out/${tag}_attn_ablation.log
 : > $log
+if ! ls tools/ablate/librsvld_a5b_abl*.so tools/ablate/librsvld_a6b_abl*.so > /dev/null 2>&1; then
+  echo "no ablation library under tools/ablate/ (build them first: MACRO=A5B_ABL LIST='1 4 5' tools/ablate_attn.sh; MACRO=A6B_ABL LIST='1 2 8 11' tools/ablate_attn.sh)" >&2
+  exit 1
+fi
 echo "== shipped library" >> $log
 HEADLINE=1 python3 tools/bench_attn.py >> $log 2>&1
 for lib in $(ls tools/ablate/librsvld_a5b_abl*.so 2>/dev/null); do
