@@ -500,6 +500,35 @@ constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
 #ifndef A6B_OCC4
 #define A6B_OCC4 1
 #endif
+// A6B_BIAS = 1 (default, round 3): the kernel is vector-issue bound (10.8 VALU per MFMA: profiles/r02_attn_pmc.json), so the
+// per-score ``fma(s, scale, -m)`` in front of every exponential moves to the matrix pipe:
+//   * Q is multiplied by scale * log2(e) once, when its fragments are loaded (one extra 16-bit rounding of Q);
+//   * the running maximum enters S as a rank-1 term: one extra 16-deep MFMA step per 32-key half whose A operand is a ones
+//     column (k-slot 0) and whose B operand holds -m of the lane's query in that slot, so the accumulator comes out as
+//     s' = scale * log2(e) * q.k - m and the softmax is a bare exp2.  m is therefore kept representable in the operand
+//     type (it only has to be the SAME number in P, in the row sum and in the rescale of O, not the exact maximum);
+//   * the maximum the bias carries is the one known BEFORE the tile (deferred maximum, T13): only when a row's scores exceed
+//     it by more than 2^8 (and on the first tile) the tile pays a subtract per score and O / l are rescaled.
+// Per 64-key tile and wave: -32 v_fma, +2 MFMAs, +8 moves.  The half-wave exchange of the row maximum is a
+// v_permlane32_swap instead of a ds_bpermute round trip.  -DA6B_BIAS=0 builds the round-2 form for A/B runs.
+#ifndef A6B_BIAS
+#define A6B_BIAS 1
+#endif
+// With the fma gone the exponentials' results are adjacent, and plain -O3 SLP-packs the row-sum adds into v_pk_add_f32,
+// which issues in two passes beside MFMAs (MI355X_MICROARCH.md "price of one filler"; round 2 measured the packed forms at
+// -1.6 .. -2.5 %): A6B_NOPK = 1 keeps them single v_add_f32 through an asm helper.
+#ifndef A6B_NOPK
+#define A6B_NOPK 1
+#endif
+__device__ __forceinline__ float a6b_add(float a, float b) {
+#if A6B_NOPK
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a + b;
+#endif
+}
 
 // NW = waves per workgroup: 4 (128 query rows) or 8 (256 query rows).  The 64-key K / V tile is filled once per workgroup,
 // so with 8 waves every wave issues ONE LDS-DMA piece per tensor per tile instead of two and there is one barrier per 256
@@ -579,13 +608,22 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         u32x4 v = {0u, 0u, 0u, 0u};
         if (qrow < p.Nq) v = *(const u32x4*)(Qb + (int64_t)qrow * p.q_ts + ks * 16 + lh * 8);
         qf[ks] = __builtin_bit_cast(v8, v);
+        if (A6B_BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (T)((float)qf[ks][e] * p.scale_log2e);
+        }
     }
     f32x16 oacc[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = A6B_BIAS ? 0.f : -INFINITY, l_run = 0.f;   // A6B_BIAS: the maximum the bias step subtracts (0 before the first tile)
+    uint32_t one_lo;   // A operand of the bias step, register 0: 1.0 in element 0 of lanes 0..31 (k-slot 0), zero elsewhere
+    {
+        T pair[2] = {lh == 0 ? (T)1.f : (T)0.f, (T)0.f};
+        __builtin_memcpy(&one_lo, pair, 4);
+    }
 
     // per-lane read offsets.  K (ds_read_b128): row kt*32 + l31, chunk 2ks + lh, swizzled by ((row>>1)&7) [row & 15 = l31 & 15]
     int koff[4];
@@ -630,6 +668,19 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
                 for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const v8*)(Ks + kt * 4096 + koff[ks]);
         }
         f32x16 sacc[2];
+        // bias step operands (transient: built per tile so that no register is held across the PV phase, where the kernel
+        // sits at its 128-register limit).  A: 1 in k-slot 0 (lanes 0..31, element 0), B: -m of the lane's query there.
+        v8 onesf, biasf;
+        if (A6B_BIAS) {
+            uint32_t zr;                                  // produced HERE by an asm move: a C++ zero would be hoisted out of
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zr));   // the loop and held in registers for the whole kernel
+            T pair[2] = {(T)(-m_run), (T)0.f};            // exact: m_run is kept representable in T
+            uint32_t b0;
+            __builtin_memcpy(&b0, pair, 4);
+            const u32x4 av = {one_lo, zr, zr, zr}, bv = {b0, zr, zr, zr};
+            onesf = __builtin_bit_cast(v8, av);
+            biasf = __builtin_bit_cast(v8, bv);
+        }
         asm volatile("s_setprio 1");   // the wave that feeds the matrix pipe issues ahead of its SIMD's softmax waves (+0.6 %)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -637,7 +688,24 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = (A6B_ABL & 32) ? abl_frag : *(const v8*)(Ks + kt * 4096 + koff[ks]);
             }
-            if constexpr (__is_same(T, f16)) {
+            if constexpr (A6B_BIAS != 0) {
+                if constexpr (__is_same(T, f16)) {
+                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sacc[kt]) : "v"(onesf), "v"(biasf));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][0]), "v"(qf[0]));
+                } else {
+                    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sacc[kt]) : "v"(onesf), "v"(biasf));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][0]), "v"(qf[0]));
+                }
+                if constexpr (__is_same(T, f16)) {
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][1]), "v"(qf[1]));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][2]), "v"(qf[2]));
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][3]), "v"(qf[3]));
+                } else {
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][1]), "v"(qf[1]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][2]), "v"(qf[2]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][3]), "v"(qf[3]));
+                }
+            } else if constexpr (__is_same(T, f16)) {
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sacc[kt]) : "v"(kf[kt][0]), "v"(qf[0]));
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][1]), "v"(qf[1]));
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sacc[kt]) : "v"(kf[kt][2]), "v"(qf[2]));
@@ -692,31 +760,70 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
                 for (int r = 0; r < 16; ++r) m4[r >> 2] = fmaxf(m4[r >> 2], sacc[kt][r]);
             mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;   // scale > 0: max commutes with it
-        const bool need = mx > m_run + 8.0f;                   // deferred max (T13); true on the first tile
         float alpha = 1.0f;
-        if (need) {
-            alpha = __builtin_amdgcn_exp2f(m_run - mx);
-            m_run = mx;
-        }
-        const float nm = -m_run;
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_fmaf(sacc[kt][r], p.scale_log2e, nm);
-                if (!(A6B_ABL & 1)) pv = __builtin_amdgcn_exp2f(pv);
-                sacc[kt][r] = pv;
-                if (!(A6B_ABL & 8) || r == 0) r4[r >> 2] += pv;
+        bool need;
+        if (A6B_BIAS) {
+            // the other half-wave's maximum of the same query: one v_permlane32_swap (lanes 32..63 of a <-> lanes 0..31 of b)
+            {
+                const uint32_t mb = __builtin_bit_cast(uint32_t, mx);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
             }
-        const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
-        l_run = l_run * alpha + rs;
-        if (__any(need)) {
+            // mx = (maximum of the tile's scores) - m_run, in log2 units.  Deferred maximum (T13): the bias keeps m_run unless
+            // the scores outgrow it by 2^8; the first tile always takes the branch (m_run = 0 there is not a maximum).
+            need = (t == 0) || (mx > A5_DEFER_LOG2);
+            if (__any(need)) {
+                const float m_new = need ? (float)(T)(m_run + mx) : m_run;   // representable in T: next tile's bias operand
+                const float delta = m_new - m_run;                            // exact (both operands are T values); 0 where !need
+                m_run = m_new;
+                // first tile: O and l are still zero and delta may be hugely NEGATIVE (scores far below the initial 0):
+                // exp2(-delta) would be +inf and 0 * inf a NaN -- there is nothing to rescale
+                alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) sacc[kt][r] -= delta;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pv = sacc[kt][r];
+                    if (!(A6B_ABL & 1)) pv = __builtin_amdgcn_exp2f(pv);
+                    sacc[kt][r] = pv;
+                    if (!(A6B_ABL & 8) || r == 0) r4[r >> 2] = a6b_add(r4[r >> 2], pv);
+                }
+            l_run = l_run * alpha + a6b_add(a6b_add(r4[0], r4[1]), a6b_add(r4[2], r4[3]));
+        } else {
+            mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;   // scale > 0: max commutes with it
+            need = mx > m_run + 8.0f;                              // deferred max (T13); true on the first tile
+            if (need) {
+                alpha = __builtin_amdgcn_exp2f(m_run - mx);
+                m_run = mx;
+            }
+            const float nm = -m_run;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pv = __builtin_fmaf(sacc[kt][r], p.scale_log2e, nm);
+                    if (!(A6B_ABL & 1)) pv = __builtin_amdgcn_exp2f(pv);
+                    sacc[kt][r] = pv;
+                    if (!(A6B_ABL & 8) || r == 0) r4[r >> 2] += pv;
+                }
+            const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+            l_run = l_run * alpha + rs;
+            if (__any(need)) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
         }
         v8 pf[4];
 #pragma unroll

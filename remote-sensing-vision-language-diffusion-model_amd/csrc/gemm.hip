@@ -40,6 +40,9 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_ABL
 #define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue, 4 three K steps
 #endif
+#ifndef G_STAGGER
+#define G_STAGGER 0   // experiment: first-round workgroups on every other CU start half a K loop late (s_sleep units per K tile),
+#endif                // so that the CUs' output bursts stop coinciding; 0 = off
 constexpr int G_NST = 4;
 constexpr int G_RING = G_NST * G_STAGE;
 constexpr int G_SMEM = G_RING + 1024;   // + the tile's 256 bias values (fp32), fetched once while the ring fills
@@ -73,6 +76,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int m0 = tile_m * 256, n0 = tile_n * 256;
     const int nk = (G_ABL & 4) ? 3 : (p.K >> 5);   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
     const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T);
+    if (G_STAGGER > 0) {
+        const int lid = blockIdx.x + blockIdx.y * gridDim.x;
+        if (lid < 256 && ((lid >> 3) & 1))
+            for (int i = 0; i < nk; ++i) __builtin_amdgcn_s_sleep(G_STAGGER);
+    }
 
     // ---- DMA roles: wave w fills rows 32w .. 32w+31 of X and of W: two wave-instructions of 16 rows x 64 B each.
     // lane -> (row = lane>>2, position = lane&3) holds source chunk position ^ ((row>>2)&3); rows past the end of the

@@ -293,6 +293,112 @@ def build_model(config, clip=None):
     return LlavaNextLlama(config)
 
 
+class FastDecoder:
+    """Token loop of the caption pass over a static key/value cache, with the decode step replayed from a hipGraph.
+
+    ``transformers``' ``generate`` launches ~500 kernels per token from Python (8 B Llama: 32 layers) and is host-bound at
+    20-30 ms per token; a caption is 256 tokens.  This class runs the SAME module weights (``model.model.layers[i].self_attn
+    .{q,k,v,o}_proj``, ``.mlp.{gate,up,down}_proj``, the two RMSNorms, ``model.model.rotary_emb``, ``lm_head``) through a
+    functional forward written out in stock torch ops -- RMSNorm, rotary embedding (half-split form), grouped-query SDPA
+    over a pre-allocated ``[1, kv_heads, max_len, head_dim]`` cache, SwiGLU -- so that one decode step has static shapes
+    and addresses and can be captured once (``torch.cuda.CUDAGraph`` = hipGraph) and replayed per token.  Sampling follows
+    ``generate`` exactly (temperature, then one ``torch.multinomial`` per step; greedy = argmax), which is what
+    tests/test_llava_next.py pins token for token against the reference's generations.  On the CPU (tests) the same code
+    runs eagerly."""
+
+    def __init__(self, model, max_len):
+        cfg = model.config
+        self.model, self.max_len = model, int(max_len)
+        self.layers = list(model.model.layers)
+        self.n_q, self.n_kv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        p = next(model.parameters())
+        self.dev, self.dt = p.device, p.dtype
+        shape = (1, self.n_kv, self.max_len, self.hd)
+        self.k = [torch.zeros(shape, device=self.dev, dtype=self.dt) for _ in self.layers]
+        self.v = [torch.zeros(shape, device=self.dev, dtype=self.dt) for _ in self.layers]
+        self.cols = torch.arange(self.max_len, device=self.dev)
+        self._graph = None
+
+    @staticmethod
+    def _rms(x, norm):
+        v = x.float()
+        v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + norm.variance_epsilon)
+        return norm.weight * v.to(x.dtype)
+
+    @staticmethod
+    def _rope(x, cos, sin):
+        h = x.shape[-1] // 2
+        return x * cos + torch.cat((-x[..., h:], x[..., :h]), dim=-1) * sin
+
+    def forward(self, embeds, pos):
+        """``embeds [1, T, H]`` at absolute positions ``pos [T]`` (long, on the device) -> logits of the LAST position
+        ``[1, vocab]``; writes the keys / values of these positions into the cache."""
+        m = self.model.model
+        T = embeds.shape[1]
+        cos, sin = m.rotary_emb(embeds, pos[None])
+        cos, sin = cos[:, None], sin[:, None]                          # [1, 1, T, hd]
+        mask = (self.cols[None, :] <= pos[:, None])[None, None]        # [1, 1, T, max_len]: causal over the filled prefix
+        h = embeds
+        for i, layer in enumerate(self.layers):
+            at = layer.self_attn
+            x = self._rms(h, layer.input_layernorm)
+            q = at.q_proj(x).view(1, T, self.n_q, self.hd).transpose(1, 2)
+            k = at.k_proj(x).view(1, T, self.n_kv, self.hd).transpose(1, 2)
+            v = at.v_proj(x).view(1, T, self.n_kv, self.hd).transpose(1, 2)
+            q, k = self._rope(q, cos, sin), self._rope(k, cos, sin)
+            self.k[i].index_copy_(2, pos, k)
+            self.v[i].index_copy_(2, pos, v)
+            o = torch.nn.functional.scaled_dot_product_attention(q, self.k[i], self.v[i], attn_mask=mask,
+                                                                 enable_gqa=self.n_q != self.n_kv)
+            h = h + at.o_proj(o.transpose(1, 2).reshape(1, T, self.n_q * self.hd))
+            x = self._rms(h, layer.post_attention_layernorm)
+            mlp = layer.mlp
+            h = h + mlp.down_proj(torch.nn.functional.silu(mlp.gate_proj(x)) * mlp.up_proj(x))
+        return self.model.lm_head(self._rms(h[:, -1], m.norm))
+
+    def _pick(self, logits, do_sample, temperature):
+        if not do_sample:
+            return logits.argmax(-1)
+        return torch.multinomial(torch.softmax(logits.float() / temperature, dim=-1), 1)[:, 0]
+
+    @torch.no_grad()
+    def generate(self, inputs_embeds, max_new_tokens, do_sample=False, temperature=1.0, eos_token_id=None, use_graph=None):
+        """-> ``[n]`` generated token ids (n <= max_new_tokens; stops after an ``eos_token_id``, which is included)."""
+        T0 = inputs_embeds.shape[1]
+        if T0 + max_new_tokens > self.max_len:
+            raise ValueError(f"FastDecoder: prompt {T0} + {max_new_tokens} new tokens exceed the cache ({self.max_len})")
+        use_graph = (self.dev.type == "cuda") if use_graph is None else use_graph
+        eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+        embed = self.model.model.embed_tokens
+        logits = self.forward(inputs_embeds.to(self.dt), torch.arange(T0, device=self.dev))
+        tok = self._pick(logits, do_sample, temperature)
+        out = [tok]
+        if use_graph and self._graph is None:
+            self._tok, self._pos = tok.clone(), torch.tensor([T0], device=self.dev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                              # warm-up off the capture stream (allocator, lazy init);
+                self.forward(embed(self._tok)[None], self._pos)        # it rewrites cache slot T0 with the same values
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._logits = self.forward(embed(self._tok)[None], self._pos)
+        for n in range(1, max_new_tokens):
+            if eos and int(tok) in eos:
+                break
+            if use_graph:
+                self._tok.copy_(tok)
+                self._pos.fill_(T0 + n - 1)
+                self._graph.replay()
+                logits = self._logits
+            else:
+                logits = self.forward(embed(tok)[None], torch.tensor([T0 + n - 1], device=self.dev))
+            tok = self._pick(logits, do_sample, temperature)
+            out.append(tok)
+        return torch.cat(out)
+
+
 def normalise_checkpoint_keys(state_dict, model):
     """Checkpoints written by transformers 4.x name the CLIP weights ``...vision_tower.vision_tower.vision_model.*``;
     transformers 5 modules drop the ``vision_model.`` level (and vice versa).  Rename towards what ``model`` has."""
@@ -401,11 +507,12 @@ def load_llava(device="cuda", model_path=DEFAULT_MODEL, adapter_path=DEFAULT_ADA
     return tokenizer, model, image_processor
 
 
-def _materialise_derived_buffers(model):
-    """After a meta-device construction: re-create the buffers a checkpoint does not store (non-persistent ones) on the CPU."""
+def _materialise_derived_buffers(model, force=False):
+    """After a meta-device construction: re-create the buffers a checkpoint does not store (non-persistent ones) on the CPU.
+    ``force``: re-create them even when they are not on the meta device (after ``to_empty`` they hold garbage)."""
     for mod in model.modules():
         for name, buf in list(mod._buffers.items()):
-            if buf is None or not buf.is_meta:
+            if buf is None or not (buf.is_meta or (force and name in ("position_ids", "inv_freq", "original_inv_freq"))):
                 continue
             if name == "position_ids":
                 mod._buffers[name] = torch.arange(buf.shape[-1]).expand(buf.shape).clone()
@@ -421,31 +528,57 @@ def _materialise_derived_buffers(model):
                 raise RuntimeError(f"load_llava: buffer {name!r} of {type(mod).__name__} is neither in the checkpoint nor derivable")
 
 
+def _eos_ids(model, tokenizer):
+    ids = getattr(getattr(model, "generation_config", None), "eos_token_id", None)
+    if ids is None:
+        ids = getattr(model.config, "eos_token_id", None)
+    if ids is None:
+        ids = getattr(tokenizer, "eos_token_id", None)
+    return [ids] if isinstance(ids, int) else list(ids or [])
+
+
 def get_img_describe(image_tensor, image, model, tokenizer, prompt, conv_templates=conv_templates,
                      image_token_index=IMAGE_TOKEN_INDEX, conv_template="llava_llama_3", num_beams=1, temperature=0.2,
-                     do_sample=True, max_new_tokens=512, device="cuda", seed=None):
+                     do_sample=True, max_new_tokens=512, device="cuda", seed=None, fast=None):
     """models/util.py:17-66 -> ``[caption]``.  ``seed`` (an addition) makes the caption a function of (image, prompt,
     weights, seed): sampling then runs inside ``torch.random.fork_rng`` with the CPU and the model's device generator seeded
     THERE, so the caller's generators -- which Stage 2 draws its noise from right afterwards, and in the reference live on
     another device (infer.py:145-166: LLaVA on cuda:1) -- are exactly where they were, however many tokens were sampled.
-    ``seed=None`` samples from the current generator state without touching any seed."""
+    ``seed=None`` samples from the current generator state without touching any seed.
+    ``fast`` (default: on a GPU, with one beam): the token loop runs through ``FastDecoder`` (static cache, decode step
+    replayed from a hipGraph) instead of ``transformers``' ``generate``; same tokens (tests/test_llava_next.py)."""
     if conv_template != "llava_llama_3":
         raise NotImplementedError("the pipeline's captioner is the Llama-3 LLaVA-NeXT (conv_template 'llava_llama_3')")
     system = getattr(conv_templates[conv_template], "system", LLAMA3_SYSTEM)
     text = llama3_prompt(tokenizer, prompt, system)
     input_ids = tokenizer_image_token(text, tokenizer, image_token_index, return_tensors="pt").unsqueeze(0).to(device)
+    mdev = next(model.parameters()).device
+    fast = (mdev.type == "cuda" and num_beams == 1) if fast is None else fast
 
     def run():
         with torch.inference_mode():
+            if fast:
+                return caption_tokens_fast(model, input_ids, image_tensor, [image.size], max_new_tokens, do_sample, temperature,
+                                           _eos_ids(model, tokenizer))
             return model.generate(input_ids, images=image_tensor, image_sizes=[image.size], do_sample=do_sample,
                                   temperature=temperature, num_beams=num_beams, max_new_tokens=max_new_tokens,
-                                  return_dict_in_generate=True, output_scores=True)
+                                  return_dict_in_generate=True, output_scores=True)[0][0]
 
     if seed is None:
         out = run()
     else:
-        mdev = next(model.parameters()).device
         with torch.random.fork_rng(devices=[mdev] if mdev.type == "cuda" else []):
             torch.manual_seed(seed)
             out = run()
-    return [tokenizer.decode(out[0][0].cpu().tolist(), skip_special_tokens=True).lstrip()]
+    return [tokenizer.decode(out.cpu().tolist(), skip_special_tokens=True).lstrip()]
+
+
+def caption_tokens_fast(model, input_ids, images, image_sizes, max_new_tokens, do_sample, temperature, eos_ids=None):
+    """Multimodal prompt -> generated token ids through the model's ``FastDecoder`` (built once per model and cache size)."""
+    embeds = model.multimodal_embeds(input_ids, images, image_sizes)
+    need = embeds.shape[1] + max_new_tokens
+    dec = getattr(model, "_fast_decoder", None)
+    if dec is None or dec.max_len < need:
+        dec = FastDecoder(model, -(-need // 256) * 256)
+        model.__dict__["_fast_decoder"] = dec          # not a submodule: plain attribute
+    return dec.generate(embeds, max_new_tokens, do_sample=do_sample, temperature=temperature, eos_token_id=eos_ids)

@@ -10,9 +10,14 @@ cropped (:556-567) into the result.  So tiled != untiled, by design; the parity 
 
 What is different is the machine mapping.  The reference walks a per-tile task queue, parks tiles in host
 memory and visits them in zig-zag order to keep ONE tile on the GPU (:846,893-957).  With 288 GB of HBM every
-tile stays resident: each tile is a Python generator that yields at each GroupNorm; the driver advances all
-tiles to the same norm layer, measures their statistics with rsvld_groupnorm_stats (fp32, deterministic),
-merges them, and resumes every tile with rsvld_groupnorm_apply.  No host round trips, no per-layer copies.
+tile stays resident, and tiles of equal shape (a 4096^2 image has 64 encoder tiles in 4 shapes) are STACKED along
+the batch: one launch per layer and shape class instead of one per layer and tile (round 3: a 512 -> 4096 image went
+through ~60 k GroupNorm launches and 12 k device copies).  Each shape class is a Python generator that yields at
+each GroupNorm; the driver advances all classes to the same norm layer, measures per-tile statistics with
+rsvld_groupnorm_stats (fp32, deterministic; one row per stacked tile), merges them over ALL tiles in tile order,
+and resumes every class with rsvld_groupnorm_apply.  Every launch is planned for ONE tile (ops.plan_units), so a
+tile's values do not depend on what it is stacked with: ``stack_tiles = False`` (one generator per tile) gives
+bit-identical results and is kept for that test.  No host round trips, no per-layer copies.
 """
 import math
 
@@ -58,9 +63,9 @@ def crop_margins(input_bbox, target_bbox, is_decoder):
 
 
 def merge_stats(stats, pixels):
-    """GroupNormParam.summary (:629-648): stats list of fp32 [B,32,2] (mean, var) per tile, pixels = h*w of
-    each tile at this layer.  weight_t = (p_t / max p) / sum(p / max p)."""
-    st = torch.stack(stats, 0)                                           # [T,B,32,2]
+    """GroupNormParam.summary (:629-648): stats = fp32 [B,32,2] (mean, var) per tile (a list, or one [T,B,32,2] tensor in
+    tile order), pixels = h*w of each tile at this layer.  weight_t = (p_t / max p) / sum(p / max p)."""
+    st = torch.stack(stats, 0) if isinstance(stats, (list, tuple)) else stats   # [T,B,32,2]
     p = torch.tensor(pixels, dtype=torch.float32, device=st.device) / max(pixels)
     p = (p / p.sum()).view(-1, 1, 1, 1)
     return (st * p).sum(0).contiguous()
@@ -119,6 +124,8 @@ def _tile_program(net, x, is_decoder):
 
 
 class VAEHook:
+    stack_tiles = True      # False: one launch per tile and layer (the round-2 form; bit-identical, kept as the A/B reference)
+
     def __init__(self, net, tile_size, is_decoder, fast_decoder=False, fast_encoder=False, color_fix=False, to_gpu=False):
         if fast_decoder or fast_encoder or color_fix:
             raise NotImplementedError("SR_backbone.init_tile_vae installs the hooks with fast modes and color_fix off")
@@ -140,22 +147,49 @@ class VAEHook:
         B, H, W, _ = z.shape
         net.last_z_shape = z.shape
         in_bboxes, out_bboxes = split_tiles(H, W, self.tile_size, self.pad, dec)
-        gens = [_tile_program(net, z[:, b[2]:b[3], b[0]:b[1], :].contiguous(), dec) for b in in_bboxes]
-        pending = [next(g) for g in gens]                # every tile advanced to its first GroupNorm
-        outs = [None] * len(gens)
+        T = len(in_bboxes)
+        # shape classes: tiles of equal (h, w) run as one stacked batch, tile-major ([t0 b0, t0 b1, .., t1 b0, ..])
+        classes = {}
+        for i, b in enumerate(in_bboxes):
+            key = (b[3] - b[2], b[1] - b[0]) if self.stack_tiles else i
+            classes.setdefault(key, []).append(i)
+        groups = list(classes.values())
+        unit = ops._PLAN_DIV                             # independent units the caller has already stacked along B
+        gens, pending = [], []
+        for idx in groups:
+            x = torch.cat([z[:, in_bboxes[i][2]:in_bboxes[i][3], in_bboxes[i][0]:in_bboxes[i][1], :] for i in idx], 0)
+            gens.append(_tile_program(net, x, dec))
+        for g, idx in zip(gens, groups):
+            with ops.plan_units(unit * len(idx)):        # every launch planned for ONE tile of ONE unit
+                pending.append(next(g))                  # advanced to the first GroupNorm
+        outs = [None] * len(groups)
+        order = torch.tensor([i for idx in groups for i in idx], device=z.device)
         while any(p is not None for p in pending):
-            live = [i for i, p in enumerate(pending) if p is not None]
+            live = [k for k, p in enumerate(pending) if p is not None]
+            assert len(live) == len(groups)              # all classes run the same layer sequence
             norm = pending[live[0]][1]
-            stats = [ops.group_norm_stats(pending[i][0], norm.num_groups) for i in live]
-            merged = merge_stats(stats, [pending[i][0].shape[1] * pending[i][0].shape[2] for i in live])
-            for i in live:
+            stats, pixels = [], [0] * T
+            for k in live:
+                x = pending[k][0]
+                with ops.plan_units(unit * len(groups[k])):
+                    st = ops.group_norm_stats(x, norm.num_groups)          # [len(idx) * B, 32, 2]
+                stats.append(st.view(len(groups[k]), B, *st.shape[1:]))
+                for i in groups[k]:
+                    pixels[i] = x.shape[1] * x.shape[2]
+            st_all = torch.empty((T, B) + tuple(stats[0].shape[2:]), device=z.device, dtype=stats[0].dtype)
+            st_all[order] = torch.cat(stats, 0)                            # back to tile order: the merge sums in that order
+            merged = merge_stats(st_all, pixels)                           # [B, 32, 2]
+            for k in live:
                 try:
-                    pending[i] = gens[i].send(merged)
+                    with ops.plan_units(unit * len(groups[k])):
+                        pending[k] = gens[k].send(merged.repeat(len(groups[k]), 1, 1))
                 except StopIteration as done:
-                    pending[i], outs[i] = None, done.value
+                    pending[k], outs[k] = None, done.value
         oh, ow = (H * 8, W * 8) if dec else (H // 8, W // 8)
         result = torch.zeros((B, oh, ow, outs[0].shape[-1]), device=z.device, dtype=outs[0].dtype)
-        for t, ib, ob in zip(outs, in_bboxes, out_bboxes):
-            m = crop_margins(ib, ob, dec)
-            result[:, ob[2]:ob[3], ob[0]:ob[1], :] = t[:, m[2]:t.shape[1] + m[3], m[0]:t.shape[2] + m[1], :]
+        for out, idx in zip(outs, groups):
+            for j, i in enumerate(idx):
+                t, ib, ob = out[j * B:(j + 1) * B], in_bboxes[i], out_bboxes[i]
+                m = crop_margins(ib, ob, dec)
+                result[:, ob[2]:ob[3], ob[0]:ob[1], :] = t[:, m[2]:t.shape[1] + m[3], m[0]:t.shape[2] + m[1], :]
         return result

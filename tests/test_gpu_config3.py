@@ -67,11 +67,11 @@ def _stage1_step(cuda, side, t, bound_eps, bound_step):
 
 def test_config3_stage1_4096_one_step(cuda):
     """Level-3 attention over 262 144 tokens (range-major split-KV), mid attention over 65 536, full-resolution convs."""
-    _stage1_step(cuda, 4096, 25, bound_eps=6e-3, bound_step=1.5e-3)
+    _stage1_step(cuda, 4096, 25, bound_eps=8e-3, bound_step=6e-4)        # measured 4.0e-3 / 2.8e-4
 
 
 def test_config2_stage1_2048_one_step(cuda):
-    _stage1_step(cuda, 2048, 25, bound_eps=6e-3, bound_step=1.5e-3)
+    _stage1_step(cuda, 2048, 25, bound_eps=1e-2, bound_step=6e-4)        # measured 5.2e-3 / 2.6e-4
 
 
 def test_config3_tiled_vae_passes_4096(cuda, full_model, golden_dir):
@@ -116,10 +116,12 @@ def test_config3_tiled_vae_passes_4096(cuda, full_model, golden_dir):
         assert (h, w, tile) == (512, 512, 64) and ins == geo["512x512_t64_dec"]["in"] and outs == geo["512x512_t64_dec"]["out"]
     assert len(enc[0][4][0]) == 64 and len(dec[0][4][0]) == 64
     names = ("VAE denoise-encode (mode)", "VAE decode of the denoise-encoded latent", "VAE encode (moments)", "final VAE decode")
-    bounds = (4e-2, 6e-2, 4e-2, 6e-2)      # 2 x measured; bf16 through ~60 layers: 1-2e-2 per pass at 64^2
-    for i, (name, bound) in enumerate(zip(names, bounds)):
-        mx, _ = _rel(res["bf16"][i], res["f32"][i], f"configs[3] tiled VAE at 4096^2, {name}: bf16 vs fp32 family")
-        assert mx < bound, name
+    # (max, mean) bounds = 2 x measured (1.8e-2 / 2.3e-3, 4.4e-2 / 3.1e-3, 5.8e-2 / 7.5e-4, ~4.4e-2 / 3e-3): bf16 through ~60
+    # layers is 1-2e-2 of the range per pass at 64^2; the maximum over 16.7 M pixels sits further out
+    bounds = ((4e-2, 5e-3), (9e-2, 7e-3), (1.2e-1, 2e-3), (9e-2, 7e-3))
+    for i, (name, (bmax, bmean)) in enumerate(zip(names, bounds)):
+        mx, mn = _rel(res["bf16"][i], res["f32"][i], f"configs[3] tiled VAE at 4096^2, {name}: bf16 vs fp32 family")
+        assert mx < bmax and mn < bmean, name
 
 
 def test_config3_stage2_latent512_one_guided_call(cuda, full_model):

@@ -114,6 +114,13 @@ def test_llava_next_on_device_vs_reference_golden(cuda, tmp_path, golden_dir, n)
     print(f"LLaVA-NeXT on the device, image {n}: embeddings max|d| = {e_emb:.2e}, logits max|d| = {e_log:.2e}")
     assert e_emb < 2e-5 and e_log < 5e-4
     assert greedy.cpu().tolist() == z[f"i{n}.greedy"].tolist()
+    # the product's token loop on a GPU: FastDecoder, decode step replayed from a hipGraph -- same tokens; a second call
+    # re-uses the captured graph on a different prompt length only if the cache is large enough (here: same image, same tokens)
+    with torch.no_grad():
+        fast = LN.caption_tokens_fast(model, ids, images, [img.size], 16, False, 1.0, LN._eos_ids(model, C.build_tokenizer()))
+        again = LN.caption_tokens_fast(model, ids, images, [img.size], 16, False, 1.0, LN._eos_ids(model, C.build_tokenizer()))
+    assert model._fast_decoder._graph is not None
+    assert fast.cpu().tolist() == z[f"i{n}.greedy"].tolist() == again.cpu().tolist()
 
 
 def test_pipeline_with_live_caption_end_to_end(cuda, tmp_path):

@@ -426,6 +426,34 @@ def test_attention_d64_rescale_path(cuda):
     _close(got, want, dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("offset", [-40.0, 0.0, 60.0])
+def test_attention_d64_bias_step_extremes(cuda, dtype, offset):
+    """The running maximum enters the score MFMA chain as a 16-bit bias operand (csrc/attention.hip, A6B_BIAS): scores far
+    below zero on the FIRST tile (the bias starts at 0 and must move down), far above it, a maximum that keeps growing by
+    less than the deferral threshold per tile and then jumps, and a ragged last tile -- all against an fp64 softmax."""
+    from rsvld_amd import ops
+    heads, D, Nq, Nk = 3, 64, 96, 200
+    g = torch.Generator().manual_seed(int(offset) + 77)
+    q = torch.randn(1, Nq, heads * D, generator=g)
+    k = torch.randn(1, Nk, heads * D, generator=g)
+    v = torch.randn(1, Nk, heads * D, generator=g)
+    # a common component along one direction shifts every score of head 0 / 1 by ~offset (after the 1/8 scale)
+    u = torch.zeros(heads * D)
+    u[:D] = 1.0 / 8.0
+    q = q + u * 8.0
+    k = k + u * (offset * 8.0)
+    k[0, 190, D:2 * D] = q[0, 5, D:2 * D] * 3.0          # late spike in the last (ragged) tile, head 1
+    for j in range(Nk):                                  # head 2: the maximum of query 7 creeps up tile by tile
+        k[0, j, 2 * D:] += q[0, 7, 2 * D:] * (0.02 * j / 8.0)
+    q, k, v = _rt(q, dtype), _rt(k, dtype), _rt(v, dtype)
+    qh, kh, vh = (t.double().view(1, -1, heads, D).transpose(1, 2) for t in (q, k, v))
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).transpose(1, 2).reshape(1, Nq, heads * D).float()
+    got = ops.attention(q.to(cuda, dtype), k.to(cuda, dtype), v.to(cuda, dtype), heads=heads)
+    assert bool(torch.isfinite(got).all())
+    _close(got, want, dtype)
+
+
 def test_attention_online_softmax_rescale_path(cuda):
     """Force the running max to jump at a late key tile (cdna_hip_programming.md rule 26)."""
     from rsvld_amd import ops

@@ -151,3 +151,23 @@ def test_caption_sampling_leaves_the_callers_generator_alone(setup):
     torch.manual_seed(5)
     b = LN.get_img_describe(images, img, model, tok, C.QUESTION, max_new_tokens=8, device="cpu", seed=None)
     assert a == b
+
+
+@pytest.mark.parametrize("n", [0, 1, 2])
+def test_fast_decoder_reproduces_the_reference_generations(setup, n):
+    """FastDecoder (static cache, functional Llama forward over the model's own weights; eager on the CPU, hipGraph replay on a
+    GPU) must produce the reference's tokens: greedy and seeded sampling at temperature 0.2, token for token."""
+    LN, model, tok, proc, z = setup
+    img = C.test_image(C.IMAGE_SIZES[n], 5 + n)
+    images = [x for x in LN.process_images([img], proc, model.config)]
+    ids = torch.tensor(z["input_ids"])
+    with torch.no_grad():
+        emb = model.multimodal_embeds(ids, images, [img.size])
+        dec = LN.FastDecoder(model, emb.shape[1] + 16)
+        logits = dec.forward(emb, torch.arange(emb.shape[1]))
+        assert float((logits[0] - torch.tensor(z[f"i{n}.logits"])).abs().max()) < 1e-4
+        greedy = dec.generate(emb, 16, do_sample=False, eos_token_id=LN._eos_ids(model, tok))
+        torch.manual_seed(3)
+        sampled = LN.caption_tokens_fast(model, ids, images, [img.size], 16, True, 0.2, LN._eos_ids(model, tok))
+    assert greedy.tolist() == z[f"i{n}.greedy"].tolist()
+    assert sampled.tolist() == z[f"i{n}.sampled"].tolist()

@@ -107,3 +107,34 @@ def test_hip_vaehook_vs_reference_golden(cuda, golden_dir, dt, rel):
     # small inputs bypass tiling (tilevae.py:692-694)
     small = seeded.synthetic_image((1, 3, 64, 64), seed=3, smooth=2).to(cuda)
     assert torch.equal(enc.forward(small), enc.original_forward(small))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_stacked_tiles_equal_per_tile_launches_bit_for_bit(cuda, dt):
+    """Tiles of equal shape run stacked along the batch (one launch per layer and shape class); every launch is planned for
+    ONE tile, so the result must be bit-identical to one launch per tile (``stack_tiles = False``).  320 x 200 with 96-px
+    tiles gives several shape classes with several tiles each; batch 2 exercises the tile-major stacking."""
+    from rsvld_amd import ops
+    from rsvld_amd.utils.tilevae import VAEHook, split_tiles
+    fs, _ = _build()
+    fs.to(cuda)
+    fs.set_compute_dtype(dt)
+    img = seeded.synthetic_image((2, 3, 320, 200), seed=93, smooth=3).to(cuda)
+    ins, _ = split_tiles(320, 200, 96, 32, False)
+    shapes = {(b[3] - b[2], b[1] - b[0]) for b in ins}
+    assert len(ins) > len(shapes) > 1
+    enc = fs.encoder
+    enc.original_forward = enc.forward
+    hook = VAEHook(enc, 96, is_decoder=False)
+    a = hook(img)
+    hook.stack_tiles = False
+    b = hook(img)
+    assert torch.equal(a, b)
+    dec = fs.decoder
+    dec.original_forward = dec.forward
+    hook = VAEHook(dec, 12, is_decoder=True)
+    zin = ops.conv2d(ops.nchw_to_nhwc(S.rnd((2, 4, 40, 28), 94).to(cuda), dt), fs.pk(fs.post_quant_conv), pad=0)
+    a = hook(zin)
+    hook.stack_tiles = False
+    assert torch.equal(a, hook(zin))
