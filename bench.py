@@ -437,6 +437,7 @@ def bench_headline(args, dev, rank, world):
                 "t_caption_ms": round(a.get("caption", 0.0) / (K if full else 1) * 1e3, 1) if live else None,
                 "t_conditioner_ms": round(a.get("conditioner", 0.0) / (K if full else 1) * 1e3, 1),
                 "caption_new_tokens": getattr(captioner, "last_tokens", None) if live else None,
+                "caption_breakdown": getattr(captioner, "breakdown", None) if live else None,
                 "seconds_per_image": round(T * it1 + T * it2 + fx, 2),
                 "phases_ms": {k: round(v * 1e3, 1) for k, v in a.items()},
                 "timed_region_s": round(dt, 2), "model_build_s": round(build_s, 1), "finite": finite,
@@ -466,13 +467,23 @@ class Captioner:
     def __call__(self, u8_image, seed, max_new_tokens=256):
         from PIL import Image
         from rsvld_amd import llava_next as LN
+        t0 = time.perf_counter()
         pil = Image.fromarray(u8_image[0].permute(1, 2, 0).contiguous().cpu().numpy())
         views = [v.to(device=self.dev, dtype=torch.float16) for v in LN.process_images([pil], self.proc, self.model.config)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         with torch.random.fork_rng(devices=[self.dev]):
             torch.manual_seed(seed)
             with torch.inference_mode():
+                if getattr(self.model, "_fast_decoder", None) is not None:
+                    self.model._fast_decoder.profile = self.breakdown = {}
                 toks = LN.caption_tokens_fast(self.model, self.prompt_ids, views, [pil.size], max_new_tokens, True, 0.2, None)
         self.last_tokens = int(toks.numel())
+        b = getattr(self, "breakdown", {})
+        if b:   # host image path | CLIP tower + projector + splice | prefill | token loop, in ms
+            b.update(image_preprocess_ms=round((t1 - t0) * 1e3, 1),
+                     vision_and_splice_ms=round((time.perf_counter() - t1 - b["prefill_s"] - b["decode_s"]) * 1e3, 1),
+                     prefill_ms=round(b.pop("prefill_s") * 1e3, 1), decode_ms=round(b.pop("decode_s") * 1e3, 1))
         return " ".join(f"w{t}" for t in toks.tolist())
 
 

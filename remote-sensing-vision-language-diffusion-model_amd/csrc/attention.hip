@@ -22,6 +22,7 @@ struct AttnArgs {
     int B, heads, Nq, Nk, D;
     int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
     float scale_log2e;
+    unsigned long long* dbg;   // diagnostic builds only (-DA6B_STAMP=1): per-wave cycle sums of the loop's phases, else unused
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -490,7 +491,25 @@ constexpr int A6B_TILE = 64 * 128;            // 64 keys x 64 d, 16-bit
 #define A6B_ABL 0   // diagnostic builds (tools/ablate_attn.sh; results WRONG, timing only): 1 no exp, 2 no in-loop DMA / barrier,
                     // 8 no running max / row sum, 16 no V fragment reads, 32 no K fragment reads
 #endif
-constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
+// K[NB] | V[NB] 64-key sub-tiles, NB = 2 KPB.  KPB = sub-tiles per barrier: 1 (double buffer, one barrier per 64 keys) or, for
+// the 8-wave workgroups (two per CU: 2 x 64 KiB of LDS), 2 (four buffers, two sub-tiles requested and one barrier per 128 keys:
+// the in-loop wait + barrier was worth 9-13 % in the ablation of round 2, profiles/r02_attn_ablation.txt).
+#ifndef A6B_KPB8
+#define A6B_KPB8 2
+#endif
+// -DA6B_STAMP=1: diagnostic build (cdna_hip_programming.md section 7, In-kernel stamps).  s_memtime stamps split every loop
+// iteration of the d = 64 kernel into  request | K reads + S chain | softmax | V reads + PV chain | wait + barrier;  the sums
+// go to the workspace pointer (memory nothing else reads).  Read the SHARES, not the run time: the stamps' waits forbid overlaps.
+#ifndef A6B_STAMP
+#define A6B_STAMP 0
+#endif
+__device__ __forceinline__ unsigned long long a6b_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 
 // A6B_OCC4 = 1 (default): 128 registers, FOUR workgroups per CU.  The K fragments are read one 32-key half at a time and
 // the V fragments after the softmax instead of behind it, so that no 32-register fragment set is live across another
@@ -514,37 +533,31 @@ constexpr int A6B_SMEM = 4 * A6B_TILE;        // K[2] | V[2]
 #ifndef A6B_BIAS
 #define A6B_BIAS 1
 #endif
-// With the fma gone the exponentials' results are adjacent, and plain -O3 SLP-packs the row-sum adds into v_pk_add_f32,
-// which issues in two passes beside MFMAs (MI355X_MICROARCH.md "price of one filler"; round 2 measured the packed forms at
-// -1.6 .. -2.5 %): A6B_NOPK = 1 keeps them single v_add_f32 through an asm helper.
-#ifndef A6B_NOPK
-#define A6B_NOPK 1
-#endif
-__device__ __forceinline__ float a6b_add(float a, float b) {
-#if A6B_NOPK
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a + b;
-#endif
-}
+// With the fma gone the exponentials' results are adjacent, and plain -O3 SLP-packs the row-sum adds into v_pk_add_f32, which
+// issues in two passes beside MFMAs (MI355X_MICROARCH.md "price of one filler"; measured here: 841 vs 880 TFLOP/s at 16 384
+// tokens).  The file is therefore compiled with -fno-slp-vectorize (csrc/Makefile).  An inline-asm v_add_f32 helper is NOT the
+// way: hipcc pads no hazard for an asm statement, and a v_add that reads a v_exp_f32 result one instruction later (the
+// "trans use" hazard of gfx940+) returned stale values -- every d = 64 test failed with errors of order 1.
+__device__ __forceinline__ float a6b_add(float a, float b) { return a + b; }
 
 // NW = waves per workgroup: 4 (128 query rows) or 8 (256 query rows).  The 64-key K / V tile is filled once per workgroup,
 // so with 8 waves every wave issues ONE LDS-DMA piece per tensor per tile instead of two and there is one barrier per 256
 // query rows: the in-loop DMA + barrier cost (ablation: +13 % without it at 65 536 tokens) is halved per MFMA.  Two
 // 8-wave workgroups per CU keep the four waves per SIMD.  Chosen for long query sequences (A6B_NW8_MIN); the gain is small: the kernel is not bound by that term alone.
 #ifndef A6B_NW8_MIN
-#define A6B_NW8_MIN 32768   // measured (one box, 2 x 10 heads): +1.5 % at 65 536 tokens, -0.5 % (noise) at 16 384
+#define A6B_NW8_MIN 16384   // round 2 (one box, 2 x 10 heads): +1.5 % at 65 536 tokens, -0.5 % (noise) at 16 384; with the bias step
+                            // (round 3, 2 x 20 heads at 16 384 tokens): +1.3 % (880 -> 891 TFLOP/s), so 16 384 tokens take it too
 #endif
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(AttnArgs p) {
     constexpr int D = 64;
+    constexpr int KPB = NW == 8 ? A6B_KPB8 : 1;   // sub-tiles per barrier
+    constexpr int NB = 2 * KPB;                   // sub-tile buffers per tensor
     constexpr int RPW = 64 / NW;     // tile rows each wave moves: 16 or 8
     constexpr int NP = RPW / 8;      // LDS-DMA pieces (8 rows x 128 B) per tensor per wave: 2 or 1
     typedef typename Mfma<T>::v8 v8;
     typedef typename Mfma<T>::v4 v4;
-    __shared__ __attribute__((aligned(16))) char smem[A6B_SMEM];
+    __shared__ __attribute__((aligned(16))) char smem[2 * NB * A6B_TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -578,8 +591,8 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
                      : "=&s"(keep) : "v"(ptr), "s"(dst) : "memory");
     };
     auto dma_tile = [&](int t) {
-        const int buf = t & 1;
-        const uint32_t kd = lds0 + buf * A6B_TILE + wu * (RPW * 128), vd = kd + 2 * A6B_TILE;
+        const int buf = t & (NB - 1);
+        const uint32_t kd = lds0 + buf * A6B_TILE + wu * (RPW * 128), vd = kd + NB * A6B_TILE;
         if (t * 64 + 64 <= p.Nk) {
             const char* kb = (const char*)(Kb + (int64_t)(t * 64 + wu * RPW) * p.k_ts);
             const char* vb = (const char*)(Vb + (int64_t)(t * 64 + wu * RPW) * p.v_ts);
@@ -599,6 +612,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         }
     };
     dma_tile(0);
+    if (KPB == 2 && nt > 1) dma_tile(1);
 
     // ---- Q fragments (B operand: col = query row on the lane, k = d)
     const int qrow = q0 + l31;
@@ -636,7 +650,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         const int row = 4 * lh + qq;   // + 16 s4 + 8 hf: multiples of 8, (row>>1)&1 unchanged
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-            voff[dt] = 2 * A6B_TILE + row * 128 + (((4 * dt + 2 * g1 + (pp >> 1)) ^ (((row >> 1) & 1) << 2)) << 4) + ((pp & 1) << 3);
+            voff[dt] = NB * A6B_TILE + row * 128 + (((4 * dt + 2 * g1 + (pp >> 1)) ^ (((row >> 1) & 1) << 2)) << 4) + ((pp & 1) << 3);
     }
 
     // The Q fragments are consumed here, before the loop: hipcc then puts its own vmcnt wait for their loads here and
@@ -647,17 +661,28 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
     __syncthreads();   // tile 0 landed
 
     if (A6B_ABL & 2) {   // both buffers hold real tiles; the loop then neither requests nor waits
-        if (nt > 1) dma_tile(1);
+        if (nt > 1 && KPB == 1) dma_tile(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     v8 abl_frag = *(const v8*)(smem + koff[0]);   // diagnostic builds only (A6B_ABL & 48): one constant fragment instead of LDS reads
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
+    unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_t = 0;
+    if (A6B_STAMP) st_t = a6b_stamp();
+#define A6B_MARK(i) do { if (A6B_STAMP) { const unsigned long long now_ = a6b_stamp(); st_sum[i] += now_ - st_t; st_t = now_; } } while (0)
+    // Outer loop = one barrier period (KPB sub-tiles), inner loop = its sub-tiles.  (A single loop with the barrier under
+    // ``if (t & 1)`` made hipcc spill 26 registers into the loop, unrolled by the period or not.)
+    for (int t0 = 0; t0 < nt; t0 += KPB) {
+    const int t1 = min(t0 + KPB, nt);
+#pragma nounroll
+    for (int t = t0; t < t1; ++t) {
+        const int buf = t & (NB - 1);
         if (A6B_ABL & 48) asm volatile("" : "+v"(abl_frag));
-        if (!(A6B_ABL & 2) && t + 1 < nt) dma_tile(t + 1);   // the other buffers were last read in tile t-1, before the barrier
+        // sub-tile t + KPB goes to the buffer sub-tile t - KPB was read from, i.e. before the last barrier (barriers close every
+        // KPB-th sub-tile); it is read KPB sub-tiles from now, behind the next vmcnt(0) + barrier
+        if (!(A6B_ABL & 2) && t + KPB < nt) dma_tile(t + KPB);
         const char* Ks = smem + buf * A6B_TILE;
         const int vb = buf * A6B_TILE;
+        A6B_MARK(0);
 
         // ---- S^T[key][q]: two 32-key halves x 4 k-steps, VGPR-form MFMAs
         v8 kf[2][4];
@@ -736,6 +761,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         };
         if (!A6B_OCC4) read_v();
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));   // MFMA D -> VALU reader (§5.7 item 2)
+        A6B_MARK(1);
 
         // ---- online softmax, register-local (this lane: 32 of its query's 64 scores, lane^32 the rest)
         if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
@@ -830,6 +856,11 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[s4][j] = (T)sacc[s4 >> 1][8 * (s4 & 1) + j];
+        if (A6B_STAMP) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) asm volatile("" : "+v"(pf[s4]));
+            A6B_MARK(2);
+        }
         if (A6B_OCC4) read_v();   // four waves per SIMD: the fragments may not be live across the softmax
 
         // ---- O^T[d][q] += V^T P^T, VGPR form
@@ -843,8 +874,21 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
                 asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(oacc[dt]) : "v"(vf[dt][s4]), "v"(pf[s4]));
         }
         asm volatile("s_setprio 0");
-        asm volatile("s_nop 15\n\ts_nop 3\n\ts_waitcnt vmcnt(0)" : "+v"(oacc[0]), "+v"(oacc[1]) : : "memory");   // O readable by VALU; next tile landed
-        if (!(A6B_ABL & 2)) __syncthreads();   // everyone done with this tile's buffers
+        if (A6B_STAMP) {
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(oacc[0]), "+v"(oacc[1]));
+            A6B_MARK(3);
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(oacc[0]), "+v"(oacc[1]));   // O readable by VALU
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next KPB sub-tiles have landed
+    if (!(A6B_ABL & 2)) __syncthreads();                // everyone done with the buffers of this barrier period
+    A6B_MARK(4);
+    }
+    if (A6B_STAMP && p.dbg != nullptr && lane == 0) {
+        unsigned long long* d = p.dbg + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + w) * 8;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) d[i] = st_sum[i];
+        d[5] = (unsigned long long)nt;
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -921,6 +965,7 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
     a.q_bs = q_batch_stride; a.q_ts = q_tok_stride; a.k_bs = k_batch_stride; a.k_ts = k_tok_stride;
     a.v_bs = v_batch_stride; a.v_ts = v_tok_stride; a.o_bs = o_batch_stride; a.o_ts = o_tok_stride;
     a.scale_log2e = scale * 1.4426950408889634f;
+    a.dbg = (A6B_STAMP && D == 64) ? (unsigned long long*)ws : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (D == 512) {
         int ns, kps;   // the key split (an accumulation-order choice) is planned on ONE of the plan_div stacked units

@@ -319,6 +319,7 @@ class FastDecoder:
         self.v = [torch.zeros(shape, device=self.dev, dtype=self.dt) for _ in self.layers]
         self.cols = torch.arange(self.max_len, device=self.dev)
         self._graph = None
+        self.profile = None      # a dict: generate() fills in device-synchronised seconds of its prefill and its token loop
 
     @staticmethod
     def _rms(x, norm):
@@ -371,9 +372,16 @@ class FastDecoder:
         use_graph = (self.dev.type == "cuda") if use_graph is None else use_graph
         eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
         embed = self.model.model.embed_tokens
+        if self.profile is not None:
+            import time
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
         logits = self.forward(inputs_embeds.to(self.dt), torch.arange(T0, device=self.dev))
         tok = self._pick(logits, do_sample, temperature)
         out = [tok]
+        if self.profile is not None:
+            torch.cuda.synchronize()
+            t_prefill = time.perf_counter()
         if use_graph and self._graph is None:
             self._tok, self._pos = tok.clone(), torch.tensor([T0], device=self.dev)
             side = torch.cuda.Stream()
@@ -396,6 +404,10 @@ class FastDecoder:
                 logits = self.forward(embed(tok)[None], torch.tensor([T0 + n - 1], device=self.dev))
             tok = self._pick(logits, do_sample, temperature)
             out.append(tok)
+        if self.profile is not None:
+            torch.cuda.synchronize()
+            self.profile.update(prompt_tokens=T0, prefill_s=t_prefill - t_start, decode_s=time.perf_counter() - t_prefill,
+                                new_tokens=len(out))
         return torch.cat(out)
 
 

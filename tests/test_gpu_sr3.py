@@ -151,7 +151,9 @@ def _pipeline_config1(net, cuda, golden_dir, prec):
     if prec == "fp32":
         assert float(d.max()) < 5e-5 and float(d.mean()) < 5e-6 and float((lsb == 0).mean()) >= 0.9995 and int(lsb.max()) <= 1
         return
-    assert float(d.max()) < 2e-3 and float(d.mean()) < 2e-4
+    # fp16 operands sit AT north_star's 1e-3 after 10 steps (8.3e-4 .. 9.9e-4 across boxes), not inside it with margin: the mode
+    # that holds the criterion with margin is compute_dtype fp32 above (9.5e-7).  Bound = 1.5 x measured.
+    assert float(d.max()) < 1.5e-3 and float(d.mean()) < 2e-4
     assert float((lsb == 0).mean()) >= 0.98 and int(lsb.max()) <= 1
 
 
@@ -196,9 +198,12 @@ def test_pipeline_t50_vs_reference_golden(sr3, cuda, golden_dir, prec):
         assert float(d.max()) < 1e-4 and float(d.mean()) < 1e-5 and int(lsb.max()) <= 1
         return
     assert float(d.max()) < S1_T50_MAX and float(d.mean()) < S1_T50_MEAN and int(lsb.max()) <= S1_T50_LSB
+    assert float((lsb == 0).mean()) >= 0.95
 
 
-S1_T50_MAX, S1_T50_MEAN, S1_T50_LSB = 4e-3, 4e-4, 1      # fp16, 50 steps (10 steps: 9.9e-4 / 1.0e-4)
+# fp16, 50 steps: measured max 2.0e-3 / mean 1.95e-4 (drift 5.6e-4 after 10 steps of the chain, 1.2e-3 after 25, 1.8e-3 after 40),
+# 97.5 % of the 8-bit hand-off identical, never more than 1 LSB apart (10 steps: 9.9e-4 / 1.0e-4 / 98.7 %)
+S1_T50_MAX, S1_T50_MEAN, S1_T50_LSB = 4e-3, 4e-4, 1
 
 
 def test_unet_forward_vs_oracle_fresh_input(sr3, cuda):
