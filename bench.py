@@ -474,7 +474,7 @@ class Captioner:
         t1 = time.perf_counter()
         with torch.random.fork_rng(devices=[self.dev]):
             torch.manual_seed(seed)
-            with torch.inference_mode():
+            with torch.no_grad():
                 if getattr(self.model, "_fast_decoder", None) is not None:
                     self.model._fast_decoder.profile = self.breakdown = {}
                 toks = LN.caption_tokens_fast(self.model, self.prompt_ids, views, [pil.size], max_new_tokens, True, 0.2, None)

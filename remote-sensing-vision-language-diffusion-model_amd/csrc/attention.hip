@@ -495,7 +495,10 @@ constexpr int A6B_TILE = 64 * 128;            // 64 keys x 64 d, 16-bit
 // the 8-wave workgroups (two per CU: 2 x 64 KiB of LDS), 2 (four buffers, two sub-tiles requested and one barrier per 128 keys:
 // the in-loop wait + barrier was worth 9-13 % in the ablation of round 2, profiles/r02_attn_ablation.txt).
 #ifndef A6B_KPB8
-#define A6B_KPB8 2
+#define A6B_KPB8 1   // measured (one box): 2 sub-tiles per barrier 957 / 1006 TFLOP/s vs 958 / 1015 with 1: no gain, kept at 1
+#endif
+#ifndef A6B_NW16_MIN
+#define A6B_NW16_MIN (1 << 30)   // experiment: 16-wave workgroups (512 query rows per K / V tile, one LDS-DMA piece per wave and tile)
 #endif
 // -DA6B_STAMP=1: diagnostic build (cdna_hip_programming.md section 7, In-kernel stamps).  s_memtime stamps split every loop
 // iteration of the d = 64 kernel into  request | K reads + S chain | softmax | V reads + PV chain | wait + barrier;  the sums
@@ -553,8 +556,9 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
     constexpr int D = 64;
     constexpr int KPB = NW == 8 ? A6B_KPB8 : 1;   // sub-tiles per barrier
     constexpr int NB = 2 * KPB;                   // sub-tile buffers per tensor
-    constexpr int RPW = 64 / NW;     // tile rows each wave moves: 16 or 8
-    constexpr int NP = RPW / 8;      // LDS-DMA pieces (8 rows x 128 B) per tensor per wave: 2 or 1
+    constexpr bool SPLIT = NW == 16;            // 16 waves: waves 0..7 move the K pieces, waves 8..15 the V pieces, ONE piece each
+    constexpr int RPW = SPLIT ? 8 : 64 / NW;    // tile rows each wave moves: 16 or 8
+    constexpr int NP = RPW / 8;                 // LDS-DMA pieces (8 rows x 128 B) per tensor per wave: 2 or 1
     typedef typename Mfma<T>::v8 v8;
     typedef typename Mfma<T>::v4 v4;
     __shared__ __attribute__((aligned(16))) char smem[2 * NB * A6B_TILE];
@@ -570,7 +574,9 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
     // ---- tile DMA.  Wave w moves key rows RPW w .. RPW w + RPW-1 of the tile: NP wave-instructions of 8 rows x 128 B per
     // tensor.  Lane (row = lane>>3, pos = lane&7) of piece i fills LDS chunk `pos` of tile row r = RPW w + 8i + row with
     // source chunk pos ^ ((r'>>1)&7) for K (r' = r & 15) and pos ^ (((r'>>1)&1)<<2) for V.
-    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int wave_u = __builtin_amdgcn_readfirstlane(w);
+    const int wu = SPLIT ? (wave_u & 7) : wave_u;          // row group of the tile this wave moves
+    const bool moves_k = !SPLIT || wave_u < 8, moves_v = !SPLIT || wave_u >= 8;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     const int64_t k_rowb = p.k_ts * (int64_t)sizeof(T), v_rowb = p.v_ts * (int64_t)sizeof(T);
     uint32_t kvo[NP], vvo[NP];
@@ -590,24 +596,30 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(ptr), "s"(dst) : "memory");
     };
+    // Full tiles are requested in order t = 0, 1, 2, ...: the two scalar row pointers advance by 64 rows per request (two
+    // 64-bit adds) instead of being recomputed from t with 64-bit multiplies (~20 SALU per request and wave, on a CU whose 16
+    // waves share one scalar unit: the request phase was 15 % of a wave's iteration in the stamped build).
+    const char* k_next = (const char*)(Kb + (int64_t)(wu * RPW) * p.k_ts);
+    const char* v_next = (const char*)(Vb + (int64_t)(wu * RPW) * p.v_ts);
+    const int64_t k_step = 64 * k_rowb, v_step = 64 * v_rowb;
     auto dma_tile = [&](int t) {
         const int buf = t & (NB - 1);
         const uint32_t kd = lds0 + buf * A6B_TILE + wu * (RPW * 128), vd = kd + NB * A6B_TILE;
         if (t * 64 + 64 <= p.Nk) {
-            const char* kb = (const char*)(Kb + (int64_t)(t * 64 + wu * RPW) * p.k_ts);
-            const char* vb = (const char*)(Vb + (int64_t)(t * 64 + wu * RPW) * p.v_ts);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                dma_fast(kb, kvo[i], kd + i * 1024);
-                dma_fast(vb, vvo[i], vd + i * 1024);
+                if (moves_k) dma_fast(k_next, kvo[i], kd + i * 1024);
+                if (moves_v) dma_fast(v_next, vvo[i], vd + i * 1024);
             }
+            k_next += k_step;
+            v_next += v_step;
         } else {   // rows past Nk re-read the last key; their scores are masked
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int rr = 8 * i + (lane >> 3), r16 = (wu * RPW + rr) & 15;
                 const int key = min(t * 64 + wu * RPW + rr, p.Nk - 1);
-                dma_slow((const char*)(Kb + (int64_t)key * p.k_ts) + (((lane & 7) ^ ((r16 >> 1) & 7)) << 4), kd + i * 1024);
-                dma_slow((const char*)(Vb + (int64_t)key * p.v_ts) + (((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4), vd + i * 1024);
+                if (moves_k) dma_slow((const char*)(Kb + (int64_t)key * p.k_ts) + (((lane & 7) ^ ((r16 >> 1) & 7)) << 4), kd + i * 1024);
+                if (moves_v) dma_slow((const char*)(Vb + (int64_t)key * p.v_ts) + (((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4), vd + i * 1024);
             }
         }
     };
@@ -990,7 +1002,11 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
                                   : go(attn_d512b_kernel<bf16, false>, attn_combine_kernel<bf16>, A5B_SMEM);
     }
     if (D == 64) {
-        if (Nq >= A6B_NW8_MIN) {   // long query sequences: 8 waves (256 query rows) share each K / V tile
+        if (Nq >= A6B_NW16_MIN) {
+            dim3 grid((unsigned)((Nq + 511) / 512), (unsigned)heads, (unsigned)B);
+            if (dtype == RSVLD_F16) hipLaunchKernelGGL((attn_d64b_kernel<f16, 16>), grid, dim3(1024), 0, s, a);
+            else hipLaunchKernelGGL((attn_d64b_kernel<bf16, 16>), grid, dim3(1024), 0, s, a);
+        } else if (Nq >= A6B_NW8_MIN) {   // long query sequences: 8 waves (256 query rows) share each K / V tile
             dim3 grid((unsigned)((Nq + 255) / 256), (unsigned)heads, (unsigned)B);
             if (dtype == RSVLD_F16) hipLaunchKernelGGL((attn_d64b_kernel<f16, 8>), grid, dim3(512), 0, s, a);
             else hipLaunchKernelGGL((attn_d64b_kernel<bf16, 8>), grid, dim3(512), 0, s, a);

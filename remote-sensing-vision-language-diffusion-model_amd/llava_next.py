@@ -320,43 +320,66 @@ class FastDecoder:
         self.cols = torch.arange(self.max_len, device=self.dev)
         self._graph = None
         self.profile = None      # a dict: generate() fills in device-synchronised seconds of its prefill and its token loop
+        # One weight-streaming GEMV for q | k | v and one for gate | up: the three (two) weight matrices of a layer become views
+        # of one concatenated tensor (no copy is kept, ``state_dict`` is unchanged), so a decode step launches 4 GEMVs per layer
+        # instead of 7.
+        self.wqkv, self.bqkv, self.wgu = [], [], []
+        for layer in self.layers:
+            at, mlp = layer.self_attn, layer.mlp
+            self.wqkv.append(self._fuse([at.q_proj, at.k_proj, at.v_proj], "weight"))
+            self.bqkv.append(self._fuse([at.q_proj, at.k_proj, at.v_proj], "bias") if at.q_proj.bias is not None else None)
+            if mlp.gate_proj.bias is not None:
+                raise NotImplementedError("FastDecoder: biased MLP projections")
+            self.wgu.append(self._fuse([mlp.gate_proj, mlp.up_proj], "weight"))
 
     @staticmethod
-    def _rms(x, norm):
-        v = x.float()
-        v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + norm.variance_epsilon)
-        return norm.weight * v.to(x.dtype)
+    def _fuse(mods, name):
+        with torch.no_grad():
+            parts = [getattr(m, name) for m in mods]
+            fused = torch.cat([q.data for q in parts], dim=0)
+            o = 0
+            for q in parts:
+                q.data = fused[o:o + q.shape[0]]      # the module keeps working (and saving) through a view of the fused tensor
+                o += q.shape[0]
+        return fused
 
-    @staticmethod
-    def _rope(x, cos, sin):
-        h = x.shape[-1] // 2
-        return x * cos + torch.cat((-x[..., h:], x[..., :h]), dim=-1) * sin
+    def _rms(self, x, norm):
+        return torch.nn.functional.rms_norm(x, (x.shape[-1],), norm.weight, norm.variance_epsilon)
 
     def forward(self, embeds, pos):
         """``embeds [1, T, H]`` at absolute positions ``pos [T]`` (long, on the device) -> logits of the LAST position
-        ``[1, vocab]``; writes the keys / values of these positions into the cache."""
+        ``[1, vocab]``; writes the keys / values of these positions into the cache.  One code path for the prefill (T > 1)
+        and the decode step (T = 1): scores in the activation type, softmax in fp32 (``transformers``' eager attention),
+        grouped-query heads as a batched matmul over the kv heads -- no expanded copy of the cache, no mask tensor beyond an
+        additive ``[T, max_len]`` row."""
         m = self.model.model
         T = embeds.shape[1]
-        cos, sin = m.rotary_emb(embeds, pos[None])
-        cos, sin = cos[:, None], sin[:, None]                          # [1, 1, T, hd]
-        mask = (self.cols[None, :] <= pos[:, None])[None, None]        # [1, 1, T, max_len]: causal over the filled prefix
-        h = embeds
+        nq, nkv, hd = self.n_q, self.n_kv, self.hd
+        g = nq // nkv
+        cos, sin = m.rotary_emb(embeds, pos[None])                                 # [1, T, hd]
+        cos, sin = cos[0][:, None], sin[0][:, None]                                # [T, 1, hd]
+        bias = torch.zeros((T, self.max_len), device=self.dev, dtype=torch.float32)
+        bias.masked_fill_(self.cols[None, :] > pos[:, None], float("-inf"))       # causal over the filled prefix
+        scale = hd ** -0.5
+        h = embeds[0]                                                               # [T, H]
         for i, layer in enumerate(self.layers):
-            at = layer.self_attn
             x = self._rms(h, layer.input_layernorm)
-            q = at.q_proj(x).view(1, T, self.n_q, self.hd).transpose(1, 2)
-            k = at.k_proj(x).view(1, T, self.n_kv, self.hd).transpose(1, 2)
-            v = at.v_proj(x).view(1, T, self.n_kv, self.hd).transpose(1, 2)
-            q, k = self._rope(q, cos, sin), self._rope(k, cos, sin)
-            self.k[i].index_copy_(2, pos, k)
-            self.v[i].index_copy_(2, pos, v)
-            o = torch.nn.functional.scaled_dot_product_attention(q, self.k[i], self.v[i], attn_mask=mask,
-                                                                 enable_gqa=self.n_q != self.n_kv)
-            h = h + at.o_proj(o.transpose(1, 2).reshape(1, T, self.n_q * self.hd))
+            qkv = torch.nn.functional.linear(x, self.wqkv[i], self.bqkv[i]).view(T, nq + 2 * nkv, hd)
+            qk = qkv[:, :nq + nkv]
+            half = hd // 2
+            qk = qk * cos + torch.cat((-qk[..., half:], qk[..., :half]), dim=-1) * sin     # rotary embedding on q and k at once
+            self.k[i][0].index_copy_(1, pos, qk[:, nq:].transpose(0, 1))
+            self.v[i][0].index_copy_(1, pos, qkv[:, nq + nkv:].transpose(0, 1))
+            q = qk[:, :nq].reshape(T, nkv, g, hd).permute(1, 0, 2, 3).reshape(nkv, T * g, hd)  # [kv head, (t, q-in-group), hd]
+            sc = torch.matmul(q, self.k[i][0].transpose(1, 2)).float().view(nkv, T, g, self.max_len)
+            pr = torch.softmax(sc * scale + bias[None, :, None, :], dim=-1).to(self.dt).view(nkv, T * g, self.max_len)
+            o = torch.matmul(pr, self.v[i][0]).view(nkv, T, g, hd).permute(1, 0, 2, 3).reshape(T, nq * hd)
+            h = h + layer.self_attn.o_proj(o)
             x = self._rms(h, layer.post_attention_layernorm)
-            mlp = layer.mlp
-            h = h + mlp.down_proj(torch.nn.functional.silu(mlp.gate_proj(x)) * mlp.up_proj(x))
-        return self.model.lm_head(self._rms(h[:, -1], m.norm))
+            gu = torch.nn.functional.linear(x, self.wgu[i])
+            inter = gu.shape[-1] // 2
+            h = h + layer.mlp.down_proj(torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:])
+        return self.model.lm_head(self._rms(h[-1:], m.norm))
 
     def _pick(self, logits, do_sample, temperature):
         if not do_sample:
@@ -396,7 +419,7 @@ class FastDecoder:
             if eos and int(tok) in eos:
                 break
             if use_graph:
-                self._tok.copy_(tok)
+                self._tok.copy_(tok.view(-1))
                 self._pos.fill_(T0 + n - 1)
                 self._graph.replay()
                 logits = self._logits
@@ -568,10 +591,11 @@ def get_img_describe(image_tensor, image, model, tokenizer, prompt, conv_templat
     fast = (mdev.type == "cuda" and num_beams == 1) if fast is None else fast
 
     def run():
-        with torch.inference_mode():
-            if fast:
+        if fast:   # (no_grad, not inference_mode: tensors made in inference mode cannot be updated in place by a later call
+            with torch.no_grad():   # outside it, and a hipGraph capture that fails on that leaves the generator in capture state)
                 return caption_tokens_fast(model, input_ids, image_tensor, [image.size], max_new_tokens, do_sample, temperature,
                                            _eos_ids(model, tokenizer))
+        with torch.inference_mode():
             return model.generate(input_ids, images=image_tensor, image_sizes=[image.size], do_sample=do_sample,
                                   temperature=temperature, num_beams=num_beams, max_new_tokens=max_new_tokens,
                                   return_dict_in_generate=True, output_scores=True)[0][0]

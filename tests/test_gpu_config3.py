@@ -67,7 +67,7 @@ def _stage1_step(cuda, side, t, bound_eps, bound_step):
 
 def test_config3_stage1_4096_one_step(cuda):
     """Level-3 attention over 262 144 tokens (range-major split-KV), mid attention over 65 536, full-resolution convs."""
-    _stage1_step(cuda, 4096, 25, bound_eps=8e-3, bound_step=6e-4)        # measured 4.0e-3 / 2.8e-4
+    _stage1_step(cuda, 4096, 25, bound_eps=1e-2, bound_step=7e-4)        # measured 4.0e-3 .. 5.0e-3 / 2.8e-4 .. 3.6e-4
 
 
 def test_config2_stage1_2048_one_step(cuda):
@@ -148,4 +148,4 @@ def test_config3_stage2_latent512_one_guided_call(cuda, full_model):
     finally:
         m.set_precision("bf16", "fp16")
     mx, mn = _rel(x16, x32, "configs[3] Stage 2 at latent 512: guided x0, fp16 vs fp32 family")
-    assert mx < 1e-2 and mn < 2e-3
+    assert mx < 7e-3 and mn < 1e-3          # measured 3.4e-3 / 4.7e-4 (latent 64: 3.8e-3 / 6.5e-4, test_gpu_configs.py)

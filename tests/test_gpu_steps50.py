@@ -17,8 +17,11 @@ import s2_common as S
 pytestmark = pytest.mark.gpu
 
 PREC = {"shipped": ("bf16", "fp16"), "vae32": ("fp32", "fp16"), "allfp32": ("fp32", "fp32")}
-# (max|d|, mean|d|) on an output of range ~2.3 = 2 x measured (printed by the test); 6 steps: test_gpu_s2.PIPE_BOUNDS
-BOUNDS50 = {"shipped": (1.2e-1, 1.6e-2), "vae32": (2e-2, 3e-3), "allfp32": (2e-4, 3e-5)}
+# (max|d|, mean|d|) on an output of range 2.6 = 2 x measured.  Measured on MI355X, cache off / on (6 steps: test_gpu_s2.PIPE_BOUNDS):
+#   shipped (bf16 VAE, fp16 UNets)  3.17e-2 / 4.6e-3   3.21e-2 / 4.7e-3   -- the same as after 6 steps: the bf16 VAE passes dominate
+#   vae32   (fp32 VAE, fp16 UNets)  6.0e-3  / 6.1e-4   8.3e-3  / 7.6e-4   -- 2 x the 6-step figure: the drift of fp16 over 50 steps
+#   allfp32                          1.1e-5  / 1.5e-6   1.9e-5  / 1.8e-6
+BOUNDS50 = {"shipped": (6.5e-2, 9.5e-3), "vae32": (1.7e-2, 1.6e-3), "allfp32": (5e-5, 5e-6)}
 
 
 @pytest.fixture(scope="module")
