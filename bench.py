@@ -409,7 +409,7 @@ def bench_headline(args, dev, rank, world):
         torch.cuda.synchronize()
         ops.set_profiler(None)
         summ = prof.summary()
-        pmc = "r02_c4_pmc_traffic.json" if is_metric_cfg else "none (PMC passes exist for the metric's configuration only)"
+        pmc = "r03_c4_pmc_traffic.json" if is_metric_cfg else "none (PMC passes exist for the metric's configuration only)"
         roof = roofline_of(summ, pmc)
         tf_img = (S1_TF_PER_IMAGE_STEP.get(side, 0) + S2_TF_PER_IMAGE_STEP.get(latent, 0)) * T
         line = {

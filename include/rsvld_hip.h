@@ -91,6 +91,9 @@ typedef struct rsvld_conv_desc {
 #define RSVLD_TUNE_HALO_NW4 (1 << 8)    /* halo conv: force the 4-wave 8x32 tile                          */
 #define RSVLD_TUNE_HALO_NW8 (1 << 9)    /* halo conv: force the 8-wave 16x32 tile                         */
 #define RSVLD_TUNE_NO_GEMM256 (1 << 10) /* keep large 1x1 / Linear layers on the implicit-GEMM kernel     */
+#define RSVLD_TUNE_F32_SPLIT (1 << 11)  /* rsvld_conv2d_nhwc_f32 only -- a precision MODE, not an A/B switch: every fp32 operand is
+                                         * split into hi + lo bf16 and each product runs as three 16-bit MFMAs into the fp32
+                                         * accumulator (~1e-5 relative; the "split" precision of SR_backbone.set_precision)        */
 
 int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
 
@@ -296,6 +299,14 @@ int rsvld_attention_f32(const float* q, const float* k, const float* v, float* o
                         int64_t v_batch_stride, int64_t v_tok_stride,
                         int64_t o_batch_stride, int64_t o_tok_stride,
                         float scale, void* stream);
+/* rsvld_attention_f32 with split operands (hi + lo bf16, three 16-bit MFMAs per product; see RSVLD_TUNE_F32_SPLIT) */
+int rsvld_attention_f32_split(const float* q, const float* k, const float* v, float* out,
+                              int B, int heads, int Nq, int Nk, int D,
+                              int64_t q_batch_stride, int64_t q_tok_stride,
+                              int64_t k_batch_stride, int64_t k_tok_stride,
+                              int64_t v_batch_stride, int64_t v_tok_stride,
+                              int64_t o_batch_stride, int64_t o_tok_stride,
+                              float scale, void* stream);
 /* fp32 forms of rsvld_layernorm, rsvld_concat_c, rsvld_axpby and rsvld_absdiff_sums (the Stage-2 networks under
  * ``diffusion_dtype: fp32``; sgm/modules/attention.py:376-486, models/modules/SR_modules.py:59-149, DFBCache.py:98-112) */
 int rsvld_layernorm_f32(const float* x, float* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
@@ -306,6 +317,12 @@ int rsvld_absdiff_sums_f32(const float* a, const float* b, float* out, int rows,
 /* rsvld_nchw_f32_to_nhwc with an fp32 destination */
 int rsvld_nchw_f32_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W,
                                int Cdst, int c_off, int zero_pad, float scale, void* stream);
+
+/* Weight-streaming matrix-vector product of the caption pass's token loop: y[n] = sum_k w[n][k] x[k] (+ bias[n]); w [N][K]
+ * row-major, x [K], bias [N] or NULL, y [N], all 16-bit (dtype), fp32 accumulation; K % 8 == 0, K <= 32768.
+ * Replaces torch.nn.functional.linear with ONE activation row in the Llama decode step behind models/util.py:17-66
+ * (llava/model/language_model/llava_llama.py:118-137): q|k|v, o, gate|up, down projections and lm_head. */
+int rsvld_gemv(const void* w, const void* x, const void* bias, void* y, int N, int K, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

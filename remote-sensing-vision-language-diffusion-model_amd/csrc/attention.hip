@@ -494,6 +494,9 @@ constexpr int A6B_TILE = 64 * 128;            // 64 keys x 64 d, 16-bit
 // K[NB] | V[NB] 64-key sub-tiles, NB = 2 KPB.  KPB = sub-tiles per barrier: 1 (double buffer, one barrier per 64 keys) or, for
 // the 8-wave workgroups (two per CU: 2 x 64 KiB of LDS), 2 (four buffers, two sub-tiles requested and one barrier per 128 keys:
 // the in-loop wait + barrier was worth 9-13 % in the ablation of round 2, profiles/r02_attn_ablation.txt).
+#ifndef A6B_SUMCHK
+#define A6B_SUMCHK 1   // sum-checked softmax (see the loop): the row maximum is taken only on tiles whose row sum says the bias was stale
+#endif
 #ifndef A6B_KPB8
 #define A6B_KPB8 1   // measured (one box): 2 sub-tiles per barrier 957 / 1006 TFLOP/s vs 958 / 1015 with 1: no gain, kept at 1
 #endif
@@ -696,7 +699,10 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         const int vb = buf * A6B_TILE;
         A6B_MARK(0);
 
-        // ---- S^T[key][q]: two 32-key halves x 4 k-steps, VGPR-form MFMAs
+        // ---- S^T[key][q]: two 32-key halves x 4 k-steps, VGPR-form MFMAs (a lambda: the sum-checked softmax below runs it a
+        // second time on the rare tile whose scores outgrew the bias)
+        f32x16 sacc[2];
+        auto s_phase = [&]() {
         v8 kf[2][4];
         if (!A6B_OCC4) {
 #pragma unroll
@@ -704,7 +710,6 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const v8*)(Ks + kt * 4096 + koff[ks]);
         }
-        f32x16 sacc[2];
         // bias step operands (transient: built per tile so that no register is held across the PV phase, where the kernel
         // sits at its 128-register limit).  A: 1 in k-slot 0 (lanes 0..31, element 0), B: -m of the lane's query there.
         v8 onesf, biasf;
@@ -755,6 +760,18 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
             }
         }
         asm volatile("s_setprio 0");
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));   // MFMA D -> VALU reader (§5.7 item 2)
+        if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (kv >= p.Nk) sacc[kt][r] = -INFINITY;
+                }
+        }
+        };
+        s_phase();
         v8 vf[2][4];
         auto read_v = [&]() {
             // V fragments of this tile: in flight behind the softmax.  A operand (row = d, k = key in P's register order):
@@ -772,36 +789,75 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
                 }
         };
         if (!A6B_OCC4) read_v();
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));   // MFMA D -> VALU reader (§5.7 item 2)
         A6B_MARK(1);
 
         // ---- online softmax, register-local (this lane: 32 of its query's 64 scores, lane^32 the rest)
-        if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kv = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (kv >= p.Nk) sacc[kt][r] = -INFINITY;
-                }
-        }
         // The running max and the row sum are reductions over the lane's 32 scores.  As ONE serial chain each (16 dependent
         // v_max3, 32 dependent v_add) they are bound by instruction latency, not issue (ablation: removing them bought 11 %,
         // removing the 32 exponentials nothing); four independent chains each, merged at the end.
-        float mx;
-        if (A6B_ABL & 8) mx = sacc[0][0];
-        else {
+        float alpha = 1.0f;
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        bool need;
+        auto tile_max = [&]() {   // maximum of the lane's 32 scores, four independent v_max3 chains
+            if (A6B_ABL & 8) return sacc[0][0];
             float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m4[r >> 2] = fmaxf(m4[r >> 2], sacc[kt][r]);
-            mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-        }
-        float alpha = 1.0f;
-        float r4[4] = {0.f, 0.f, 0.f, 0.f};
-        bool need;
-        if (A6B_BIAS) {
+            return fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        };
+        auto exp_and_sum = [&]() {   // P = exp2(s') in place, -> the lane's row-sum share
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r4[j] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pv = sacc[kt][r];
+                    if (!(A6B_ABL & 1)) pv = __builtin_amdgcn_exp2f(pv);
+                    sacc[kt][r] = pv;
+                    if (!(A6B_ABL & 8) || r == 0) r4[r >> 2] = a6b_add(r4[r >> 2], pv);
+                }
+            return a6b_add(a6b_add(r4[0], r4[1]), a6b_add(r4[2], r4[3]));
+        };
+        if (A6B_BIAS && A6B_SUMCHK) {
+            // Sum-checked softmax: no row maximum on the common path.  The scores come out of the matrix pipe relative to the
+            // maximum m_run known before the tile; P = exp2(s') and its row sum are needed anyway, and the SUM tells whether
+            // the bias was stale: as long as a lane's 32 exponentials add up to <= 2^14 none of them exceeds 2^14 -- finite
+            // in fp16 / bf16 -- and O, l are fp32.  Only when the sum is larger (or inf / NaN: s' > 128 overflows exp2), and on
+            // the first tile, the tile is REDONE: the scores are recomputed (the exponentials overwrote them; the K
+            // sub-tile is still in LDS), the exact maximum is taken, m_run moves up, O and l are rescaled.  -22 vector
+            // instructions per tile (17 v_max3, the half-wave exchange, the compare) of ~108.
+            float rs = exp_and_sum();
+            need = (t == 0) || !(rs <= 16384.0f);
+            if (__any(need)) {
+                s_phase();
+                float mx = tile_max();
+                {
+                    const uint32_t mb = __builtin_bit_cast(uint32_t, mx);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                    mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+                }
+                // both half-waves of a query take the same decision from the same mx: m_run stays equal in lane and lane ^ 32
+                const bool up = (t == 0) || (mx > 0.0f);                     // the maximum only ever moves UP (alpha <= 1)
+                const float m_new = up ? (float)(T)(m_run + mx) : m_run;     // representable in T: next tile's bias operand
+                const float delta = m_new - m_run;                           // exact; 0 where the maximum stays
+                m_run = m_new;
+                alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);      // first tile: nothing to rescale (delta may be << 0)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kt][r] -= delta;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                rs = exp_and_sum();
+            }
+            l_run = l_run * alpha + rs;
+        } else if (A6B_BIAS) {
+            float mx = tile_max();
             // the other half-wave's maximum of the same query: one v_permlane32_swap (lanes 32..63 of a <-> lanes 0..31 of b)
             {
                 const uint32_t mb = __builtin_bit_cast(uint32_t, mx);
@@ -838,6 +894,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
                 }
             l_run = l_run * alpha + a6b_add(a6b_add(r4[0], r4[1]), a6b_add(r4[2], r4[3]));
         } else {
+            float mx = tile_max();
             mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;   // scale > 0: max commutes with it
             need = mx > m_run + 8.0f;                              // deferred max (T13); true on the first tile
             if (need) {

@@ -8,9 +8,38 @@
 //   layernorm / concat / axpby / absdiff   the remaining ops of the Stage-2 UNet + ControlNet under ``diffusion_dtype: fp32``
 // This is the ACCURACY mode of the library, not the fast path: simple LDS tiling, no LDS-DMA pipelines.  The fp32 matrix
 // rate of gfx950 is 1/16 of the 16-bit rate, so the reference's default (bf16 VAE) stays the benchmarked configuration.
+//
+// SPLIT instantiations (round 3; ``RSVLD_TUNE_F32_SPLIT`` / rsvld_attention_f32_split): the same kernels on the same fp32 tensors, but
+// every matrix operand x is split on the fly into two bf16 numbers, hi = bf16(x) and lo = bf16(x - hi) (together 16 mantissa bits,
+// fp32's exponent range), and each fp32 product a*b becomes THREE 16-bit MFMAs into the fp32 accumulator,
+//     a_hi b_hi + a_lo b_hi + a_hi b_lo        (the dropped a_lo b_lo term is 2^-16 of the product),
+// i.e. 6 v_mfma_f32_32x32x16_bf16 (192 cycles) per 32-deep chunk instead of 16 v_mfma_f32_32x32x2_f32 (1 024 cycles).  Relative
+// error of a product ~1e-5: between the 16-bit kernels (1e-3) and the fp32 operands (1e-7); everything else (accumulation,
+// softmax, GroupNorm statistics, epilogues) is the fp32 code of this file.
 #include "rsvld_common.h"
 
 namespace {
+
+// split-operand helpers: x = hi + lo in bf16 (round to nearest even both times)
+__device__ __forceinline__ void split2(float x, bf16& hi, bf16& lo) {
+    hi = (bf16)x;
+    lo = (bf16)(x - (float)hi);
+}
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bf16 h, l;
+        split2(x[e], h, l);
+        hi[e] = h;
+        lo[e] = l;
+    }
+}
+// acc += a b with a = ah + al, b = bh + bl (three 16-bit products, small terms first)
+__device__ __forceinline__ f32x16 mfma_split(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------------------- convolution
 // out[m][n] = sum_k A[m][k] W[n][k];  m = (b, oy, ox), k = (tap, channel), gathered on the fly.
@@ -25,10 +54,13 @@ struct ConvF32Args {
     int64_t M;
 };
 constexpr int CF_BK = 32, CF_LD = CF_BK + 1;   // 33-float rows: the 32 rows one ds_read_b32 touches sit on 32 banks
+constexpr int CS_LD = CF_BK + 8;               // SPLIT: 40 bf16 = 80-byte rows (16-byte aligned fragments)
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args p) {
-    __shared__ float As[64 * CF_LD];
-    __shared__ float Bs[64 * CF_LD];
+    __shared__ __attribute__((aligned(16))) float As[SPLIT ? 1 : 64 * CF_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[SPLIT ? 1 : 64 * CF_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Sh[SPLIT ? 4 * 64 * CS_LD : 8];   // SPLIT: A hi | A lo | W hi | W lo
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const int64_t m0 = (int64_t)blockIdx.x * 64;
     const int n0 = blockIdx.y * 64;
@@ -79,19 +111,44 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(ConvF32Args p) {
                     v = *(const f32x4*)(src + ((xb[i] + (int64_t)iy * p.W + ix) * cs + c));
                 }
             }
-            float* d = As + (lr + 32 * i) * CF_LD + kq;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             f32x4 wv = {0.f, 0.f, 0.f, 0.f};
             const int n = n0 + lr + 32 * i;
             if (kv && n < p.Cout) wv = *(const f32x4*)(p.w + (int64_t)n * p.Ktot + k);
-            float* e = Bs + (lr + 32 * i) * CF_LD + kq;
-            e[0] = wv[0]; e[1] = wv[1]; e[2] = wv[2]; e[3] = wv[3];
+            if constexpr (SPLIT) {
+                bf16x4 ah, al, wh, wl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bf16 h, l;
+                    split2(v[e], h, l);
+                    ah[e] = h; al[e] = l;
+                    split2(wv[e], h, l);
+                    wh[e] = h; wl[e] = l;
+                }
+                const int o = (lr + 32 * i) * CS_LD + kq;
+                *(bf16x4*)(Sh + o) = ah;
+                *(bf16x4*)(Sh + 64 * CS_LD + o) = al;
+                *(bf16x4*)(Sh + 2 * 64 * CS_LD + o) = wh;
+                *(bf16x4*)(Sh + 3 * 64 * CS_LD + o) = wl;
+            } else {
+                float* d = As + (lr + 32 * i) * CF_LD + kq;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+                float* e = Bs + (lr + 32 * i) * CF_LD + kq;
+                e[0] = wv[0]; e[1] = wv[1]; e[2] = wv[2]; e[3] = wv[3];
+            }
         }
         __syncthreads();
-        const float* ar = As + (wm * 32 + (lane & 31)) * CF_LD + (lane >> 5);
-        const float* br = Bs + (wn * 32 + (lane & 31)) * CF_LD + (lane >> 5);
+        if constexpr (SPLIT) {   // lane: A row / W row (lane & 31), k-slots 8 (lane >> 5) .. +7 of each 16-deep step
+            const int ao = (wm * 32 + (lane & 31)) * CS_LD + (lane >> 5) * 8, bo = (wn * 32 + (lane & 31)) * CS_LD + (lane >> 5) * 8;
 #pragma unroll
-        for (int s = 0; s < CF_BK / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * s], br[2 * s], acc, 0, 0, 0);
+            for (int ks = 0; ks < CF_BK / 16; ++ks)
+                acc = mfma_split(*(const bf16x8*)(Sh + ao + ks * 16), *(const bf16x8*)(Sh + 64 * CS_LD + ao + ks * 16),
+                                 *(const bf16x8*)(Sh + 2 * 64 * CS_LD + bo + ks * 16), *(const bf16x8*)(Sh + 3 * 64 * CS_LD + bo + ks * 16), acc);
+        } else {
+            const float* ar = As + (wm * 32 + (lane & 31)) * CF_LD + (lane >> 5);
+            const float* br = Bs + (wn * 32 + (lane & 31)) * CF_LD + (lane >> 5);
+#pragma unroll
+            for (int s = 0; s < CF_BK / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[2 * s], br[2 * s], acc, 0, 0, 0);
+        }
         __syncthreads();
     }
 
@@ -207,6 +264,7 @@ struct AttnF32Args {
 };
 constexpr int AF_MAXBLK = 4;   // d-blocks per wave: D <= 4 waves x 4 x 32 = 512
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
     extern __shared__ float af_smem[];
     const int D = p.D, LDK = D + 1, nblk = D >> 5;
@@ -220,12 +278,24 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
     const int qrow = min(q0 + l31, p.Nq - 1);
 
     // Q fragments of this wave's d-blocks: B operand, B[k = d][col = q] = Q[q][d]
-    float qf[AF_MAXBLK][16];
+    // (SPLIT: per 16-deep step ks the lane holds d = 32 blk + 16 ks + 8 h + 0..7 as a hi and a lo bf16x8 -- the same 64 registers)
+    float qf[SPLIT ? 1 : AF_MAXBLK][16];
+    bf16x8 qh[SPLIT ? AF_MAXBLK : 1][2], ql[SPLIT ? AF_MAXBLK : 1][2];
 #pragma unroll
     for (int j = 0; j < AF_MAXBLK; ++j) {
         const int blk = w + 4 * j;
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) qf[j][s] = blk < nblk ? Qb[(int64_t)qrow * p.q_ts + blk * 32 + 2 * s + h] : 0.f;
+            for (int ks = 0; ks < 2; ++ks) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = blk < nblk ? Qb[(int64_t)qrow * p.q_ts + blk * 32 + ks * 16 + 8 * h + e] : 0.f;
+                split8(x, qh[j][ks], ql[j][ks]);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) qf[j][s] = blk < nblk ? Qb[(int64_t)qrow * p.q_ts + blk * 32 + 2 * s + h] : 0.f;
+        }
     }
     f32x16 oacc[AF_MAXBLK];
 #pragma unroll
@@ -254,9 +324,22 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
         for (int j = 0; j < AF_MAXBLK; ++j) {
             const int blk = w + 4 * j;
             if (blk < nblk) {
-                const float* kr = Ks + l31 * LDK + blk * 32 + h;
+                if constexpr (SPLIT) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * s], qf[j][s], sacc, 0, 0, 0);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const float* kr = Ks + l31 * LDK + blk * 32 + ks * 16 + 8 * h;
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] = kr[e];
+                        bf16x8 kh, kl;
+                        split8(x, kh, kl);
+                        sacc = mfma_split(kh, kl, qh[j][ks], ql[j][ks], sacc);
+                    }
+                } else {
+                    const float* kr = Ks + l31 * LDK + blk * 32 + h;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * s], qf[j][s], sacc, 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -288,17 +371,44 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnF32Args p) {
         l_run = l_run * alpha + rs;
         m_run = m_new;
         // ---- O^T[d][q] = alpha O^T + V^T P^T for this wave's d-blocks; V rows straight from global memory (coalesced along d)
+        // (SPLIT: k-slot (h, e) of step ks is score register 8 ks + e of lane half h, i.e. key 16 ks + 8 (e >> 2) + 4 h + (e & 3):
+        //  P is taken from its registers as it stands and V is fetched in that key order)
+        bf16x8 ph[2], pl[2];
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = sc[8 * ks + e];
+                split8(x, ph[ks], pl[ks]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < AF_MAXBLK; ++j) {
             const int blk = w + 4 * j;
             if (blk < nblk) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+                if constexpr (SPLIT) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int key = min(key0 + (s & 3) + 8 * (s >> 2) + 4 * h, p.Nk - 1);   // clamped rows carry P = 0
-                    const float vv = Vb[(int64_t)key * p.v_ts + blk * 32 + l31];
-                    oacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[s], oacc[j], 0, 0, 0);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int key = min(key0 + 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3), p.Nk - 1);   // clamped rows carry P = 0
+                            x[e] = Vb[(int64_t)key * p.v_ts + blk * 32 + l31];
+                        }
+                        bf16x8 vh, vl;
+                        split8(x, vh, vl);
+                        oacc[j] = mfma_split(vh, vl, ph[ks], pl[ks], oacc[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const int key = min(key0 + (s & 3) + 8 * (s >> 2) + 4 * h, p.Nk - 1);   // clamped rows carry P = 0
+                        const float vv = Vb[(int64_t)key * p.v_ts + blk * 32 + l31];
+                        oacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[s], oacc[j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -427,7 +537,8 @@ extern "C" int rsvld_conv2d_nhwc_f32(const rsvld_conv_desc* d, void* stream) {
     const int64_t gm = cdiv64(a.M, 64);
     if (gm > 0x7fffffffLL) return RSVLD_EINVAL;
     dim3 grid((unsigned)gm, (unsigned)((d->Cout + 63) / 64));
-    hipLaunchKernelGGL(conv_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (d->tune & RSVLD_TUNE_F32_SPLIT) hipLaunchKernelGGL(conv_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return rsvld_check_launch();
 }
 
@@ -466,7 +577,7 @@ extern "C" int rsvld_groupnorm_apply_f32(const float* x, float* y, const float* 
     return rsvld_check_launch();
 }
 
-extern "C" int rsvld_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int Nq, int Nk,
+static int attention_f32_launch(bool split, const float* q, const float* k, const float* v, float* out, int B, int heads, int Nq, int Nk,
                                    int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
                                    int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride, int64_t o_batch_stride,
                                    int64_t o_tok_stride, float scale, void* stream) {
@@ -481,13 +592,31 @@ extern "C" int rsvld_attention_f32(const float* q, const float* k, const float* 
     a.v_bs = v_batch_stride; a.v_ts = v_tok_stride; a.o_bs = o_batch_stride; a.o_ts = o_tok_stride;
     a.scale = scale;
     const int smem = (32 * (D + 1) + 4 * 16 * 64) * (int)sizeof(float);   // 81 KiB at D = 512
-    const void* kern = (const void*)attn_f32_kernel;
-    static const hipError_t attr = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (32 * 513 + 4096) * 4);
-    if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    static const hipError_t attr0 = hipFuncSetAttribute((const void*)attn_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (32 * 513 + 4096) * 4);
+    static const hipError_t attr1 = hipFuncSetAttribute((const void*)attn_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (32 * 513 + 4096) * 4);
+    if (attr0 != hipSuccess || attr1 != hipSuccess) return RSVLD_ELAUNCH;
     dim3 grid((unsigned)((Nq + 31) / 32), (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), smem, (hipStream_t)stream, a);
+    if (split) hipLaunchKernelGGL(attn_f32_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_f32_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
     return rsvld_check_launch();
 }
+
+extern "C" int rsvld_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int heads, int Nq, int Nk,
+                                   int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
+                                   int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride, int64_t o_batch_stride,
+                                   int64_t o_tok_stride, float scale, void* stream) {
+    return attention_f32_launch(false, q, k, v, out, B, heads, Nq, Nk, D, q_batch_stride, q_tok_stride, k_batch_stride, k_tok_stride,
+                                v_batch_stride, v_tok_stride, o_batch_stride, o_tok_stride, scale, stream);
+}
+
+extern "C" int rsvld_attention_f32_split(const float* q, const float* k, const float* v, float* out, int B, int heads, int Nq, int Nk,
+                                         int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
+                                         int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride, int64_t o_batch_stride,
+                                         int64_t o_tok_stride, float scale, void* stream) {
+    return attention_f32_launch(true, q, k, v, out, B, heads, Nq, Nk, D, q_batch_stride, q_tok_stride, k_batch_stride, k_tok_stride,
+                                v_batch_stride, v_tok_stride, o_batch_stride, o_tok_stride, scale, stream);
+}
+
 
 extern "C" int rsvld_nchw_f32_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cdst, int c_off,
                                           int zero_pad, float scale, void* stream) {

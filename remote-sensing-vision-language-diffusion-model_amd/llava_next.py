@@ -346,6 +346,15 @@ class FastDecoder:
     def _rms(self, x, norm):
         return torch.nn.functional.rms_norm(x, (x.shape[-1],), norm.weight, norm.variance_epsilon)
 
+    def _lin(self, x, w, b=None):
+        """``x [T, K] @ w[N, K]^T``.  The decode step (ONE row, 16-bit, on the GPU) streams the weights through this library's
+        HBM-bound matrix-vector kernel (rsvld_gemv: the PyTorch GEMV of the same shapes ran at ~3 TB/s); everything else is
+        ``torch.nn.functional.linear``."""
+        if x.shape[0] == 1 and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and w.is_contiguous() and w.shape[1] % 8 == 0:
+            from . import ops
+            return ops.gemv(w, x[0].contiguous(), b)[None]
+        return torch.nn.functional.linear(x, w, b)
+
     def forward(self, embeds, pos):
         """``embeds [1, T, H]`` at absolute positions ``pos [T]`` (long, on the device) -> logits of the LAST position
         ``[1, vocab]``; writes the keys / values of these positions into the cache.  One code path for the prefill (T > 1)
@@ -364,7 +373,7 @@ class FastDecoder:
         h = embeds[0]                                                               # [T, H]
         for i, layer in enumerate(self.layers):
             x = self._rms(h, layer.input_layernorm)
-            qkv = torch.nn.functional.linear(x, self.wqkv[i], self.bqkv[i]).view(T, nq + 2 * nkv, hd)
+            qkv = self._lin(x, self.wqkv[i], self.bqkv[i]).view(T, nq + 2 * nkv, hd)
             qk = qkv[:, :nq + nkv]
             half = hd // 2
             qk = qk * cos + torch.cat((-qk[..., half:], qk[..., :half]), dim=-1) * sin     # rotary embedding on q and k at once
@@ -374,12 +383,12 @@ class FastDecoder:
             sc = torch.matmul(q, self.k[i][0].transpose(1, 2)).float().view(nkv, T, g, self.max_len)
             pr = torch.softmax(sc * scale + bias[None, :, None, :], dim=-1).to(self.dt).view(nkv, T * g, self.max_len)
             o = torch.matmul(pr, self.v[i][0]).view(nkv, T, g, hd).permute(1, 0, 2, 3).reshape(T, nq * hd)
-            h = h + layer.self_attn.o_proj(o)
+            h = h + self._lin(o, layer.self_attn.o_proj.weight, layer.self_attn.o_proj.bias)
             x = self._rms(h, layer.post_attention_layernorm)
-            gu = torch.nn.functional.linear(x, self.wgu[i])
+            gu = self._lin(x, self.wgu[i])
             inter = gu.shape[-1] // 2
-            h = h + layer.mlp.down_proj(torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:])
-        return self.model.lm_head(self._rms(h[-1:], m.norm))
+            h = h + self._lin(torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:], layer.mlp.down_proj.weight)
+        return self._lin(self._rms(h[-1:], m.norm), self.model.lm_head.weight, self.model.lm_head.bias)
 
     def _pick(self, logits, do_sample, temperature):
         if not do_sample:

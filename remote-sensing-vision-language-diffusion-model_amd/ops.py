@@ -474,6 +474,22 @@ def attention(q, k, v, heads, scale=None):
     return out
 
 
+def gemv(w, x, bias=None):
+    """``w [N, K]`` (16-bit, rows contiguous) times ONE activation row ``x [K]`` (+ ``bias [N]``) -> ``[N]``: the weight-streaming
+    products of the caption pass's token loop (rsvld_gemv; HBM-bound, no tile, no MFMA)."""
+    _need_gpu(w, x, bias)
+    N, K = w.shape
+    if x.numel() != K or w.stride(1) != 1 or w.stride(0) != K or not x.is_contiguous():
+        raise L.RsvldError("gemv: w must be a contiguous [N, K] matrix and x a contiguous row of K elements")
+    if x.dtype != w.dtype or (bias is not None and bias.dtype != w.dtype):
+        raise L.RsvldError("gemv: w, x and bias must share one 16-bit dtype")
+    y = torch.empty(N, device=w.device, dtype=w.dtype)
+    lib = L.load()
+    _launch("gemv", 2.0 * N * K, (N * K + K + N) * 2, lambda: L.check(
+        lib.rsvld_gemv(_ptr(w), _ptr(x), _ptr(bias), _ptr(y), N, K, _dt(w), _stream()), "rsvld_gemv"))
+    return y
+
+
 # ----------------------------------------------------------------------------- small fp32 layers
 def linear_small(x, w, b, act_in=0, act_out=0):
     """fp32 ``[rows, in] -> [rows, out]`` with torch nn.Linear weight layout."""

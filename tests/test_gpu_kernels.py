@@ -444,6 +444,9 @@ def test_attention_d64_bias_step_extremes(cuda, dtype, offset):
     q = q + u * 8.0
     k = k + u * (offset * 8.0)
     k[0, 190, D:2 * D] = q[0, 5, D:2 * D] * 3.0          # late spike in the last (ragged) tile, head 1
+    # head 1, query 9: a key in tile 1 scores ~7 nats (2^10) above everything before it -- below the 2^14 row-sum limit of the
+    # sum-checked softmax, so the tile is NOT redone and P, O, l carry values up to 2^10 until a later rescale
+    k[0, 100, D:2 * D] = q[0, 9, D:2 * D] * (7.0 * 8.0 / float((q[0, 9, D:2 * D] ** 2).sum()))
     for j in range(Nk):                                  # head 2: the maximum of query 7 creeps up tile by tile
         k[0, j, 2 * D:] += q[0, 7, 2 * D:] * (0.02 * j / 8.0)
     q, k, v = _rt(q, dtype), _rt(k, dtype), _rt(v, dtype)
@@ -469,6 +472,24 @@ def test_attention_online_softmax_rescale_path(cuda):
     want = torch.softmax(q @ k.transpose(1, 2) * scale, -1) @ v
     got = ops.attention(q.to(cuda, dtype), k.to(cuda, dtype), v.to(cuda, dtype), heads=1, scale=scale)
     _close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(4096, 4096), (6144, 4096), (28672, 4096), (4096, 14336), (1003, 520), (17, 8)])
+def test_gemv_weight_streaming(cuda, dtype, shape):
+    """rsvld_gemv (the caption pass's decode-step products: Llama-3-8B q|k|v, o, gate|up, down shapes, ragged N and K) against
+    an fp64 matrix-vector product of the same 16-bit operands."""
+    from rsvld_amd import ops
+    N, K = shape
+    g = torch.Generator().manual_seed(N + K)
+    w = _rt(torch.randn(N, K, generator=g) / K ** 0.5, dtype)
+    x = _rt(torch.randn(K, generator=g), dtype)
+    b = _rt(torch.randn(N, generator=g) * 0.1, dtype)
+    want = (w.double() @ x.double()).float()
+    got = ops.gemv(w.to(cuda, dtype), x.to(cuda, dtype))
+    _close(got, want, dtype)
+    got = ops.gemv(w.to(cuda, dtype), x.to(cuda, dtype), b.to(cuda, dtype))
+    _close(got, want + b, dtype)
 
 
 def test_small_layers_and_embeddings(cuda):

@@ -11,7 +11,7 @@ MACRO=${MACRO:-A5B_ABL}
 LIST=${LIST:-"1 4 5"}
 TAG=$(echo $MACRO | tr A-Z a-z)
 for N in $LIST; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -D$MACRO=$N -I$SRC -I$ROOT/include -c $SRC/attention.hip -o /tmp/attn_abl$N.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ablate/librsvld_${TAG}$N.so /tmp/attn_abl$N.o $SRC/build/conv_igemm.o $SRC/build/conv_halo.o $SRC/build/gemm.o $SRC/build/norm.o $SRC/build/elementwise.o $SRC/build/sampler.o $SRC/build/f32.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -fno-slp-vectorize -D$MACRO=$N -I$SRC -I$ROOT/include -c $SRC/attention.hip -o /tmp/attn_abl$N.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ablate/librsvld_${TAG}$N.so /tmp/attn_abl$N.o $SRC/build/conv_igemm.o $SRC/build/conv_halo.o $SRC/build/gemm.o $SRC/build/norm.o $SRC/build/elementwise.o $SRC/build/sampler.o $SRC/build/f32.o $SRC/build/gemv.o
 done
 ls -la $ROOT/tools/ablate
