@@ -86,8 +86,8 @@ def build_stage1(T):
     model = create_model(opt)
     sched = dict(opt["model"]["beta_schedule"]["val"], n_timestep=T)
     model.set_new_noise_schedule(sched, schedule_phase="val")
-    if PRECISION == "fp32":
-        model.netG.denoise_fn.set_compute_dtype("fp32")
+    if PRECISION in ("fp32", "split"):
+        model.netG.denoise_fn.set_compute_dtype(PRECISION)
     return model.netG, opt
 
 
@@ -121,8 +121,8 @@ def build_stage2(dev, tile_vae, live_conditioner=False):
             if p_.dim() >= 2 and float(p_.abs().max()) == 0.0:
                 p_.copy_(torch.randn(p_.shape, generator=g) * 0.02)
     m.to(dev).eval()
-    if PRECISION == "fp32":
-        m.set_precision("fp32", "fp32")
+    if PRECISION in ("fp32", "split"):
+        m.set_precision(PRECISION, PRECISION)
     if tile_vae:   # SR_model.py:95-125: encoder tiles of 512 px, decoder tiles of 64 latent px, cross-tile GroupNorm
         m.init_tile_vae(512, 64)
     return m
@@ -416,7 +416,8 @@ def bench_headline(args, dev, rank, world):
             "metric": METRIC if is_metric_cfg else f"two-stage SR images/sec @{T} steps, {args.lr_side}px x{args.scale} (secondary workload)",
             "value": round(value, 6), "unit": "img/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if PRECISION == "fp32" else "f16 (UNets, fp32 accumulate), bf16 (VAE)", "data": "synthetic",
+            "dtype": {"fp32": "f32", "split": "f32 tensors, bf16 hi+lo split operands (3 MFMAs per product)"}.get(
+                PRECISION, "f16 (UNets, fp32 accumulate), bf16 (VAE)"), "data": "synthetic",
             "config": {
                 "workload": ((f"BASELINE configs[3]/[4] shape = the metric's configuration: " if is_metric_cfg else
                               "BASELINE configs[2] shape (Stage 1 + Stage 2, cached text embeds): " if (args.lr_side, args.scale) == (512, 4)
@@ -636,9 +637,10 @@ def main():
     ap.add_argument("--cached-cond", action="store_true", help="c4 / c4full: cached text embeddings (PreparedConditioner) and no "
                                                                 "caption pass, as rounds 1-2 measured (default: live LLaVA-NeXT "
                                                                 "caption + live text towers, BASELINE configs[3])")
-    ap.add_argument("--precision", default="default", choices=["default", "fp32"],
-                    help="fp32: both stages on the fp32-operand kernel family (the reference's CPU-path precision); secondary "
-                         "measurement only -- the metric is quoted on the reference's GPU policy (fp16 UNets, bf16 VAE)")
+    ap.add_argument("--precision", default="default", choices=["default", "fp32", "split"],
+                    help="fp32: both stages on the fp32-operand kernel family (the reference's CPU-path precision); split: fp32 tensors "
+                         "with every matrix product as three 16-bit MFMAs on hi + lo bf16 operands; secondary measurements only -- the "
+                         "metric is quoted on the reference's GPU policy (fp16 UNets, bf16 VAE)")
     ap.add_argument("--no-graph", action="store_true", help="c2: launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--pmc-pass", action="store_true", help="c4: one iteration of each stage + the fixed part and nothing "
                                                              "else (the process rocprofv3 --pmc counts)")

@@ -16,6 +16,7 @@ ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 TUNE_TILE = {"256x64": 1, "128x64": 2, "128x128": 3, "64x128": 4}
 TUNE_STAGES_SHIFT, TUNE_NO_KSPLIT, TUNE_REG_STAGING = 3, 1 << 6, 1 << 7
 TUNE_HALO_NW4, TUNE_HALO_NW8, TUNE_NO_GEMM256 = 1 << 8, 1 << 9, 1 << 10
+TUNE_F32_SPLIT = 1 << 11   # rsvld_conv2d_nhwc_f32: split-operand precision mode (three 16-bit MFMAs per fp32 product)
 
 ERRORS = {-1: "RSVLD_EINVAL (bad shape / pointer / combination)",
           -2: "RSVLD_EUNSUPPORTED", -3: "RSVLD_ELAUNCH (HIP launch failed)"}
@@ -87,6 +88,8 @@ SIGNATURES = {
     "rsvld_axpby_f32": (_i, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
     "rsvld_absdiff_sums_f32": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "rsvld_attention_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
+    "rsvld_attention_f32_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
                                  _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "rsvld_nchw_f32_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
 }

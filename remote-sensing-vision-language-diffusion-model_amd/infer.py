@@ -178,11 +178,14 @@ def main(argv=None):
     p.add_argument("--llava_adapter", type=str, default="./CKPT_PTH/Llava-next")
     p.add_argument("--use_tile_vae", action="store_true")
     p.add_argument("--fp32", action="store_true", help="both stages on the fp32-operand kernels (reference CPU-path precision; slow)")
+    p.add_argument("--split", action="store_true", help="both stages in the split-operand mode: fp32 tensors, every matrix product as "
+                                                         "three 16-bit MFMAs on hi + lo bf16 operands (~1e-5 per product)")
     a = p.parse_args(argv)
     cfg = PipelineConfig(input_img=a.input_img, output_dir=a.output_dir, upscale_factor=a.upscale_factor, seed=a.seed,
                          img_threshold=a.img_threshold, edm_steps=a.edm_steps, sr3_steps=a.sr3_steps, caption=a.caption,
                          no_llava=a.no_llava, llava_path=a.llava_path, llava_adapter=a.llava_adapter, use_tile_vae=a.use_tile_vae,
-                         **(dict(ae_dtype="fp32", diff_dtype="fp32", sr3_dtype="fp32") if a.fp32 else {}))
+                         **(dict(ae_dtype="fp32", diff_dtype="fp32", sr3_dtype="fp32") if a.fp32 else
+                            dict(ae_dtype="split", diff_dtype="split", sr3_dtype="split") if a.split else {}))
     SuperResolutionPipeline(cfg).process()
 
 

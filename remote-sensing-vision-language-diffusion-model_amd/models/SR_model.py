@@ -36,12 +36,16 @@ class SR_backbone(DiffusionEngine):
     def set_precision(self, ae_dtype, diffusion_dtype):
         """The reference fixes both in the constructor (SR_model.py:28-33); here they can also be switched on a loaded model.
         "fp32" (either one) runs that network on the fp32-operand kernel family (csrc/f32.hip) -- the reference without
-        autocast, i.e. what its CPU path computes; "bf16" / "fp16" run the fast 16-bit kernels (fp32 accumulation)."""
-        assert (ae_dtype in ["fp32", "fp16", "bf16"]) and (diffusion_dtype in ["fp32", "fp16", "bf16"])
+        autocast, i.e. what its CPU path computes; "bf16" / "fp16" run the fast 16-bit kernels (fp32 accumulation);
+        "split" (an addition) keeps fp32 tensors and fp32 arithmetic everywhere except the matrix products, whose operands are
+        split into hi + lo bf16 with three 16-bit MFMAs per product: ~1e-5 relative per product, between the two."""
+        assert (ae_dtype in ["fp32", "split", "fp16", "bf16"]) and (diffusion_dtype in ["fp32", "split", "fp16", "bf16"])
         if ae_dtype == "fp16":
             raise RuntimeError("fp16 cause NaN in AE")
-        self.ae_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[ae_dtype]
-        self.model.dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[diffusion_dtype]
+        self.ae_dtype = {"fp32": torch.float32, "split": torch.float32, "bf16": torch.bfloat16}[ae_dtype]
+        self.model.dtype = {"fp32": torch.float32, "split": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[diffusion_dtype]
+        self.model.split = diffusion_dtype == "split"
+        self.first_stage_model.split = ae_dtype == "split"
         self.first_stage_model.set_compute_dtype(self.ae_dtype)
 
     # ---- first stage ------------------------------------------------------------------------

@@ -63,6 +63,23 @@ def plan_units(n):
         _PLAN_DIV = old
 
 
+# ----------------------------------------------------------------------------- split-operand precision mode
+# Inside ``with f32_split(True)`` the matrix products of the fp32-operand family (conv2d / linear / attention on fp32 tensors) run
+# with every operand split into hi + lo bf16 and three 16-bit MFMAs per product (csrc/f32.hip, SPLIT instantiations): ~1e-5
+# relative instead of fp32's 1e-7, at a fraction of the fp32 matrix time.  Set by the owning network (``precision "split"``).
+_F32_SPLIT = False
+
+
+@contextlib.contextmanager
+def f32_split(on):
+    global _F32_SPLIT
+    old, _F32_SPLIT = _F32_SPLIT, bool(on)
+    try:
+        yield
+    finally:
+        _F32_SPLIT = old
+
+
 def _tune_from_env():
     """Developer A/B switches -> rsvld_conv_desc.tune.  The environment is read HERE, once, by the Python tools layer;
     the C ABI itself reads no environment (it is stateless)."""
@@ -329,10 +346,11 @@ def _conv2d_f32(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alph
         bias=None if pc.bias is None else pc.bias.data_ptr(), rowvec=None if rowvec is None else rowvec.data_ptr(),
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo,
-        upsample=int(upsample), dtype=L.F32, out_f32=1, act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=1, tune=0)
+        upsample=int(upsample), dtype=L.F32, out_f32=1, act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=1,
+        tune=L.TUNE_F32_SPLIT if _F32_SPLIT else 0)
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
     nbytes = 4.0 * (x.numel() + pc.w.numel() + out.numel() + (0 if residual is None else residual.numel()))
-    _launch("conv_f32", flops, nbytes, lambda: L.check(L.load().rsvld_conv2d_nhwc_f32(C.byref(d), _stream()),
+    _launch("conv_f32_split" if _F32_SPLIT else "conv_f32", flops, nbytes, lambda: L.check(L.load().rsvld_conv2d_nhwc_f32(C.byref(d), _stream()),
                                                        "rsvld_conv2d_nhwc_f32"))
     out._nhwc = True     # an fp32 4-d tensor is otherwise taken for NCHW by the VAE's input adapter
     return out
@@ -460,10 +478,11 @@ def attention(q, k, v, heads, scale=None):
     if q.dtype == torch.float32:
         if k.dtype != torch.float32 or v.dtype != torch.float32:
             raise L.RsvldError("attention (fp32): q, k, v must all be fp32")
-        _launch(f"attention_f32_d{D}", flops, nbytes, lambda: L.check(
-            lib.rsvld_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
-                                    q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                    out.stride(0), out.stride(1), scale, _stream()), "rsvld_attention_f32"))
+        fn = lib.rsvld_attention_f32_split if _F32_SPLIT else lib.rsvld_attention_f32
+        _launch(f"attention_f32{'_split' if _F32_SPLIT else ''}_d{D}", flops, nbytes, lambda: L.check(
+            fn(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
+               q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+               out.stride(0), out.stride(1), scale, _stream()), "rsvld_attention_f32"))
         return out
     ws_bytes = lib.rsvld_attention_ws_bytes(B, heads, Nq, Nk, D, _PLAN_DIV)   # split-KV partials (D = 512, small grids)
     ws = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8) if ws_bytes > 0 else None

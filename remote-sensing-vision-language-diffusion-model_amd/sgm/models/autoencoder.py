@@ -12,6 +12,7 @@ from ..modules.distributions.distributions import DiagonalGaussianDistribution
 
 class AutoencoderKL(HipNet):
     compute_dtype = torch.bfloat16
+    split = False     # with compute_dtype fp32: the split-operand precision mode (``ae_dtype: split``)
 
     def __init__(self, embed_dim: int, **kwargs):
         super().__init__()
@@ -39,8 +40,9 @@ class AutoencoderKL(HipNet):
 
     def moments(self, x, encoder=None):
         """posterior parameters, fp32 NHWC ``[B, h, w, 8]`` (mean | logvar)."""
-        h = (encoder or self.encoder)(x)
-        return ops.conv2d(h, self.pk(self.quant_conv), pad=0, out_f32=True)
+        with ops.f32_split(self.split and self.compute_dtype == torch.float32):
+            h = (encoder or self.encoder)(x)
+            return ops.conv2d(h, self.pk(self.quant_conv), pad=0, out_f32=True)
 
     def encode(self, x):
         assert not self.training, f"{self.__class__.__name__} only supports inference currently"
@@ -48,10 +50,11 @@ class AutoencoderKL(HipNet):
 
     def decode(self, z, **decoder_kwargs):
         """z fp32 NCHW ``[B,4,h,w]`` -> fp32 NCHW image ``[B,3,8h,8w]``."""
-        zin = ops.nchw_to_nhwc(z.float().contiguous(), self.compute_dtype)
-        h = ops.conv2d(zin, self.pk(self.post_quant_conv), pad=0)
-        dec = self.decoder(h, **decoder_kwargs)
-        return ops.nhwc_to_nchw(dec, channels=self.decoder.out_ch)
+        with ops.f32_split(self.split and self.compute_dtype == torch.float32):
+            zin = ops.nchw_to_nhwc(z.float().contiguous(), self.compute_dtype)
+            h = ops.conv2d(zin, self.pk(self.post_quant_conv), pad=0)
+            dec = self.decoder(h, **decoder_kwargs)
+            return ops.nhwc_to_nchw(dec, channels=self.decoder.out_ch)
 
 
 class AutoencoderKLInferenceWrapper(AutoencoderKL):

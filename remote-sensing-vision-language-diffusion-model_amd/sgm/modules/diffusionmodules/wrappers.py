@@ -23,6 +23,7 @@ class ControlWrapper(nn.Module):
         self.diffusion_model = diffusion_model
         self.control_model = None
         self.dtype = dtype
+        self.split = False     # with dtype fp32: the split-operand precision mode (SR_backbone.set_precision(..., "split"))
 
     def load_control_model(self, control_model):
         self.control_model = control_model
@@ -43,6 +44,10 @@ class ControlWrapper(nn.Module):
         return ops.nchw_to_nhwc(t, dt)
 
     def forward(self, x, t, c, control_scale=1, fbcache_mode="none", partial_info=None, **kwargs):
+        with ops.f32_split(self.split and self._compute_dtype() == torch.float32):
+            return self._forward(x, t, c, control_scale, fbcache_mode, partial_info, **kwargs)
+
+    def _forward(self, x, t, c, control_scale=1, fbcache_mode="none", partial_info=None, **kwargs):
         if not x.is_cuda:
             raise RsvldError("ControlWrapper runs on the GPU only")
         dt = self._compute_dtype()

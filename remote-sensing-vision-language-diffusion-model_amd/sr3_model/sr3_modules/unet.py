@@ -145,6 +145,7 @@ class UNet(nn.Module):
         self.final_conv = Block(cur, self.out_channel, groups=norm_groups)
 
         self.compute_dtype = torch.float16   # storage / MFMA operand type of the activations
+        self.split = False                   # with compute_dtype fp32: matrix products on split operands ("split")
         self._pk = None                      # packed weights, built lazily on the parameters' device
 
     # ------------------------------------------------------------------ weight packing
@@ -159,9 +160,10 @@ class UNet(nn.Module):
     def set_compute_dtype(self, dt):
         """fp16 (default) / bf16: 16-bit storage, fp32 accumulation; fp32: the fp32-operand kernel family (what the reference's
         own Stage 1 computes in: it runs without autocast)."""
-        dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}.get(dt, dt)
+        self.split = dt == "split"      # fp32 tensors, matrix products on split operands (three 16-bit MFMAs per product)
+        dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32, "split": torch.float32}.get(dt, dt)
         if dt not in (torch.float16, torch.bfloat16, torch.float32):
-            raise ValueError(f"compute_dtype {dt!r}: fp16, bf16 or fp32")
+            raise ValueError(f"compute_dtype {dt!r}: fp16, bf16, fp32 or split")
         if dt != self.compute_dtype:
             self.compute_dtype = dt
             self.invalidate_packed()
@@ -282,6 +284,10 @@ class UNet(nn.Module):
     def forward_nhwc(self, x, noise_level):
         """x: 16-bit NHWC ``[B,H,W,pad8(in_channel)]``; noise_level fp32 ``[B,1]`` -> fp32 NHWC eps
         ``[B,H,W,pad8(out_channel)]`` (channels beyond out_channel are zero)."""
+        with ops.f32_split(self.split and self.compute_dtype == torch.float32):
+            return self._forward_nhwc(x, noise_level)
+
+    def _forward_nhwc(self, x, noise_level):
         if self._pk is None:
             self._pack()
         pk = self._pk
