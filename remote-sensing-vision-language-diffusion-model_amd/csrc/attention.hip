@@ -590,14 +590,22 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         vvo[i] = (uint32_t)(rr * v_rowb) + (uint32_t)(((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4);
     }
     auto dma_fast = [&](const char* base, uint32_t voff, uint32_t dst) {
+#if A5B_M0_CLOBBER   // M0 declared clobbered instead of saved / restored (see the note at the d = 512 kernel's dma_one)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
+#else
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+#endif
     };
     auto dma_slow = [&](const char* ptr, uint32_t dst) {   // per-lane 64-bit address (tail tile: clamped rows)
+#if A5B_M0_CLOBBER
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(ptr), "s"(dst) : "memory", "m0");
+#else
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(ptr), "s"(dst) : "memory");
+#endif
     };
     // Full tiles are requested in order t = 0, 1, 2, ...: the two scalar row pointers advance by 64 rows per request (two
     // 64-bit adds) instead of being recomputed from t with 64-bit multiplies (~20 SALU per request and wave, on a CU whose 16
