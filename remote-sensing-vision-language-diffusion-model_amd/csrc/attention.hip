@@ -60,8 +60,17 @@ constexpr float A5_DEFER_LOG2 = 8.0f;   // rescale O only when a row's running m
 // Split-KV: when the query tiles alone cannot fill the chip, blockIdx.y walks key ranges and the
 // partial (O / l, m, l) triples are merged by attn_combine_kernel.
 // ---------------------------------------------------------------------------------------
+// A5B_M0_CLOBBER = 1 (round 3): the d = 512 kernel's LDS-DMA statements write M0 and declare it clobbered instead of saving and
+// restoring it around every piece (2 scalar instructions fewer per piece, and the restore no longer waits behind the DMA's own
+// read of M0): 1 050 -> 1 077 TFLOP/s at 262 144 keys (+2.5 %), unchanged at 65 536 (profiles/r03_attn_d64_ab.txt, run 7).
+// hipcc reserves M0 and only warns; the build is sound because the COMPILER never touches M0 in this translation unit, which
+// tools/audit_m0.py / tests/test_build_audits.py check on the assembly.  The d = 64 kernel keeps the save / restore form
+// (A6B_M0_CLOBBER = 0): with the clobber form it ran 12 % SLOWER (1 012 -> 894 TFLOP/s), same run.
 #ifndef A5B_M0_CLOBBER
-#define A5B_M0_CLOBBER 0
+#define A5B_M0_CLOBBER 1
+#endif
+#ifndef A6B_M0_CLOBBER
+#define A6B_M0_CLOBBER 0
 #endif
 #ifndef A5B_ABL
 #define A5B_ABL 0   // diagnostic builds (tools/ablate_attn.sh): 1 no softmax VALU, 2 no V reads, 4 no DMA, 8 no K reads
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
                               // real data: zero-filled operands would raise the clock and overstate the saving)
     auto dma_one = [&](const char* base, uint32_t voff, uint32_t dst) {
         if ((A5B_ABL & 4) && !abl_dma_on) return;
-#if A5B_M0_CLOBBER   // experiment: M0 declared clobbered instead of saved / restored around every piece (2 SALU fewer per piece)
+#if A5B_M0_CLOBBER   // M0 declared clobbered instead of saved / restored around every piece (2 SALU fewer per piece)
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
 #else
         uint32_t keep;
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         vvo[i] = (uint32_t)(rr * v_rowb) + (uint32_t)(((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4);
     }
     auto dma_fast = [&](const char* base, uint32_t voff, uint32_t dst) {
-#if A5B_M0_CLOBBER   // M0 declared clobbered instead of saved / restored (see the note at the d = 512 kernel's dma_one)
+#if A6B_M0_CLOBBER   // M0 declared clobbered instead of saved / restored (measured 12 % slower here: off, see A5B_M0_CLOBBER)
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
 #else
         uint32_t keep;
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
 #endif
     };
     auto dma_slow = [&](const char* ptr, uint32_t dst) {   // per-lane 64-bit address (tail tile: clamped rows)
-#if A5B_M0_CLOBBER
+#if A6B_M0_CLOBBER
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(ptr), "s"(dst) : "memory", "m0");
 #else
         uint32_t keep;

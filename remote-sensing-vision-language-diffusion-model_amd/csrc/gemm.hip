@@ -40,6 +40,9 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_ABL
 #define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue, 4 three K steps
 #endif
+#ifndef G_ASMDMA
+#define G_ASMDMA 1   // 1: LDS-DMA pieces as inline asm in the scalar-base form, steady-state loop without the "is there a tile to
+#endif               // request" branches (see dma_piece / the slot loops); 0: the round-2 form (builtin, per-lane 64-bit addresses)
 #ifndef G_STAGGER
 #define G_STAGGER 0   // experiment: first-round workgroups on every other CU start half a K loop late (s_sleep units per K tile),
 #endif                // so that the CUs' output bursts stop coinciding; 0 = off
@@ -95,10 +98,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
     const char* Xb = (const char*)p.x;
     const char* Wb = (const char*)p.w;
-    auto dma_piece = [&](int kt, int j) {   // j = 0..3: (X, W) x (rows 0..15, 16..31) of this wave's share of tile kt
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    // j = 0..3: (X, W) x (rows 0..15, 16..31) of this wave's share of tile kt.
+    // G_ASMDMA: the builtin made hipcc form a per-lane 64-bit address for every piece -- a v_lshl_add_u64 INTO the fragment
+    // registers the four MFMAs in front of it had just read (a write-after-read wait on the matrix pipe in the middle of the
+    // MFMA slot) -- and a branch around every piece.  Here the tile's row base is a scalar (SGPR pair), the lane's row / swizzle
+    // offset a 32-bit VGPR that lives across the loop, and M0 (the LDS destination) is written inside the statement and
+    // declared clobbered: nothing else in this file uses M0 (tools/audit_m0.py checks the assembly).
+    auto dma_piece = [&](int kt, int j) {
+#if G_ASMDMA
+        const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024);
+        const char* base = ((j & 1) ? Wb : Xb) + kt * 64;
+        const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[j >> 1];
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
+#else
         char* st = smem + (kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024;
         const char* src = ((j & 1) ? Wb : Xb) + kt * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)(src + ((j & 1) ? wvo[j >> 1] : xvo[j >> 1])), (lptr_t)st, 16, 0, 0);
+#endif
     };
     auto dma_tile = [&](int kt) {
 #pragma unroll
@@ -147,6 +164,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             }
         __builtin_amdgcn_s_setprio(0);
     };
+    auto mma_tile_dma = [&](int next) {   // steady state: the tile to request always exists, no branch around the pieces
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], acc[ni][mi]);
+                __builtin_amdgcn_sched_barrier(0);   // one piece after every fourth MFMA (hipcc otherwise moves the asm
+                dma_piece(next, 2 * ks + ni);        // statements to the head of the slot, three of them behind the first MFMA)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
     // own DMAs of tile kt+1 have landed; `ahead` later tiles of this wave may stay in flight (4 instructions per tile)
     auto wait_ahead = [&](int ahead) {
         if (ahead >= 2) g_wait_vm<8>();
@@ -181,8 +212,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // before the barrier that opened the slot).  Before the barrier that precedes anybody's read of tile kt+1 every
     // wave has waited for its own pieces of it: group 0 at the end of its multiply slot (tiles kt+2, kt+3 behind it),
     // group 1 at the end of its read slot (only tile kt+2 behind it: it requests kt+3 one slot later).
+    const int nk_main = G_ASMDMA ? max(nk - 3, 0) : 0;   // tiles whose multiply slot requests tile kt + 3
     if (grp == 0) {
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nk_main; ++kt) {              // steady state: two tiles stay in flight behind tile kt + 1
+            read_tile(kt);
+            slot_end();
+            mma_tile_dma(kt + 3);
+            g_wait_vm<8>();
+            slot_end();
+        }
+        for (int kt = nk_main; kt < nk; ++kt) {
             read_tile(kt);
             slot_end();
             mma_tile(kt + 3 < nk ? kt + 3 : -1);
@@ -192,7 +231,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         slot_end();
     } else {
         slot_end();
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nk_main; ++kt) {              // steady state: one tile stays in flight behind tile kt + 1
+            read_tile(kt);
+            g_wait_vm<4>();
+            slot_end();
+            mma_tile_dma(kt + 3);
+            slot_end();
+        }
+        for (int kt = nk_main; kt < nk; ++kt) {
             read_tile(kt);
             wait_ahead(min(nk - 1, kt + 2) - (kt + 1));
             slot_end();

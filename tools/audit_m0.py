@@ -1,19 +1,24 @@
-"""Audit for the inline-asm LDS-DMA statements that declare M0 clobbered instead of saving / restoring it (-DA5B_M0_CLOBBER=1):
+"""Audit for the inline-asm LDS-DMA statements that declare M0 clobbered instead of saving / restoring it (attn_d512b_kernel, gemm256_kernel):
 hipcc reserves M0 and warns that clobbering it "may lead to undefined behaviour", so the build is only acceptable while the
-COMPILER itself never reads or writes M0 in that translation unit.  Compiles attention.hip to assembly and fails if M0 appears
-anywhere outside an ;;#ASMSTART .. ;;#ASMEND block.   python tools/audit_m0.py [extra hipcc flags]"""
+COMPILER itself never reads or writes M0 in that translation unit.  Compiles the units to assembly and fails if M0 appears
+anywhere outside an ;;#ASMSTART .. ;;#ASMEND block.   python tools/audit_m0.py [extra hipcc flags]
+(tests/test_build_audits.py runs it for gemm.hip, whose shipped build has such statements.)"""
 import os, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "remote-sensing-vision-language-diffusion-model_amd", "csrc")
 
 
-def audit(extra=()):
+# translation units whose inline-asm LDS-DMA statements clobber M0, with the flags they are built with
+UNITS = {"attention.hip": ["-fno-slp-vectorize"], "gemm.hip": []}
+
+
+def audit(unit="attention.hip", extra=()):
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "attention.s")
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-fno-slp-vectorize",
-               "-DA5B_M0_CLOBBER=1", f"-I{SRC}", f"-I{os.path.join(ROOT, 'include')}", "-S", "--cuda-device-only", "-o", out,
-               os.path.join(SRC, "attention.hip"), *extra]
+        out = os.path.join(tmp, "unit.s")
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", *UNITS[unit],
+               f"-I{SRC}", f"-I{os.path.join(ROOT, 'include')}", "-S", "--cuda-device-only", "-o", out,
+               os.path.join(SRC, unit), *extra]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         bad, inasm, dma = [], False, 0
         for n, line in enumerate(open(out), 1):
@@ -31,8 +36,11 @@ def audit(extra=()):
 
 
 if __name__ == "__main__":
-    bad, dma = audit(sys.argv[1:])
-    print(f"{dma} LDS-DMA instructions inside asm blocks; compiler uses of m0 outside asm blocks: {len(bad)}")
-    for n, l in bad[:20]:
-        print(f"  line {n}: {l}")
-    sys.exit(1 if bad else 0)
+    rc = 0
+    for unit in UNITS:
+        bad, dma = audit(unit, sys.argv[1:])
+        print(f"{unit}: {dma} LDS-DMA instructions inside asm blocks; compiler uses of m0 outside asm blocks: {len(bad)}")
+        for n, l in bad[:20]:
+            print(f"  line {n}: {l}")
+        rc |= 1 if bad else 0
+    sys.exit(rc)
