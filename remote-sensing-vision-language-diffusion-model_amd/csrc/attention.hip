@@ -992,6 +992,8 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
         }
 }
 
+#include "attention_d64c.inc"
+
 }  // namespace
 
 // split-KV plan of the D = 512 kernel: key ranges per workgroup
@@ -1076,7 +1078,19 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
                                   : go(attn_d512b_kernel<bf16, false>, attn_combine_kernel<bf16>, A5B_SMEM);
     }
     if (D == 64) {
-        if (Nq >= A6B_NW16_MIN) {
+        // RSVLD_D64_KERNEL=b|c (diagnostic: tests and A/B runs) overrides the choice between attn_d64b and attn_d64c, which agree
+        // bit for bit on every shape
+        const char* force_env = getenv("RSVLD_D64_KERNEL");
+        const char force = force_env ? force_env[0] : 0;
+        const int64_t wg_c = (int64_t)((Nq + 511) / 512) * heads * B;
+        if ((a.dbg == nullptr || force == 'c') && force != 'b' && Nk > 64 && (wg_c >= A6C_MIN_WG || force == 'c')) {   // long query sequences: the ping-pong kernel
+            dim3 grid((unsigned)((Nq + 511) / 512), (unsigned)heads, (unsigned)B);
+            static const hipError_t attr16 = hipFuncSetAttribute((const void*)attn_d64c_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, A6C_SMEM);
+            static const hipError_t attrbf = hipFuncSetAttribute((const void*)attn_d64c_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, A6C_SMEM);
+            if (attr16 != hipSuccess || attrbf != hipSuccess) return RSVLD_ELAUNCH;
+            if (dtype == RSVLD_F16) hipLaunchKernelGGL((attn_d64c_kernel<f16>), grid, dim3(512), A6C_SMEM, s, a);
+            else hipLaunchKernelGGL((attn_d64c_kernel<bf16>), grid, dim3(512), A6C_SMEM, s, a);
+        } else if (Nq >= A6B_NW16_MIN) {
             dim3 grid((unsigned)((Nq + 511) / 512), (unsigned)heads, (unsigned)B);
             if (dtype == RSVLD_F16) hipLaunchKernelGGL((attn_d64b_kernel<f16, 16>), grid, dim3(1024), 0, s, a);
             else hipLaunchKernelGGL((attn_d64b_kernel<bf16, 16>), grid, dim3(1024), 0, s, a);

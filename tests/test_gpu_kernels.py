@@ -390,10 +390,20 @@ def test_attention_d512_shared_kv_tile(cuda, dtype, shape):
     assert float((got.float() - ref.float()).abs().max()) < (2e-3 if dtype == torch.float16 else 1.6e-2)
 
 
+@pytest.fixture(params=["b", "c"])
+def d64_kernel(request, monkeypatch):
+    """Both d = 64 kernels on every case: ``b`` (four waves per SIMD) and ``c`` (ping-pong, 512 query rows per workgroup), which
+    the library otherwise chooses between by the number of query rows (csrc/attention.hip, RSVLD_D64_KERNEL)."""
+    monkeypatch.setenv("RSVLD_D64_KERNEL", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 10, 256, 256), (1, 20, 64, 77), (2, 5, 100, 333), (1, 10, 4096, 4096), (3, 2, 1, 1)])
-def test_attention_d64_multihead(cuda, dtype, shape):
-    """SDXL self / cross attention and ZeroCrossAttn: heads x d=64, keys 77 (text), ragged, 4096 tokens."""
+@pytest.mark.parametrize("shape", [(2, 10, 256, 256), (1, 20, 64, 77), (2, 5, 100, 333), (1, 10, 4096, 4096), (3, 2, 1, 1),
+                                   (1, 2, 700, 64), (1, 1, 513, 129), (1, 2, 1100, 192)])
+def test_attention_d64_multihead(cuda, dtype, shape, d64_kernel):
+    """SDXL self / cross attention and ZeroCrossAttn: heads x d=64, keys 77 (text), ragged, 4096 tokens; one, two, three and
+    four key tiles (the ping-pong kernel's prologue requests three and its ring holds four)."""
     from rsvld_amd import ops
     B, heads, Nq, Nk = shape
     D = 64
@@ -408,7 +418,7 @@ def test_attention_d64_multihead(cuda, dtype, shape):
     _close(got, want, dtype)
 
 
-def test_attention_d64_rescale_path(cuda):
+def test_attention_d64_rescale_path(cuda, d64_kernel):
     """A late key dominates one query row (running max jumps by >> 2^8 in a late tile) and another row's max creeps
     up by less than the deferral threshold: both branches of the deferred-max logic."""
     from rsvld_amd import ops
@@ -428,7 +438,7 @@ def test_attention_d64_rescale_path(cuda):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("offset", [-40.0, 0.0, 60.0])
-def test_attention_d64_bias_step_extremes(cuda, dtype, offset):
+def test_attention_d64_bias_step_extremes(cuda, dtype, offset, d64_kernel):
     """The running maximum enters the score MFMA chain as a 16-bit bias operand (csrc/attention.hip, A6B_BIAS): scores far
     below zero on the FIRST tile (the bias starts at 0 and must move down), far above it, a maximum that keeps growing by
     less than the deferral threshold per tile and then jumps, and a ragged last tile -- all against an fp64 softmax."""
@@ -455,6 +465,29 @@ def test_attention_d64_bias_step_extremes(cuda, dtype, offset):
     got = ops.attention(q.to(cuda, dtype), k.to(cuda, dtype), v.to(cuda, dtype), heads=heads)
     assert bool(torch.isfinite(got).all())
     _close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 3, 1500, 1000), (1, 2, 4096, 2048 + 17), (1, 1, 64, 640)])
+def test_attention_d64_pingpong_equals_four_wave_kernel_bit_for_bit(cuda, dtype, shape, monkeypatch):
+    """attn_d64c re-schedules attn_d64b's arithmetic (same MFMA chains, same exponentials, row-sum order, sum check and redo):
+    the outputs are EQUAL, so which kernel a shape gets is not a numerics decision (batch-invariant by construction). A late
+    spike forces the redo path in a late tile."""
+    from rsvld_amd import ops
+    B, heads, Nq, Nk = shape
+    D = 64
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q = torch.randn(B, Nq, heads * D, generator=g)
+    k = torch.randn(B, Nk, heads * D, generator=g)
+    v = torch.randn(B, Nk, heads * D, generator=g)
+    k[0, Nk - 5, :D] = q[0, 33, :D] * 4.0
+    q, k, v = (t.to(cuda, dtype) for t in (q, k, v))
+    outs = {}
+    for kern in ("b", "c"):
+        monkeypatch.setenv("RSVLD_D64_KERNEL", kern)
+        outs[kern] = ops.attention(q, k, v, heads=heads)
+    assert bool(torch.isfinite(outs["c"]).all())
+    assert torch.equal(outs["b"], outs["c"])
 
 
 def test_attention_online_softmax_rescale_path(cuda):
