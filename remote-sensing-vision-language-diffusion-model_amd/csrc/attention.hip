@@ -993,6 +993,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
 }
 
 #include "attention_d64c.inc"
+#include "attention_d64p.inc"
 
 }  // namespace
 
@@ -1082,6 +1083,15 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
         // bit for bit on every shape
         const char* force_env = getenv("RSVLD_D64_KERNEL");
         const char force = force_env ? force_env[0] : 0;
+        if (force == 'p' && Nk > 64 && k_tok_stride < (1 << 23) && v_tok_stride < (1 << 23)) {   // the pipelined kernel (diagnostic selection only so far; 24-bit row stride in bytes)
+            dim3 grid((unsigned)((Nq + 255) / 256), (unsigned)heads, (unsigned)B);
+            static const hipError_t a16 = hipFuncSetAttribute((const void*)attn_d64p_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, A6P_SMEM);
+            static const hipError_t abf = hipFuncSetAttribute((const void*)attn_d64p_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, A6P_SMEM);
+            if (a16 != hipSuccess || abf != hipSuccess) return RSVLD_ELAUNCH;
+            if (dtype == RSVLD_F16) hipLaunchKernelGGL((attn_d64p_kernel<f16>), grid, dim3(512), A6P_SMEM, s, a);
+            else hipLaunchKernelGGL((attn_d64p_kernel<bf16>), grid, dim3(512), A6P_SMEM, s, a);
+            return rsvld_check_launch();
+        }
         const int64_t wg_c = (int64_t)((Nq + 511) / 512) * heads * B;
         if ((a.dbg == nullptr || force == 'c') && force != 'b' && Nk > 64 && (wg_c >= A6C_MIN_WG || force == 'c')) {   // long query sequences: the ping-pong kernel
             dim3 grid((unsigned)((Nq + 511) / 512), (unsigned)heads, (unsigned)B);

@@ -390,7 +390,7 @@ def test_attention_d512_shared_kv_tile(cuda, dtype, shape):
     assert float((got.float() - ref.float()).abs().max()) < (2e-3 if dtype == torch.float16 else 1.6e-2)
 
 
-@pytest.fixture(params=["b", "c"])
+@pytest.fixture(params=["b", "c", "p"])
 def d64_kernel(request, monkeypatch):
     """Both d = 64 kernels on every case: ``b`` (four waves per SIMD) and ``c`` (ping-pong, 512 query rows per workgroup), which
     the library otherwise chooses between by the number of query rows (csrc/attention.hip, RSVLD_D64_KERNEL)."""
@@ -468,7 +468,7 @@ def test_attention_d64_bias_step_extremes(cuda, dtype, offset, d64_kernel):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 3, 1500, 1000), (1, 2, 4096, 2048 + 17), (1, 1, 64, 640)])
+@pytest.mark.parametrize("shape", [(2, 3, 1500, 1000), (1, 2, 4096, 2048 + 17), (1, 1, 64, 640), (1, 2, 300, 128), (1, 1, 257, 191), (1, 2, 256, 70)])
 def test_attention_d64_pingpong_equals_four_wave_kernel_bit_for_bit(cuda, dtype, shape, monkeypatch):
     """attn_d64c re-schedules attn_d64b's arithmetic (same MFMA chains, same exponentials, row-sum order, sum check and redo):
     the outputs are EQUAL, so which kernel a shape gets is not a numerics decision (batch-invariant by construction). A late
@@ -483,11 +483,12 @@ def test_attention_d64_pingpong_equals_four_wave_kernel_bit_for_bit(cuda, dtype,
     k[0, Nk - 5, :D] = q[0, 33, :D] * 4.0
     q, k, v = (t.to(cuda, dtype) for t in (q, k, v))
     outs = {}
-    for kern in ("b", "c"):
+    for kern in ("b", "c", "p"):
         monkeypatch.setenv("RSVLD_D64_KERNEL", kern)
         outs[kern] = ops.attention(q, k, v, heads=heads)
-    assert bool(torch.isfinite(outs["c"]).all())
+    assert bool(torch.isfinite(outs["c"]).all()) and bool(torch.isfinite(outs["p"]).all())
     assert torch.equal(outs["b"], outs["c"])
+    assert torch.equal(outs["b"], outs["p"])
 
 
 def test_attention_online_softmax_rescale_path(cuda):
