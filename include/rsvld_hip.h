@@ -179,6 +179,22 @@ int rsvld_attention(const void* q, const void* k, const void* v, void* out,
                     int64_t v_batch_stride, int64_t v_tok_stride,
                     int64_t o_batch_stride, int64_t o_tok_stride,
                     float scale, int dtype, int plan_div, void* ws, void* stream);
+/* The same call with a developer A/B override (tests, tools): which of the three d = 64 kernels runs.  They agree bit for
+ * bit on every shape (tests/test_gpu_kernels.py), so the library's own choice (tune = 0: by grid size) is a speed decision only:
+ *   attn_d64b  four waves per SIMD, 128 / 256 query rows per workgroup (short sequences, small grids);
+ *   attn_d64c  "ping-pong": 8 waves x 64 query rows, matrix and vector segments of the two waves of a SIMD in anti-phase
+ *              (grids of >= 1024 workgroups: the Stage-2 self-attention of the headline, +2-5 %);
+ *   attn_d64p  "pipelined": every wave mixes its MFMAs with chunks of the next tile's softmax (experiment, 12 % slower). */
+#define RSVLD_ATTN_D64_FOUR_WAVE 1
+#define RSVLD_ATTN_D64_PINGPONG 2
+#define RSVLD_ATTN_D64_PIPELINED 3
+int rsvld_attention_tuned(const void* q, const void* k, const void* v, void* out,
+                          int B, int heads, int Nq, int Nk, int D,
+                          int64_t q_batch_stride, int64_t q_tok_stride,
+                          int64_t k_batch_stride, int64_t k_tok_stride,
+                          int64_t v_batch_stride, int64_t v_tok_stride,
+                          int64_t o_batch_stride, int64_t o_tok_stride,
+                          float scale, int dtype, int plan_div, void* ws, void* stream, int tune);
 /* bytes of `ws` the call above needs (0 = none, ws may be NULL): the D = 512 kernel splits the keys over
  * workgroups when the query tiles of B / plan_div batch rows alone cannot fill the chip and merges the partial
  * results from ws (plan_div: independent units stacked along B, see the conventions; 0 or 1 = plan on B). */

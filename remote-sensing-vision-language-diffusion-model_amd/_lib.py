@@ -57,6 +57,8 @@ SIGNATURES = {
     "rsvld_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
     "rsvld_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
                              _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _i, _vp, _vp]),
+    "rsvld_attention_tuned": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                             _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _i, _vp, _vp, _i]),
     "rsvld_attention_ws_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
     "rsvld_linear_small_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsvld_sinusoidal_embedding": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -8,7 +8,6 @@
 // waves with a cross-wave reduction of partial scores; register-staged K / V^T with two query tiles per wave) were
 // measured against these on the same boxes (history of the round) and removed.
 #include "rsvld_common.h"
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -1036,11 +1035,11 @@ extern "C" int64_t rsvld_attention_ws_bytes(int B, int heads, int Nq, int Nk, in
     return (int64_t)ns * B * heads * Nq * (512 + 2) * 4;
 }
 
-extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
-                               int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
-                               int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride,
-                               int64_t o_batch_stride, int64_t o_tok_stride, float scale, int dtype, int plan_div,
-                               void* ws, void* stream) {
+extern "C" int rsvld_attention_tuned(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
+                                     int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
+                                     int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride,
+                                     int64_t o_batch_stride, int64_t o_tok_stride, float scale, int dtype, int plan_div,
+                                     void* ws, void* stream, int tune) {
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return RSVLD_EINVAL;
     if (dtype != RSVLD_F16 && dtype != RSVLD_BF16) return RSVLD_EINVAL;
     // 16-byte vector access along d: strides must keep rows 8-element aligned
@@ -1079,10 +1078,9 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
                                   : go(attn_d512b_kernel<bf16, false>, attn_combine_kernel<bf16>, A5B_SMEM);
     }
     if (D == 64) {
-        // RSVLD_D64_KERNEL=b|c (diagnostic: tests and A/B runs) overrides the choice between attn_d64b and attn_d64c, which agree
-        // bit for bit on every shape
-        const char* force_env = getenv("RSVLD_D64_KERNEL");
-        const char force = force_env ? force_env[0] : 0;
+        // tune (RSVLD_ATTN_D64_*: tests and A/B runs) overrides the choice between the three d = 64 kernels, which agree bit for
+        // bit on every shape; 0 = by grid size
+        const char force = tune == RSVLD_ATTN_D64_FOUR_WAVE ? 'b' : tune == RSVLD_ATTN_D64_PINGPONG ? 'c' : tune == RSVLD_ATTN_D64_PIPELINED ? 'p' : 0;
         if (force == 'p' && Nk > 64 && k_tok_stride < (1 << 23) && v_tok_stride < (1 << 23)) {   // the pipelined kernel (diagnostic selection only so far; 24-bit row stride in bytes)
             dim3 grid((unsigned)((Nq + 255) / 256), (unsigned)heads, (unsigned)B);
             static const hipError_t a16 = hipFuncSetAttribute((const void*)attn_d64p_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, A6P_SMEM);
@@ -1116,4 +1114,13 @@ extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void
         return rsvld_check_launch();
     }
     return RSVLD_EUNSUPPORTED;
+}
+
+extern "C" int rsvld_attention(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
+                               int D, int64_t q_batch_stride, int64_t q_tok_stride, int64_t k_batch_stride,
+                               int64_t k_tok_stride, int64_t v_batch_stride, int64_t v_tok_stride,
+                               int64_t o_batch_stride, int64_t o_tok_stride, float scale, int dtype, int plan_div,
+                               void* ws, void* stream) {
+    return rsvld_attention_tuned(q, k, v, out, B, heads, Nq, Nk, D, q_batch_stride, q_tok_stride, k_batch_stride, k_tok_stride,
+                                 v_batch_stride, v_tok_stride, o_batch_stride, o_tok_stride, scale, dtype, plan_div, ws, stream, 0);
 }

@@ -27,9 +27,9 @@ for (B, heads, N) in [(2, 20, 16384), (2, 10, 65536)]:
     dbg = torch.zeros(nwg * nw * 8, device=dev, dtype=torch.int64)
     p = lambda t: C.c_void_p(t.data_ptr())
     for _ in range(3):   # the last launch's stamps are read (clock settled)
-        rc = lib.rsvld_attention(p(q), p(k), p(v), p(out), B, heads, N, N, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                 v.stride(0), v.stride(1), out.stride(0), out.stride(1), C.c_float(D ** -0.5), L.F16, 1, p(dbg),
-                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = lib.rsvld_attention_tuned(p(q), p(k), p(v), p(out), B, heads, N, N, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                       v.stride(0), v.stride(1), out.stride(0), out.stride(1), C.c_float(D ** -0.5), L.F16, 1, p(dbg),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream), 2 if PINGPONG else 1)
         assert rc == 0, rc
     torch.cuda.synchronize()
     d = dbg.view(-1, 8).cpu().double()
