@@ -71,6 +71,14 @@ constexpr float A5_DEFER_LOG2 = 8.0f;   // rescale O only when a row's running m
 #ifndef A6B_M0_CLOBBER
 #define A6B_M0_CLOBBER 0
 #endif
+// A5B_FINE = 1 (experiment, round 3): the softmax of tile t cut into 32 parts, ONE behind every MFMA of the S(t+1) chain (<= 3
+// vector instructions in a 24-cycle MFMA shadow), instead of 8 parts of ~10 instructions behind every fourth MFMA.  Same
+// operations in the same order (bit-identical output).  Measured (profiles/r03_attn_d64_ab.txt, run 17): +1.3 % at 65 536 keys,
+// -0.3 % at 262 144 (94 % of the Stage-1 attention time): the granularity of the vector work is not what the ablation's 10 %
+// are made of.  Off.
+#ifndef A5B_FINE
+#define A5B_FINE 0
+#endif
 #ifndef A5B_ABL
 #define A5B_ABL 0   // diagnostic builds (tools/ablate_attn.sh): 1 no softmax VALU, 2 no V reads, 4 no DMA, 8 no K reads
 #endif
@@ -93,6 +101,22 @@ constexpr int A5B_SMEM = 4 * A5B_TILE;     // K[2] | V[2]
 constexpr int A5B_SMEM_SH = 3 * A5B_TILE;  // X[3]
 __host__ __device__ constexpr int a5b_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+// A5B_SWAPMAX = 1 (experiment, round 3): the maximum over lane and lane ^ 32 by v_permlane32_swap instead of ds_bpermute (what
+// __shfl_xor compiles to; its result returns through lgkmcnt, and the wait for it also drains the K-fragment reads in flight in the
+// middle of the S chain).  Measured (run 17, 262 144 keys): 1 099 TFLOP/s with ds_bpermute, 1 054 with the swap (-4 %; with the
+// 32-part softmax 1 020): on one wave per SIMD the swap's own latency and hazard padding cost more than the drained reads.  Off.
+#ifndef A5B_SWAPMAX
+#define A5B_SWAPMAX 0
+#endif
+__device__ __forceinline__ float a5b_halfwave_max(float mx) {
+#if A5B_SWAPMAX
+    const uint32_t mb = __builtin_bit_cast(uint32_t, mx);
+    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+#else
+    return fmaxf(mx, __shfl_xor(mx, 32));
+#endif
+}
 
 template <typename T, bool SH>
 __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_per_split, float* part_o, float* part_ml) {
@@ -258,6 +282,20 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     if constexpr ((ks) + KD < 32 && !(A5B_ABL & 8)) A5B_KREAD((ks) % KD, (ks) + KD)
 #define A5B_STEP4(NAME, SACC, k) \
     A5B_STEP(NAME, SACC, k); A5B_STEP(NAME, SACC, (k) + 1); A5B_STEP(NAME, SACC, (k) + 2); A5B_STEP(NAME, SACC, (k) + 3)
+#if A5B_FINE   // HOOK(k), k = 0..31, behind MFMA k
+#define A5B_STEPH(NAME, SACC, k, HOOK) A5B_STEP(NAME, SACC, k); HOOK(k)
+#define A5B_STEPH4(NAME, SACC, k, HOOK) \
+    A5B_STEPH(NAME, SACC, k, HOOK); A5B_STEPH(NAME, SACC, (k) + 1, HOOK); A5B_STEPH(NAME, SACC, (k) + 2, HOOK); A5B_STEPH(NAME, SACC, (k) + 3, HOOK)
+#define A5B_CHAIN(NAME, SACC, KBUF, HOOK)                                                                               \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) ka[c] = lds0 + (uint32_t)((KBUF) * A5B_TILE + kbase[c]);              \
+    A5B_KREAD(0, 0); A5B_KREAD(1, 1); A5B_KREAD(2, 2); A5B_KREAD(3, 3); A5B_KREAD(4, 4); A5B_KREAD(5, 5);               \
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" NAME " %0, %1, %2, 0" : "=&v"(SACC) : "v"(kfr[0]), "v"(qf[0]), "i"(KD - 1)); \
+    A5B_KREAD(0, KD); HOOK(0);                                                                                          \
+    A5B_STEPH(NAME, SACC, 1, HOOK); A5B_STEPH(NAME, SACC, 2, HOOK); A5B_STEPH(NAME, SACC, 3, HOOK);                     \
+    A5B_STEPH4(NAME, SACC, 4, HOOK); A5B_STEPH4(NAME, SACC, 8, HOOK); A5B_STEPH4(NAME, SACC, 12, HOOK);                 \
+    A5B_STEPH4(NAME, SACC, 16, HOOK); A5B_STEPH4(NAME, SACC, 20, HOOK); A5B_STEPH4(NAME, SACC, 24, HOOK);               \
+    A5B_STEPH4(NAME, SACC, 28, HOOK)
+#else
 #define A5B_CHAIN(NAME, SACC, KBUF, HOOK)                                                                               \
     _Pragma("unroll") for (int c = 0; c < 8; ++c) ka[c] = lds0 + (uint32_t)((KBUF) * A5B_TILE + kbase[c]);              \
     A5B_KREAD(0, 0); A5B_KREAD(1, 1); A5B_KREAD(2, 2); A5B_KREAD(3, 3); A5B_KREAD(4, 4); A5B_KREAD(5, 5);               \
@@ -267,6 +305,7 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     A5B_STEP4(NAME, SACC, 4); HOOK(1); A5B_STEP4(NAME, SACC, 8); HOOK(2); A5B_STEP4(NAME, SACC, 12); HOOK(3);           \
     A5B_STEP4(NAME, SACC, 16); HOOK(4); A5B_STEP4(NAME, SACC, 20); HOOK(5); A5B_STEP4(NAME, SACC, 24); HOOK(6);         \
     A5B_STEP4(NAME, SACC, 28); HOOK(7)
+#endif
 #define A5B_MFMA_NAME(T_) (__is_same(T_, f16) ? "f16" : "bf16")
 #define A5B_NOHOOK(i)
 
@@ -313,7 +352,7 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);   // on the raw scores: scale > 0 commutes with max
                 asm volatile("" : "+v"(sacc), "+v"(mx));
             } else if (part == 1) {
-                mx = fmaxf(mx, __shfl_xor(mx, 32)) * p.scale_log2e;
+                mx = a5b_halfwave_max(mx) * p.scale_log2e;
                 // deferred max (T13): the reference point moves only when the tile max exceeds it by more than 2^8, so
                 // the rescale of O (256 accumulator registers through VGPRs) is skipped on almost every tile
                 need = mx > m_run + A5_DEFER_LOG2;   // true on the first tile (m_run = -inf)
@@ -342,9 +381,64 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
         };
         // (each part ends with an empty volatile asm naming what it produced: volatile asms keep their order, so the part
         // is computed at its hook; without the pins hipcc sinks the whole softmax behind the chain)
+        // the same softmax in 32 parts (A5B_FINE): 0..7 max of two scores each, 8 half-wave exchange + scale, 9 the deferred-max
+        // decision, 10..25 one exponential each (fma + exp2 + row-sum add), 26 the row sum, 27..30 four conversions each
+        auto sm32 = [&](int part) {
+            if (A5B_ABL & 1) {
+                if (part == 30) sm(6);
+                return;
+            }
+            if (part < 8) {
+                if (part == 0 && k_begin + (t + 1) * 32 > k_end) {   // ragged last tile (uniform branch)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = k_begin + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (kv >= k_end) sacc[r] = -INFINITY;
+                    }
+                }
+                mx = fmaxf(mx, fmaxf(sacc[2 * part], sacc[2 * part + 1]));
+                asm volatile("" : "+v"(mx));
+            } else if (part == 8) {
+                mx = a5b_halfwave_max(mx) * p.scale_log2e;
+                asm volatile("" : "+v"(mx));
+            } else if (part == 9) {
+                need = mx > m_run + A5_DEFER_LOG2;   // true on the first tile (m_run = -inf)
+                if (need) {
+                    alpha = __builtin_amdgcn_exp2f(m_run - mx);
+                    m_run = mx;
+                }
+                asm volatile("" : "+v"(alpha), "+v"(m_run));
+            } else if (part <= 25) {
+                const int r = part - 10;
+                sacc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], p.scale_log2e, -m_run));
+                rs += sacc[r];
+                asm volatile("" : "+v"(sacc[r]), "+v"(rs));
+            } else if (part == 26) {
+                l_run = l_run * alpha + rs;
+                asm volatile("" : "+v"(l_run));
+            } else if (part <= 30) {
+                const int q4 = part - 27;   // scores 4 q4 .. 4 q4 + 3 -> pf[q4 >> 1][4 (q4 & 1) ..]
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pf[q4 >> 1][4 * (q4 & 1) + j] = (T)sacc[4 * q4 + j];
+                if (q4 & 1) asm volatile("" : "+v"(pf[q4 >> 1]));
+            }
+        };
 
         f32x16 snext;
         if (more) {
+#if A5B_FINE
+#define A5B_HOOK(k)                                                   \
+    if constexpr (((k) & 3) == 3) {                                   \
+        if constexpr (SH) {                                           \
+            if (more2) dma_kb(t + 2, b_dma, (k) >> 2);                \
+        } else {                                                      \
+            if (more2) dma_k(t + 2, (k) >> 2);                        \
+            dma_v(t + 1, (k) >> 2);                                   \
+        }                                                             \
+    }                                                                 \
+    sm32(k);                                                          \
+    __builtin_amdgcn_sched_barrier(0)
+#else
 #define A5B_HOOK(i)                                                   \
     if constexpr (SH) {                                               \
         if (more2) dma_kb(t + 2, b_dma, i);                           \
@@ -354,12 +448,16 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     }                                                                 \
     sm(i);                                                            \
     __builtin_amdgcn_sched_barrier(0)
+#endif
             if constexpr (__is_same(T, f16)) {
                 A5B_CHAIN("v_mfma_f32_32x32x16_f16", snext, (SH ? b_s : ((t + 1) & 1)), A5B_HOOK);
             } else {
                 A5B_CHAIN("v_mfma_f32_32x32x16_bf16", snext, (SH ? b_s : ((t + 1) & 1)), A5B_HOOK);
             }
 #undef A5B_HOOK
+        } else if (A5B_FINE) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sm32(i);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) sm(i);
@@ -416,6 +514,10 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
 #undef A5B_MFMA_NAME
 #undef A5B_CHAIN
 #undef A5B_STEP4
+#if A5B_FINE
+#undef A5B_STEPH4
+#undef A5B_STEPH
+#endif
 #undef A5B_STEP
 #undef A5B_KREAD
 
