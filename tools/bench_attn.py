@@ -18,9 +18,12 @@ if os.environ.get("ONLY512"):
 if os.environ.get("ONLY64"):
     CASES = [c for c in CASES if c[3] == 64]
 print("library:", os.environ.get("RSVLD_LIB", "in-tree build"))
+NK = int(os.environ.get("CROSS", 0))     # CROSS=77: cross-attention against that many keys (the text tokens) instead of self-attention
 for (B, heads, N, D) in CASES:
     qkv = torch.randn(B, N, 3 * heads * D, device=dev, dtype=torch.float16)
     q, k, v = qkv[..., :heads * D], qkv[..., heads * D:2 * heads * D], qkv[..., 2 * heads * D:]
+    if NK:
+        k, v = k[:, :NK], v[:, :NK]
     if os.environ.get("SHARED") and D == 512:     # keys = values = one tensor: the shared-tile instantiation (Stage 1)
         v = k
     for _ in range(2):
@@ -33,5 +36,5 @@ for (B, heads, N, D) in CASES:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    fl = 4.0 * B * heads * N * N * D
+    fl = 4.0 * B * heads * N * (NK or N) * D
     print(f"B{B} heads{heads} N{N} D{D}: {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TF/s", flush=True)
