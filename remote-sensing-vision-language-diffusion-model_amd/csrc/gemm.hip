@@ -40,6 +40,13 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_ABL
 #define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue, 4 three K steps
 #endif
+// G_ONEBAR = 1 (experiment, round 3): ONE barrier per K tile instead of two (see the loop).  Correct (kernel tests green) and within
+// +-1 % of the two-barrier form on all nine headline shapes at 20 repetitions each (profiles/r03_gemm_onebar_ab.txt): the mid-tile
+// barrier is not what the K loop loses.  On the K-dominated shape (32 768 x 5 120 -> 1 280) the kernel is level with the vendor GEMM
+// (862-891 vs 876-912 TFLOP/s); the gap is the unhidden epilogue at K <= 2 048 and the 20 % padding of N = 640 to three 256-wide tiles.  Off.
+#ifndef G_ONEBAR
+#define G_ONEBAR 0
+#endif
 #ifndef G_ASMDMA
 #define G_ASMDMA 1   // 1: LDS-DMA pieces as inline asm in the scalar-base form, steady-state loop without the "is there a tile to
 #endif               // request" branches (see dma_piece / the slot loops); 0: the round-2 form (builtin, per-lane 64-bit addresses)
@@ -213,6 +220,40 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // wave has waited for its own pieces of it: group 0 at the end of its multiply slot (tiles kt+2, kt+3 behind it),
     // group 1 at the end of its read slot (only tile kt+2 behind it: it requests kt+3 one slot later).
     const int nk_main = G_ASMDMA ? max(nk - 3, 0) : 0;   // tiles whose multiply slot requests tile kt + 3
+#if G_ONEBAR
+    // ONE barrier per K tile (experiment; the scheme of attn_d64c): between two barriers a wave reads the fragments of one tile (R)
+    // and multiplies one tile (M); group 0 runs  M(kt) R(kt+1) | barrier,  group 1  R(kt) M(kt) | barrier,  so the two waves of a
+    // SIMD still alternate on the matrix pipe, but without the mid-tile barrier whose release latency was a bubble of the pipe
+    // twice per tile, and a wave stalled on the issue of its LDS-DMA pieces no longer idles the pipe when its partner is
+    // multiplying.  Both groups run the same loop body  R(kt) [barrier if group 0] M(kt) [barrier if group 1]  (group 0's loop
+    // is rotated by one segment).  Barrier #kt: tile kt + 1 has landed in every wave's view (group 0 then has requested up to
+    // tile kt + 2, group 1 up to tile kt + 3); the stage tile kt + 3 overwrites held tile kt - 1, whose reads returned before
+    // barrier #(kt - 1).
+    for (int kt = 0; kt < nk_main; ++kt) {
+        read_tile(kt);
+        if (grp == 0) {
+            g_wait_vm<4>();
+            slot_end();
+        }
+        mma_tile_dma(kt + 3);
+        if (grp == 1) {
+            g_wait_vm<8>();
+            slot_end();
+        }
+    }
+    for (int kt = nk_main; kt < nk; ++kt) {
+        read_tile(kt);
+        if (grp == 0) {
+            wait_ahead(min(nk - 1, kt + 2) - (kt + 1));
+            slot_end();
+        }
+        mma_tile(kt + 3 < nk ? kt + 3 : -1);
+        if (grp == 1) {
+            wait_ahead(min(nk - 1, kt + 3) - (kt + 1));
+            slot_end();
+        }
+    }
+#else
     if (grp == 0) {
         for (int kt = 0; kt < nk_main; ++kt) {              // steady state: two tiles stay in flight behind tile kt + 1
             read_tile(kt);
@@ -246,6 +287,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             slot_end();
         }
     }
+
+#endif
 
 #if G_ABL & 2
     if (p.M > 0) return;   // diagnostic build: no epilogue at all (the accumulators stay live for the compiler)
