@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "rsvld_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -46,6 +47,9 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 // (862-891 vs 876-912 TFLOP/s); the gap is the unhidden epilogue at K <= 2 048 and the 20 % padding of N = 640 to three 256-wide tiles.  Off.
 #ifndef G_ONEBAR
 #define G_ONEBAR 0
+#endif
+#ifndef G_EPI_SPECIALISED
+#define G_EPI_SPECIALISED 1
 #endif
 #ifndef G_ASMDMA
 #define G_ASMDMA 1   // 1: LDS-DMA pieces as inline asm in the scalar-base form, steady-state loop without the "is there a tile to
@@ -316,6 +320,57 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                                                               : u32x4{0u, 0u, 0u, 0u};
         }
     }
+    // Staging pass, specialised OUTSIDE the unrolled loops on (activation, alpha == 1): with the dispatch inside, every one of
+    // the 32 quads of a lane carried two uniform branches, re-read its bias quad from LDS (the staging stores may alias it for
+    // the compiler) and recomputed its swizzled address.  The bias quad and the staging offset of a quad depend on (ni, g) only
+    // (the row enters the swizzle as row & 31 = l31 for every mi): loops reordered, mi innermost.  Same operations on the same
+    // values: bit-identical.
+#if G_EPI_SPECIALISED
+    {
+        auto pass = [&](auto ACT, auto ALPHA1) {
+            constexpr int act = decltype(ACT)::value;
+            constexpr bool alpha1 = decltype(ALPHA1)::value;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wn * 64 + ni * 32 + 8 * g + 4 * lh;                    // tile column of the quad
+                    const f32x4 bq = *(const f32x4*)(smem + G_RING + col * 4);             // zeros without a bias / past N
+                    const int oc = col >> 1;                                               // GEGLU: output column inside the 128-wide tile
+                    const int so = act == 2 ? (grp * 128 + l31) * 256 + (((oc >> 3) ^ (l31 & 15)) << 4) + (oc & 7) * 2
+                                            : (grp * 128 + l31) * 512 + (((col >> 3) ^ l31) << 4) + (col & 7) * 2;
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e] + bq[e];
+                        if constexpr (act == 2) {   // channels are (value, gate) interleaved: 2 outputs per quad
+                            T o2[2] = {(T)(p.alpha * v[0] * gelu_erf_f(v[1])), (T)(p.alpha * v[2] * gelu_erf_f(v[3]))};
+                            uint32_t packed;
+                            __builtin_memcpy(&packed, o2, 4);
+                            *(uint32_t*)(smem + so + mi * (32 * 256)) = packed;
+                        } else {
+                            if constexpr (act == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                            }
+                            v4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = alpha1 ? (T)v[e] : (T)(v[e] * p.alpha);
+                            *(v4*)(smem + so + mi * (32 * 512)) = o;
+                        }
+                    }
+                }
+        };
+        typedef std::integral_constant<int, 0> A0;
+        typedef std::integral_constant<int, 1> A1;
+        typedef std::integral_constant<int, 2> A2;
+        if (geglu) pass(A2{}, std::false_type{});
+        else if (p.act == RSVLD_ACT_SILU) pass(A1{}, std::false_type{});
+        else if (p.alpha == 1.0f) pass(A0{}, std::true_type{});
+        else pass(A0{}, std::false_type{});
+    }
+#else
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int row = grp * 128 + mi * 32 + l31;
@@ -348,6 +403,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
             }
     }
+#endif
     __syncthreads();
     {
         const int n_tile_out = geglu ? 128 : 256;                         // channels of the stored tile
