@@ -426,9 +426,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
             }
         } else if (nn < p.N_out) {
-            for (int row = tid / row_chunks; row < 256; row += rows_per_pass) {
-                if (m0 + row >= p.M || ((G_ABL & 1) && p.M > 0)) break;
-                *(u32x4*)((T*)p.out + (int64_t)(m0 + row) * p.N_out + nn) = *(const u32x4*)(smem + c_off(row, chunk));
+            if (G_EPI_SPECIALISED && !geglu && m0 + 256 <= p.M && !(G_ABL & 1)) {
+                // full tile, 32 chunks per row: thread -> (row r0 + 16 i, chunk): one output pointer advanced by a constant, the
+                // staging offset alternates between two precomputed values (row & 31 = (r0 & 15) | 16 (i & 1)): 16 x (read, store,
+                // pointer add) instead of 16 x (bounds test, 64-bit multiply-add, swizzle)
+                const int r0 = tid >> 5;
+                char* o = (char*)((T*)p.out + (int64_t)(m0 + r0) * p.N_out + nn);
+                const int64_t ostep = (int64_t)16 * p.N_out * (int64_t)sizeof(T);
+                const int so0 = r0 * 512 + ((chunk ^ r0) << 4), so1 = (r0 + 16) * 512 + ((chunk ^ (r0 + 16)) << 4);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    *(u32x4*)o = *(const u32x4*)(smem + ((i & 1) ? so1 : so0) + (i >> 1) * (32 * 512));
+                    o += ostep;
+                }
+            } else {
+                for (int row = tid / row_chunks; row < 256; row += rows_per_pass) {
+                    if (m0 + row >= p.M || ((G_ABL & 1) && p.M > 0)) break;
+                    *(u32x4*)((T*)p.out + (int64_t)(m0 + row) * p.N_out + nn) = *(const u32x4*)(smem + c_off(row, chunk));
+                }
             }
         }
         (void)n_tile_out;
