@@ -79,6 +79,13 @@ constexpr float A5_DEFER_LOG2 = 8.0f;   // rescale O only when a row's running m
 #ifndef A5B_FINE
 #define A5B_FINE 0
 #endif
+// A5B_STEADY_LOOP = 1 (round 3): the key-tile loop body exists three times (attention_d512_body.inc): two steady-state copies per
+// loop trip for tiles whose successors t + 1, t + 2 exist and are full -- no branch around the S chain, the 8 / 16 LDS-DMA requests
+// per tile or the ragged-tile mask, and the two score register sets swap roles instead of being copied -- and the general copy for
+// the last tiles.
+#ifndef A5B_STEADY_LOOP
+#define A5B_STEADY_LOOP 1
+#endif
 #ifndef A5B_ABL
 #define A5B_ABL 0   // diagnostic builds (tools/ablate_attn.sh): 1 no softmax VALU, 2 no V reads, 4 no DMA, 8 no K reads
 #endif
@@ -193,6 +200,10 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
             dma_one((const char*)(Vb + (int64_t)key * p.v_ts), (uint32_t)((lane ^ ((i & 3) << 2)) << 4), dst);
         }
     };
+    // the same requests for tiles known to be full (the steady-state copy of the loop body): no bounds test, no branch
+    auto dma_kb_fast = [&](int t, int buf, int i) { dma_one(k_tile0 + (int64_t)t * 32 * k_rowb, kvo[i], lds0 + buf * A5B_TILE + (wu * 8 + i) * 1024); };
+    auto dma_k_fast = [&](int t, int i) { dma_kb_fast(t, t & 1, i); };
+    auto dma_v_fast = [&](int t, int i) { dma_one(v_tile0 + (int64_t)t * 32 * v_rowb, vvo[i], lds0 + (2 + (t & 1)) * A5B_TILE + (wu * 8 + i) * 1024); };
     // Software pipeline: iteration t runs S(t+1) beside softmax(t), then PV(t).  K is therefore fetched two tiles ahead
     // of its PV (K(t+2) lands in the buffer S(t) read in iteration t-1), V one tile ahead.
     if constexpr (SH) {   // X(0) -> buffer 0, X(1) -> buffer 1
@@ -319,196 +330,54 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
     __syncthreads();   // every wave has read K(0): iteration 0 overwrites that buffer with K(2)
 
     int b_pv = 0;   // SH: ring position of tile t (t % 3)
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt, more2 = t + 2 < nt;
-        const int b_s = b_pv == 2 ? 0 : b_pv + 1, b_dma = b_pv == 0 ? 2 : b_pv - 1;   // (t + 1) % 3, (t + 2) % 3
-        const int vb = (SH ? b_pv : (t & 1)) * A5B_TILE;
-
-        // ---- online softmax of tile t, register-local (this lane holds 16 of its query's 32 scores, lane^32 the
-        // rest), cut into 8 parts for the hooks of the S(t+1) chain
-        float mx = -INFINITY, alpha = 1.0f, rs = 0.f;
-        bool need = false;
-        v8 pf[2];
-        auto sm = [&](int part) {
-            if (A5B_ABL & 1) {
-                if (part == 6) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[s2][j] = (T)sacc[8 * s2 + j];
-                    asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(l_run));
-                }
-                return;
-            }
-            if (part == 0) {
-                if (k_begin + (t + 1) * 32 > k_end) {   // ragged last tile (uniform branch)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kv = k_begin + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (kv >= k_end) sacc[r] = -INFINITY;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);   // on the raw scores: scale > 0 commutes with max
-                asm volatile("" : "+v"(sacc), "+v"(mx));
-            } else if (part == 1) {
-                mx = a5b_halfwave_max(mx) * p.scale_log2e;
-                // deferred max (T13): the reference point moves only when the tile max exceeds it by more than 2^8, so
-                // the rescale of O (256 accumulator registers through VGPRs) is skipped on almost every tile
-                need = mx > m_run + A5_DEFER_LOG2;   // true on the first tile (m_run = -inf)
-                if (need) {
-                    alpha = __builtin_amdgcn_exp2f(m_run - mx);
-                    m_run = mx;
-                }
-                asm volatile("" : "+v"(alpha), "+v"(m_run));
-            } else if (part >= 2 && part <= 5) {
-                const int r0 = 4 * (part - 2);
-#pragma unroll
-                for (int r = r0; r < r0 + 4; ++r) {
-                    sacc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], p.scale_log2e, -m_run));   // one fma: no scale pass
-                    rs += sacc[r];
-                }
-                asm volatile("" : "+v"(sacc[r0]), "+v"(sacc[r0 + 1]), "+v"(sacc[r0 + 2]), "+v"(sacc[r0 + 3]), "+v"(rs));
-            } else if (part == 6) {
-                l_run = l_run * alpha + rs;
-                // P as the B operand of k-step s: registers 8s..8s+7 <-> keys 16s + 8(j>>2) + 4lh + (j&3)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[s2][j] = (T)sacc[8 * s2 + j];
-                asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(l_run));
-            }
-        };
-        // (each part ends with an empty volatile asm naming what it produced: volatile asms keep their order, so the part
-        // is computed at its hook; without the pins hipcc sinks the whole softmax behind the chain)
-        // the same softmax in 32 parts (A5B_FINE): 0..7 max of two scores each, 8 half-wave exchange + scale, 9 the deferred-max
-        // decision, 10..25 one exponential each (fma + exp2 + row-sum add), 26 the row sum, 27..30 four conversions each
-        auto sm32 = [&](int part) {
-            if (A5B_ABL & 1) {
-                if (part == 30) sm(6);
-                return;
-            }
-            if (part < 8) {
-                if (part == 0 && k_begin + (t + 1) * 32 > k_end) {   // ragged last tile (uniform branch)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kv = k_begin + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (kv >= k_end) sacc[r] = -INFINITY;
-                    }
-                }
-                mx = fmaxf(mx, fmaxf(sacc[2 * part], sacc[2 * part + 1]));
-                asm volatile("" : "+v"(mx));
-            } else if (part == 8) {
-                mx = a5b_halfwave_max(mx) * p.scale_log2e;
-                asm volatile("" : "+v"(mx));
-            } else if (part == 9) {
-                need = mx > m_run + A5_DEFER_LOG2;   // true on the first tile (m_run = -inf)
-                if (need) {
-                    alpha = __builtin_amdgcn_exp2f(m_run - mx);
-                    m_run = mx;
-                }
-                asm volatile("" : "+v"(alpha), "+v"(m_run));
-            } else if (part <= 25) {
-                const int r = part - 10;
-                sacc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], p.scale_log2e, -m_run));
-                rs += sacc[r];
-                asm volatile("" : "+v"(sacc[r]), "+v"(rs));
-            } else if (part == 26) {
-                l_run = l_run * alpha + rs;
-                asm volatile("" : "+v"(l_run));
-            } else if (part <= 30) {
-                const int q4 = part - 27;   // scores 4 q4 .. 4 q4 + 3 -> pf[q4 >> 1][4 (q4 & 1) ..]
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pf[q4 >> 1][4 * (q4 & 1) + j] = (T)sacc[4 * q4 + j];
-                if (q4 & 1) asm volatile("" : "+v"(pf[q4 >> 1]));
-            }
-        };
-
-        f32x16 snext;
-        if (more) {
-#if A5B_FINE
-#define A5B_HOOK(k)                                                   \
-    if constexpr (((k) & 3) == 3) {                                   \
-        if constexpr (SH) {                                           \
-            if (more2) dma_kb(t + 2, b_dma, (k) >> 2);                \
-        } else {                                                      \
-            if (more2) dma_k(t + 2, (k) >> 2);                        \
-            dma_v(t + 1, (k) >> 2);                                   \
-        }                                                             \
-    }                                                                 \
-    sm32(k);                                                          \
-    __builtin_amdgcn_sched_barrier(0)
-#else
-#define A5B_HOOK(i)                                                   \
-    if constexpr (SH) {                                               \
-        if (more2) dma_kb(t + 2, b_dma, i);                           \
-    } else {                                                          \
-        if (more2) dma_k(t + 2, i);                                   \
-        dma_v(t + 1, i);                                              \
-    }                                                                 \
-    sm(i);                                                            \
-    __builtin_amdgcn_sched_barrier(0)
+    int t = 0;
+#if A5B_STEADY_LOOP
+    f32x16 sacc2;
+#define A5B_STEADY 1
+#define A5B_PAIR 1
+#define dma_kb_s dma_kb_fast
+#define dma_k_s dma_k_fast
+#define dma_v_s dma_v_fast
+    for (; t + 4 < nt;) {   // two tiles per trip: tile t scores in sacc, tile t + 1 in sacc2, tile t + 2 in sacc again
+        {
+#define S_CUR sacc
+#define S_NXT sacc2
+#include "attention_d512_body.inc"
+#undef S_CUR
+#undef S_NXT
+        }
+        ++t;
+        {
+#define S_CUR sacc2
+#define S_NXT sacc
+#include "attention_d512_body.inc"
+#undef S_CUR
+#undef S_NXT
+        }
+        ++t;
+    }
+#undef dma_kb_s
+#undef dma_k_s
+#undef dma_v_s
+#undef A5B_PAIR
+#undef A5B_STEADY
 #endif
-            if constexpr (__is_same(T, f16)) {
-                A5B_CHAIN("v_mfma_f32_32x32x16_f16", snext, (SH ? b_s : ((t + 1) & 1)), A5B_HOOK);
-            } else {
-                A5B_CHAIN("v_mfma_f32_32x32x16_bf16", snext, (SH ? b_s : ((t + 1) & 1)), A5B_HOOK);
-            }
-#undef A5B_HOOK
-        } else if (A5B_FINE) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) sm32(i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sm(i);
-        }
-
-        // first V fragments of PV(t)
-        constexpr int VD = 5;
-        auto vread = [&](int n) {
-            const int dt = n >> 1, s2 = n & 1;
-            const int off = vb + vbase[dt & 3] + (dt >> 2) * 256 + (16 * s2) * 1024;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
-            // rows +8 (hf = 1): in the shared image the low swizzle bits are (lh + 2 hf) & 3, i.e. chunk bit 1 flips
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + ((SH ? (off ^ 32) : off) + 8 * 1024)));
-            typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
-            return __builtin_bit_cast(v8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        };
-        v8 vfr[VD];
-#pragma unroll
-        for (int i = 0; i < VD; ++i) vfr[i] = vread(i);
-
-        if (__any(need)) {
-            // O lives in the accumulator file; written as plain C++ (oacc *= alpha) hipcc pulls all 256 values into
-            // VGPRs at once and spills 375 registers.  One element at a time through a scratch VGPR instead; the
-            // write -> MFMA hazard (cdna_hip_programming.md §5.7 item 2) is covered by the s_nop that ends each string,
-            // the MFMA -> read hazard by the 32 S-chain MFMAs (or the epilogue of the previous PV) before this point.
-            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-#pragma unroll
-            for (int dt = 0; dt < 16; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float x = oacc[dt][r], tmp;
-                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1\n\ts_nop 1"
-                                 : "+a"(x), "=&v"(tmp)
-                                 : "v"(alpha));
-                    oacc[dt][r] = x;
-                }
-        }
-
-        // ---- O^T[d][q] += V^T P^T; the A operand (row = d, k = the same key order) is two transposed reads:
-        // elements 0..3 = keys 16s + 4lh + 0..3, elements 4..7 = keys 16s + 8 + 4lh + 0..3.  Explicit fragment ring.
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < 32; ++n) {
-            oacc[n >> 1] = Mfma<T>::mma(vfr[n % VD], pf[n & 1], oacc[n >> 1]);
-            if (n + VD < 32 && !(A5B_ABL & 2)) vfr[n % VD] = vread(n + VD);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) sacc = snext;   // readable by VALU: 32 PV MFMAs have issued since the chain's last MFMA
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of the next tiles have landed
-        __syncthreads();   // everyone done with this tile's buffers
-        b_pv = b_s;
+    for (; t < nt; ++t) {
+#define A5B_PAIR 0
+#define S_CUR sacc
+#define S_NXT snext
+#define A5B_STEADY 0
+#define dma_kb_s dma_kb
+#define dma_k_s dma_k
+#define dma_v_s dma_v
+#include "attention_d512_body.inc"
+#undef dma_kb_s
+#undef dma_k_s
+#undef dma_v_s
+#undef A5B_STEADY
+#undef S_CUR
+#undef S_NXT
+#undef A5B_PAIR
     }
 #undef A5B_NOHOOK
 #undef A5B_MFMA_NAME
