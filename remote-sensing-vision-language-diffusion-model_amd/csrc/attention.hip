@@ -87,7 +87,7 @@ constexpr float A5_DEFER_LOG2 = 8.0f;   // rescale O only when a row's running m
 #define A5B_STEADY_LOOP 1
 #endif
 #ifndef A5B_ABL
-#define A5B_ABL 0   // diagnostic builds (tools/ablate_attn.sh): 1 no softmax VALU, 2 no V reads, 4 no DMA, 8 no K reads
+#define A5B_ABL 0   // diagnostic builds (tools/ablate_attn.sh): 1 no softmax VALU, 2 no V reads, 4 no DMA, 8 no K reads, 16 no per-tile barrier
 #endif
 constexpr int A5B_TILE = 32 * 1024;        // one 32-key x 512 tile, 16-bit
 constexpr int A5B_SMEM = 4 * A5B_TILE;     // K[2] | V[2]

@@ -488,7 +488,9 @@ def attention(q, k, v, heads, scale=None):
     ws = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8) if ws_bytes > 0 else None
     # developer A/B switch (read here, by the Python tools layer: the C ABI reads no environment): RSVLD_D64_KERNEL=b|c|p
     tune = {"b": 1, "c": 2, "p": 3}.get(os.environ.get("RSVLD_D64_KERNEL", ""), 0)
-    _launch(f"attention_d{D}", flops, nbytes, lambda: L.check(
+    # (profiler group: the short cross-attention launches -- 77 text keys -- are a different kernel and a different regime than
+    #  the self-attention of the same layer: kept apart so that the roofline of the dominant group describes ONE kind of launch)
+    _launch(f"attention_d{D}" + ("_cross" if (D == 64 and Nk != Nq) else ""), flops, nbytes, lambda: L.check(
         lib.rsvld_attention_tuned(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
                                   q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                                   out.stride(0), out.stride(1), scale, _dt(q), _PLAN_DIV, _ptr(ws), _stream(), tune),
