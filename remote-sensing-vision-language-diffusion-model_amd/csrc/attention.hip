@@ -525,6 +525,47 @@ __device__ __forceinline__ unsigned long long a6b_stamp() {
 // "trans use" hazard of gfx940+) returned stale values -- every d = 64 test failed with errors of order 1.
 __device__ __forceinline__ float a6b_add(float a, float b) { return a + b; }
 
+// O of one wave's 32 query rows (d = 64): normalised, through a wave-private 4 KiB LDS image (16-byte chunks XOR-swizzled by the
+// row) to whole 128-byte rows -- 16 bytes per lane, eight lanes per row -- instead of 8 bytes per lane at a row stride (32 rows x
+// 2 pieces per store instruction).  LDS operations of one wave complete in order: no barrier.  A6_STAGE_O = 0: the direct stores.
+#ifndef A6_STAGE_O
+#define A6_STAGE_O 1
+#endif
+template <typename T>
+__device__ __forceinline__ void a6_store_o(char* wbuf, const f32x16 (&oacc)[2], float inv, int q0, int lane, const AttnArgs& p, int b, int h) {
+    typedef typename Mfma<T>::v4 v4;
+    const int l31 = lane & 31, lh = lane >> 5;
+    T* Ob = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)h * 64;
+    if (!A6_STAGE_O) {
+        if (q0 + l31 >= p.Nq) return;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (T)(oacc[dt][4 * g + e] * inv);
+                *(v4*)(Ob + (int64_t)(q0 + l31) * p.o_ts + dt * 32 + 8 * g + 4 * lh) = o;
+            }
+        return;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (T)(oacc[dt][4 * g + e] * inv);
+            *(v4*)(wbuf + l31 * 128 + (((dt * 4 + g) ^ (l31 & 7)) << 4) + lh * 8) = o;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (lane >> 3) + 8 * j, chunk = lane & 7;
+        const u32x4 v = *(const u32x4*)(wbuf + row * 128 + ((chunk ^ (row & 7)) << 4));
+        if (q0 + row < p.Nq) *(u32x4*)(Ob + (int64_t)(q0 + row) * p.o_ts + chunk * 8) = v;
+    }
+}
+
 // NW = waves per workgroup: 4 (128 query rows) or 8 (256 query rows).  The 64-key K / V tile is filled once per workgroup,
 // so with 8 waves every wave issues ONE LDS-DMA piece per tensor per tile instead of two and there is one barrier per 256
 // query rows: the in-loop DMA + barrier cost (ablation: +13 % without it at 65 536 tokens) is halved per MFMA.  Two
@@ -948,8 +989,12 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    if (qrow >= p.Nq) return;
     const float inv = 1.0f / l_tot;
+    if (NW <= 8) {   // (the K / V buffers are dead behind the loop's last barrier: 4 KiB of them per wave; NW = 16 has no room)
+        a6_store_o<T>(smem + w * 4096, oacc, inv, q0, lane, p, b, h);
+        return;
+    }
+    if (qrow >= p.Nq) return;
     T* Ob = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)h * D + (int64_t)qrow * p.o_ts;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
