@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64 * NW, A6B_OCC4 ? 4 : 2) void attn_d64b_kernel(At
             // instructions per tile (17 v_max3, the half-wave exchange, the compare) of ~108.
             float rs = exp_and_sum();
             need = (t == 0) || !(rs <= 16384.0f);
-            if (__any(need)) {
+            if (__builtin_expect(__any(need), 0)) {
                 s_phase();
                 float mx = tile_max();
                 {
