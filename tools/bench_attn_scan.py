@@ -5,7 +5,10 @@ import torch
 from rsvld_amd import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-for (B, heads, N) in [(2, 20, 16384), (2, 40, 16384), (4, 20, 16384), (1, 20, 16384), (2, 20, 8192), (2, 20, 32768), (2, 10, 65536), (1, 10, 65536)]:
+SHAPES = [(2, 20, 16384), (2, 40, 16384), (4, 20, 16384), (1, 20, 16384), (2, 20, 8192), (2, 20, 32768), (2, 10, 65536), (1, 10, 65536)]
+if os.environ.get('SCAN2'):
+    SHAPES = [(2, 20, 16384), (1, 40, 16384), (3, 20, 16384), (2, 30, 16384), (2, 16, 16384), (2, 24, 16384), (2, 20, 16384)]
+for (B, heads, N) in SHAPES:
     D = 64
     qkv = torch.randn(B, N, 3 * heads * D, device=dev, dtype=torch.float16)
     q, k, v = qkv[..., :heads * D], qkv[..., heads * D:2 * heads * D], qkv[..., 2 * heads * D:]
@@ -13,7 +16,7 @@ for (B, heads, N) in [(2, 20, 16384), (2, 40, 16384), (4, 20, 16384), (1, 20, 16
         ops.attention(q, k, v, heads)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = int(os.environ.get('REPS', 5))
     e0.record()
     for _ in range(reps):
         ops.attention(q, k, v, heads)
