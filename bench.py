@@ -80,7 +80,7 @@ def build_stage1(T):
     from rsvld_amd.configs import sr3 as SR3
     from rsvld_amd.sr3_model import create_model
     from rsvld_amd.utils import logger as Logger
-    opt = Logger.parse(SR3.SR3_Config())
+    opt = Logger.parse(SR3.SR3_Config(), allow_random_init=True)
     opt["path"]["resume_state"] = None          # no checkpoints offline
     torch.manual_seed(0)
     model = create_model(opt)

@@ -88,7 +88,7 @@ class SuperResolutionPipeline:
         self._load_refinement_model()
 
     def _load_sr3_model(self):
-        opt = Logger.parse(SR3.SR3_Config())
+        opt = Logger.parse(SR3.SR3_Config(), allow_random_init=self.cfg.allow_random_init)
         self.sr3_model = create_model(opt)
         self.sr3_model.netG.denoise_fn.set_compute_dtype(self.cfg.sr3_dtype)
         sched = dict(opt["model"]["beta_schedule"]["val"])

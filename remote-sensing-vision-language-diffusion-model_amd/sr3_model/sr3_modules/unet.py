@@ -160,7 +160,10 @@ class UNet(nn.Module):
     def set_compute_dtype(self, dt):
         """fp16 (default) / bf16: 16-bit storage, fp32 accumulation; fp32: the fp32-operand kernel family (what the reference's
         own Stage 1 computes in: it runs without autocast)."""
-        self.split = dt == "split"      # fp32 tensors, matrix products on split operands (three 16-bit MFMAs per product)
+        split = dt == "split"           # fp32 tensors, matrix products on split operands (three 16-bit MFMAs per product)
+        if split != self.split:         # captured hipGraphs bake the mode in: a new version drops them
+            self.split = split
+            self.pack_version += 1
         dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32, "split": torch.float32}.get(dt, dt)
         if dt not in (torch.float16, torch.bfloat16, torch.float32):
             raise ValueError(f"compute_dtype {dt!r}: fp16, bf16, fp32 or split")

@@ -5,7 +5,10 @@ import os
 from collections import OrderedDict
 
 
-def parse(args):
+def parse(args, allow_random_init=False):
+    """``allow_random_init`` (bench / tests): a configured ``resume_state`` whose ``<resume_state>_gen.pth`` does not exist
+    becomes None (seeded random weights).  Otherwise it raises FileNotFoundError -- the rule of ``create_SR_model``: a wrong
+    checkpoint path must not silently produce noise images (reference: sr3_model/model.py:149-170 loads unconditionally)."""
     json_str = ""
     with open(args.config, "r") as f:
         for line in f:
@@ -23,5 +26,8 @@ def parse(args):
     opt["enable_wandb"] = getattr(args, "enable_wandb", False)
     rs = opt.get("path", {}).get("resume_state")
     if rs is not None and not os.path.exists(f"{rs}_gen.pth"):
-        opt["path"]["resume_state"] = None      # no checkpoint offline: random init
+        if not allow_random_init:
+            raise FileNotFoundError(f"Stage-1 checkpoint {rs}_gen.pth (path.resume_state of {args.config}) does not exist; "
+                                    "pass allow_random_init=True (PipelineConfig.allow_random_init) to run on seeded random weights")
+        opt["path"]["resume_state"] = None
     return opt

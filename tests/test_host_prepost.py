@@ -93,3 +93,22 @@ def test_stage1_loader_vs_fixture(tmp_path):
         got = load_sr_input(p, s)["SR"].numpy()
         side = int(max(w, h) * s)
         assert got.shape == (1, 3, side, side) and np.array_equal(got, want), (i, w, h, s)
+
+
+def test_stage1_option_parser_refuses_a_missing_checkpoint(tmp_path):
+    """A configured-but-missing ``resume_state`` must raise (same rule as ``create_SR_model``), not fall back to random weights
+    (reference: sr3_model/model.py:149-170 loads the file unconditionally); ``allow_random_init`` is the explicit opt-out."""
+    import json
+    from rsvld_amd.configs import sr3 as SR3
+    from rsvld_amd.utils import logger as Logger
+    base = json.loads("".join(l.split("//")[0] for l in open(SR3.SR3_Config.config)))
+    base["path"]["resume_state"] = str(tmp_path / "missing_ckpt")
+    cfg = tmp_path / "opt.json"
+    cfg.write_text(json.dumps(base))
+    args = SR3.SR3_Config()
+    args.config = str(cfg)
+    with pytest.raises(FileNotFoundError):
+        Logger.parse(args)
+    assert Logger.parse(args, allow_random_init=True)["path"]["resume_state"] is None
+    (tmp_path / "missing_ckpt_gen.pth").write_bytes(b"x")
+    assert Logger.parse(args)["path"]["resume_state"] == str(tmp_path / "missing_ckpt")
