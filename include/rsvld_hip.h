@@ -39,6 +39,7 @@ extern "C" {
 #define RSVLD_F16 0
 #define RSVLD_BF16 1
 #define RSVLD_F32 2   /* accepted ONLY by the *_f32 entry points at the end of this header */
+#define RSVLD_SPLIT 3 /* split-operand precision on the 16-bit tilings (rsvld_conv_desc.dtype; the *_split entry points below) */
 
 /* epilogue activations for rsvld_conv2d_nhwc */
 #define RSVLD_ACT_NONE 0
@@ -95,6 +96,15 @@ typedef struct rsvld_conv_desc {
                                          * split into hi + lo bf16 and each product runs as three 16-bit MFMAs into the fp32
                                          * accumulator (~1e-5 relative; the "split" precision of SR_backbone.set_precision)        */
 
+/* dtype = RSVLD_SPLIT (accepted by rsvld_conv2d_nhwc and rsvld_conv3x3_halo_nhwc): the "split" precision of
+ * SR_backbone.set_precision / compute_dtype "split" as a PRODUCT path.  An fp32 activation v travels as two bf16 PLANES per row,
+ *     x, x2 : [B,H,W, lo(C) | hi(C)]   hi = bf16(v), lo = bf16(v - hi)        (Cin / Cin2 stay the LOGICAL channel counts)
+ * and a weight as the per-tap TRIPLE  w : [Cout][KH*KW][ W_hi(Cin+Cin2) | W_lo(Cin+Cin2) | W_hi(Cin+Cin2) ]  (rsvld_split_pack_weights),
+ * so that v W = v_lo W_hi + v_hi W_lo + v_hi W_hi (the dropped lo*lo term is 2^-16 of the product) is ONE bf16 contraction over
+ * 3 (Cin+Cin2) logical channels per tap whose third segment re-reads the hi planes: the 16-bit kernels run unchanged at three MFMAs
+ * per fp32 product, fp32 accumulation.  residual: fp32 [.., Cout_out].  out: fp32 [.., Cout_out] when out_f32 = 1 (the residual
+ * stream), bf16 planes [.., lo(Cout_out) | hi(Cout_out)] when out_f32 = 0 (a tensor that only feeds another matrix product; no
+ * residual then).  The fused GroupNorm prologue of the halo kernel is not available (rsvld_groupnorm_apply_split writes planes). */
 int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
 
 /* 3x3 / stride-1 / pad-1 convolution with an LDS-resident input halo patch (each activation byte crosses
@@ -339,6 +349,54 @@ int rsvld_nchw_f32_to_nhwc_f32(const float* src, float* dst, int B, int C, int H
  * Replaces torch.nn.functional.linear with ONE activation row in the Llama decode step behind models/util.py:17-66
  * (llava/model/language_model/llava_llama.py:118-137): q|k|v, o, gate|up, down projections and lm_head. */
 int rsvld_gemv(const void* w, const void* x, const void* bias, void* y, int N, int K, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Split-operand product path (round 4): the producers / consumers of bf16 PLANES around the RSVLD_SPLIT convolutions.
+ * "planes [rows][2C]" = per row lo(C) | hi(C) of an fp32 [rows][C] tensor (see RSVLD_SPLIT above); C % 8 == 0.
+ * Replaces the same reference calls as the fp32-operand family (models/SR_model.py:28-33,57-85 without autocast;
+ * sgm/modules/diffusionmodules/wrappers.py:84-110; models/sr3_model/sr3_modules/unet.py:81-143).
+ * ------------------------------------------------------------------------------------- */
+/* fp32 [rows][C] -> planes [rows][2C], and back (x = float(hi) + float(lo)) */
+int rsvld_split_planes(const float* x, void* planes, int64_t rows, int C, void* stream);
+int rsvld_merge_planes(const void* planes, float* x, int64_t rows, int C, void* stream);
+/* fp32 K-major weights [Cout][taps][Ctot] -> bf16 triples [Cout][taps][W_hi(Ctot) | W_lo(Ctot) | W_hi(Ctot)] */
+int rsvld_split_pack_weights(const float* w, void* w3, int64_t Cout, int taps, int Ctot, void* stream);
+/* planes [rows][lo(C) | hi(C)] (row stride ld elements, ld >= 2C) -> the TRANSPOSED triple [C][V_hi^T(rows_p) | V_lo^T(rows_p) | V_hi^T(rows_p)]
+ * (rows_p = rows padded with zeros to a multiple of 8): the "weights" of the P V product of an attention run as two split GEMMs */
+int rsvld_planes_transpose_triple(const void* planes, void* w3, int64_t rows, int64_t rows_p, int C, int64_t ld, void* stream);
+/* planes [rows][lo(C) | hi(C)] -> row-wise triple [rows_p][hi(C) | lo(C) | hi(C)] (rows >= rows zero): the "weights" of Q K^T */
+int rsvld_planes_to_triple(const void* planes, void* w3, int64_t rows, int64_t rows_p, int C, int64_t ld, void* stream);
+/* row softmax of fp32 scores s [rows][ld] over the first `cols` columns, p = softmax(scale * s) -> planes [rows][lo(cols_p) | hi(cols_p)]
+ * (cols_p = cols padded to a multiple of 8; pad columns are written as zeros).  One wave per row, two passes. */
+int rsvld_softmax_rows_split(const float* s, void* p_planes, int64_t rows, int cols, int cols_p, int64_t ld, float scale, void* stream);
+/* GroupNorm statistics of fp32 NHWC [x | x2] -> the per-(image, channel) affine (scale, shift) fp32 [B][C1+C2][2]; ws holds
+ * rsvld_groupnorm_ws_bytes(B, HW, C1+C2, groups) bytes.  fp32 partial sums per row chunk, fp64 merge in a fixed order. */
+int rsvld_groupnorm_scale_shift_f32(const float* x, const float* x2, const float* gamma, const float* beta, float* scale_shift,
+                                    int B, int HW, int C1, int C2, int groups, float eps, void* ws, void* stream);
+/* statistics only, (mean, biased variance) fp32 [B][groups][2], through the same coalesced pass (the tiled VAE merges them across
+ * tiles, utils/tilevae.py:629-648), and the affine of SUPPLIED statistics */
+int rsvld_groupnorm_stats_f32_fast(const float* x, const float* x2, float* mean_var, int B, int HW, int C1, int C2, int groups,
+                                   void* ws, void* stream);
+int rsvld_groupnorm_scale_shift_from_stats(const float* mean_var, const float* gamma, const float* beta, float* scale_shift,
+                                           int B, int C, int groups, float eps, void* stream);
+/* y = act(scale * [x | x2] + shift) [* (1 + mod_scale1p) + mod_shift] from fp32 NHWC inputs; out: planes [B,HW, 2(C1+C2)]
+ * (out_f32 = 0) or fp32 [B,HW,C1+C2] (out_f32 = 1).  mod_* fp32 with row stride mod_stride (ZeroSFT, SR_modules.py:100-106). */
+int rsvld_groupnorm_apply_split(const float* x, const float* x2, void* out, const float* scale_shift,
+                                const float* mod_scale1p, const float* mod_shift, int mod_stride,
+                                int B, int HW, int C1, int C2, int silu, int out_f32, void* stream);
+/* LayerNorm of fp32 rows -> planes [rows][2C] (out_f32 = 0) or fp32 (out_f32 = 1); C % 8 == 0, C <= 4096 */
+int rsvld_layernorm_split(const float* x, void* out, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                          int out_f32, void* stream);
+/* Flash attention on planes, D = 64 (sgm CrossAttention at sgm/modules/attention.py:357-359 under diffusion_dtype "split"):
+ * q / k / v point at the LO plane of element (b, n, h, d) = base + b*batch_stride + n*tok_stride + h*64 + d, the HI plane sits
+ * *_plane elements further; three bf16 MFMAs per product in both contractions, fp32 softmax.  out: planes (o_plane = distance of
+ * its hi plane, out_f32 = 0) or fp32 (out_f32 = 1). */
+int rsvld_attention_split_d64(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
+                              int64_t q_batch_stride, int64_t q_tok_stride, int64_t q_plane,
+                              int64_t k_batch_stride, int64_t k_tok_stride, int64_t k_plane,
+                              int64_t v_batch_stride, int64_t v_tok_stride, int64_t v_plane,
+                              int64_t o_batch_stride, int64_t o_tok_stride, int64_t o_plane,
+                              float scale, int out_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RSVLD_LIB") or os.path.join(_PKG_DIR, "librsvld_hip.so")
 
 F16, BF16, F32 = 0, 1, 2   # F32: the *_f32 entry points only (fp32-operand VAE family)
+SPLIT = 3                   # rsvld_conv_desc.dtype: bf16 planes + weight triples (the split-operand product path)
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 # rsvld_conv_desc.tune (developer A/B overrides)
 TUNE_TILE = {"256x64": 1, "128x64": 2, "128x128": 3, "64x128": 4}
@@ -94,6 +95,19 @@ SIGNATURES = {
     "rsvld_attention_f32_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
                                  _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp]),
     "rsvld_nchw_f32_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "rsvld_split_planes": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "rsvld_merge_planes": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "rsvld_split_pack_weights": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "rsvld_planes_transpose_triple": (_i, [_vp, _vp, _i64, _i64, _i, _i64, _vp]),
+    "rsvld_planes_to_triple": (_i, [_vp, _vp, _i64, _i64, _i, _i64, _vp]),
+    "rsvld_softmax_rows_split": (_i, [_vp, _vp, _i64, _i, _i, _i64, _f, _vp]),
+    "rsvld_groupnorm_scale_shift_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "rsvld_groupnorm_stats_f32_fast": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rsvld_groupnorm_scale_shift_from_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "rsvld_groupnorm_apply_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsvld_layernorm_split": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
+    "rsvld_attention_split_d64": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                       _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _vp]),
 }
 
 _lib = None

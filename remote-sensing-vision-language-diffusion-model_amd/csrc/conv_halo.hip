@@ -40,6 +40,9 @@ struct HaloArgs {
     int tiles_y8;           // rows of the 8x32-pixel grid of the statistics partials
     int rv_stride, Cout_out;
     int B_plan, tune;       // batch rows the launch plan is made for (B / plan_div); RSVLD_TUNE_*
+    // dtype RSVLD_SPLIT (round 4; see gemm.hip): x / x2 are bf16 planes [.., lo(C) | hi(C)], the weights the per-tap triple
+    // [W_hi | W_lo | W_hi]; Ctot = 3 Cseg logical channels whose third segment re-reads the hi planes; fp32 residual, fp32 / planes out
+    int split, Cseg;
 };
 
 constexpr int TH = 8, TW = 32, PW = TW + 2, PROWS = (TH + 2) * PW;   // 340 patch pixels
@@ -56,6 +59,19 @@ __device__ __forceinline__ int swz_off(int row, int c) { return row * 128 + ((c 
 // per-lane part of a tap's read address a function of (kx, k-step) alone: 12 precomputed registers, the rest is an
 // immediate offset -- no address arithmetic inside the tap loop.
 __device__ __forceinline__ int patch_off(int py, int px, int c) { return (py * PW + px) * 128 + ((c ^ ((px >> 1) & 7)) << 4); }
+
+// logical channel ch0 (start of a 32- or 64-channel chunk) -> source tensor (0: x, 1: x2), channel inside a pixel's row, elements per
+// pixel.  Split: segment 0 = lo planes, segments 1, 2 = hi planes; a pixel's row holds lo | hi.
+__device__ __forceinline__ void halo_src_of(const HaloArgs& p, int ch0, int& which, int& Cs, int& coff) {
+    if (!p.split) {
+        if (ch0 < p.Cin) { which = 0; Cs = p.Cin; coff = ch0; } else { which = 1; Cs = p.Cin2; coff = ch0 - p.Cin; }
+        return;
+    }
+    int hi = 0;
+    if (ch0 >= p.Cseg) { ch0 -= p.Cseg; hi = 1; }
+    if (ch0 >= p.Cseg) ch0 -= p.Cseg;
+    if (ch0 < p.Cin) { which = 0; Cs = 2 * p.Cin; coff = ch0 + hi * p.Cin; } else { which = 1; Cs = 2 * p.Cin2; coff = ch0 - p.Cin + hi * p.Cin2; }
+}
 
 // ---- epilogue shared by the halo kernels: accumulators -> LDS (fp32) -> bias / row vector / SiLU / residual ->
 // 16-byte NHWC stores, plus the per-channel (sum, sumsq) partials of every 8x32-pixel sub-tile for the next GroupNorm.
@@ -86,7 +102,7 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
         // The residual pieces of this pass are requested BEFORE the staging writes and their barrier, so that the HBM round trip
         // runs under them (one row at a time every store waited for its own residual load; same change as in gemm.hip).
         u32x4 rres[RPT];
-        if (p.residual != nullptr && n < p.Cout) {
+        if (p.residual != nullptr && n < p.Cout && !p.split) {
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const int prow = pass * EPI_ROWS + rr + j * RPP;
@@ -136,7 +152,14 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
                 for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
                 if (p.residual != nullptr) {
                     float rf[8];
-                    unpack8<T>(rres[j], rf);
+                    if (p.split) {   // fp32 residual
+                        const float* r = (const float*)p.residual + m * p.Cout_out + n;
+                        const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { rf[e] = r0[e]; rf[4 + e] = r1[e]; }
+                    } else {
+                        unpack8<T>(rres[j], rf);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += p.beta * rf[e];
                 }
@@ -144,7 +167,15 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
                 }
-                if (p.out_f32) {
+                if (p.split && !p.out_f32) {   // planes: lo | hi per pixel row
+                    float lo[8];
+                    typename Mfma<T>::v8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { hv[e] = (T)v[e]; lo[e] = v[e] - (float)hv[e]; }
+                    T* ob = (T*)p.out + m * (2 * p.Cout_out) + n;
+                    *(u32x4*)ob = pack8<T>(lo);
+                    *(u32x4*)(ob + p.Cout_out) = __builtin_bit_cast(u32x4, hv);
+                } else if (p.out_f32) {
                     float* o = (float*)p.out + m * p.Cout_out + n;
                     *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
                     *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -221,17 +252,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
         // with ush = 1 the conv runs on the nearest-x2 up-sampled map: output-grid pixel (y, x) reads source (y>>1, x>>1)
         poff[i] = (pp < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y >> p.ush) * p.Ws + (x >> p.ush) : -1;
     }
-    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * p.Cin;
-    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * p.Cin2 : nullptr;
+    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * (p.split ? 2 * p.Cin : p.Cin);
+    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * (p.split ? 2 * p.Cin2 : p.Cin2) : nullptr;
     const T* __restrict__ Wp = (const T*)p.w;
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
     u32x4 rp[PLOADS];
     auto load_patch = [&](int kc) {
-        const int ch0 = kc * 64;
-        const T* src;
-        int Cs, coff;
-        if (ch0 < p.Cin) { src = X1; Cs = p.Cin; coff = ch0 + c * 8; } else { src = X2; Cs = p.Cin2; coff = ch0 - p.Cin + c * 8; }
+        int which, Cs, coff;
+        halo_src_of(p, kc * 64, which, Cs, coff);
+        const T* src = which ? X2 : X1;
+        coff += c * 8;
 #pragma unroll
         for (int i = 0; i < PLOADS; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
@@ -452,17 +483,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
         // dead target: the duplicate half of (scale, shift) buffer 0, never read
         pdst[i] = pp < PR ? p32_off(py, px, c4) : (int)(abuf - patch) + 512 + (tid & 31) * 16;
     }
-    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * p.Cin;
-    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * p.Cin2 : nullptr;
+    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * (p.split ? 2 * p.Cin : p.Cin);
+    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * (p.split ? 2 * p.Cin2 : p.Cin2) : nullptr;
     const T* __restrict__ Wp = (const T*)p.w;
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
     u32x4 rp[PL];
     auto issue_patch = [&](int k32, u32x4 (&r)[PL]) {
-        const int ch0 = k32 * 32;
-        const T* src;
-        int Cs, coff;
-        if (ch0 < p.Cin) { src = X1; Cs = p.Cin; coff = ch0 + c4 * 8; } else { src = X2; Cs = p.Cin2; coff = ch0 - p.Cin + c4 * 8; }
+        int which, Cs, coff;
+        halo_src_of(p, k32 * 32, which, Cs, coff);
+        const T* src = which ? X2 : X1;
+        coff += c4 * 8;
 #pragma unroll
         for (int i = 0; i < PL; ++i) {
             const T* ptr = src + (int64_t)(poff[i] < 0 ? 0 : poff[i]) * Cs + coff;   // padding reads a valid dummy, zeroed later
@@ -712,7 +743,7 @@ extern "C" int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d) {
     if (d->Ho != up * d->H || d->Wo != up * d->W) return 0;
     if (d->Cin % 64 != 0 || d->Cin2 % 64 != 0) return 0;
     if (d->act == RSVLD_ACT_GEGLU) return 0;
-    if (d->out_f32 && d->Cout > 32) return 0;
+    if (d->out_f32 && d->Cout > 32 && d->dtype != RSVLD_SPLIT) return 0;
     if (d->Wo < 16 || d->Ho < 4) return 0;   // tiny maps: the 8x32 tile would be mostly padding
     return 1;
 }
@@ -723,20 +754,25 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     if (d->x == nullptr || d->w == nullptr || d->out == nullptr) return RSVLD_EINVAL;
     if (d->B <= 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
     if ((d->Cin2 > 0) != (d->x2 != nullptr)) return RSVLD_EINVAL;
-    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16) return RSVLD_EINVAL;
+    const bool split = d->dtype == RSVLD_SPLIT;
+    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16 && !split) return RSVLD_EINVAL;
+    if (split && norm_scale_shift != nullptr) return RSVLD_EUNSUPPORTED;   // the normalised tensor is split by its own kernel (rsvld_groupnorm_apply_split)
+    if (split && !d->out_f32 && d->residual != nullptr) return RSVLD_EINVAL;
     if ((int64_t)d->Ho * d->Wo >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
     if (norm_scale_shift != nullptr && d->upsample) return RSVLD_EUNSUPPORTED;   // no GroupNorm sits before an Upsample conv
     HaloArgs a;
     a.x = d->x; a.x2 = d->x2; a.w = d->w; a.bias = d->bias; a.rowvec = d->rowvec; a.residual = d->residual; a.out = d->out;
     a.ab = norm_scale_shift;
-    a.stats = d->out_f32 ? nullptr : out_stats_partials;
+    a.stats = (d->out_f32 && !split) ? nullptr : out_stats_partials;
+    a.split = split ? 1 : 0;
+    a.Cseg = d->Cin + d->Cin2;
     a.B = d->B; a.H = d->Ho; a.W = d->Wo; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
     a.B_plan = d->plan_div > 1 ? (d->B + d->plan_div - 1) / d->plan_div : d->B;
     a.tune = d->tune;
     a.Hs = d->H; a.Ws = d->W; a.ush = d->upsample ? 1 : 0;
     a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.norm_silu = norm_silu ? 1 : 0;
     a.alpha = d->alpha; a.beta = d->beta;
-    a.Ctot = d->Cin + d->Cin2;
+    a.Ctot = (split ? 3 : 1) * (d->Cin + d->Cin2);
     a.nchunks = a.Ctot / 64;
     a.tiles_x = (d->Wo + TW - 1) / TW;
     a.tiles_y = (d->Ho + TH - 1) / TH;
@@ -744,5 +780,5 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
     a.Cout_out = d->Cout;
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == RSVLD_F16 ? dispatch_halo<f16>(a, s) : dispatch_halo<bf16>(a, s);
+    return d->dtype == RSVLD_F16 ? dispatch_halo<f16>(a, s) : dispatch_halo<bf16>(a, s);   // RSVLD_SPLIT runs the bf16 kernels
 }

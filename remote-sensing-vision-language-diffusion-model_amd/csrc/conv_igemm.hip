@@ -21,6 +21,11 @@
 //
 // Fusions: nearest x2 up-sampling of the input (index >>1), channel concatenation of two
 // inputs, bias, per-image row vector (time embedding), residual add, SiLU / GEGLU.
+//
+// dtype RSVLD_SPLIT (round 4, the split-operand precision on this tiling; see gemm.hip): x / x2 are bf16 PLANES [.., lo(C) | hi(C)]
+// of fp32 activations, the weights are packed per tap as the triple [W_hi | W_lo | W_hi] over the concatenated channels, and the
+// kernel runs as a bf16 convolution over 3 (Cin + Cin2) logical channels per tap whose third segment re-reads the hi planes:
+// x_lo W_hi + x_hi W_lo + x_hi W_hi.  Residual fp32; output fp32 (out_f32) or planes.
 #include <stdlib.h>
 #include <string.h>
 
@@ -51,6 +56,9 @@ struct ConvArgs {
     int rv_stride; // row stride of rowvec
     int M_plan;    // rows the launch plan is made for (M / plan_div)
     int tune;      // RSVLD_TUNE_*
+    int split;     // RSVLD_SPLIT: planes in, triple weights; Ctot8 / KC then count the 3 (Cin + Cin2) LOGICAL channels
+    int Cseg8;     // split: (Cin + Cin2) / 8, the chunks of one segment
+    int C2_8;      // Cin2 / 8
 };
 
 constexpr int BK_BYTES = 128;  // 64 x 16-bit per LDS row
@@ -150,11 +158,24 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
 
     u32x4 ra[A_LOADS], rb[B_LOADS];
 
+    // logical 8-channel chunk -> (source tensor, chunk inside a pixel's row, elements per pixel).  Split: segment 0 reads the lo
+    // planes, segments 1 and 2 the hi planes; a pixel's row holds lo | hi.
+    auto src_of = [&](int ch, const T*& src, int& cc, int& Cs) {
+        if (!p.split) {
+            if (ch < p.C1_8) { src = X1; cc = ch; Cs = p.Cin; } else { src = X2; cc = ch - p.C1_8; Cs = p.Cin2; }
+            return;
+        }
+        int hi = 0;
+        if (ch >= p.Cseg8) { ch -= p.Cseg8; hi = 1; }
+        if (ch >= p.Cseg8) ch -= p.Cseg8;
+        if (ch < p.C1_8) { src = X1; cc = ch + hi * p.C1_8; Cs = 2 * p.Cin; } else { src = X2; cc = ch - p.C1_8 + hi * p.C2_8; Cs = 2 * p.Cin2; }
+    };
+
     auto load_tile = [&](int kt) {
         const bool kvalid = ky < p.KH;
         const T* src;
         int cc, Cs;
-        if (ci < p.C1_8) { src = X1; cc = ci; Cs = p.Cin; } else { src = X2; cc = ci - p.C1_8; Cs = p.Cin2; }
+        src_of(ci, src, cc, Cs);
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
         const bool kvalid = ky < p.KH;
         const T* src;
         int cc, Cs;
-        if (ci < p.C1_8) { src = X1; cc = ci; Cs = p.Cin; } else { src = X2; cc = ci - p.C1_8; Cs = p.Cin2; }
+        src_of(ci, src, cc, Cs);
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
@@ -300,7 +321,7 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
     // the residual pieces this thread will add on the way out are requested before the staging pass (their HBM round trip
     // runs under it; same change as in gemm.hip / conv_halo.hip)
     u32x4 rres[RPT];
-    if (p.residual != nullptr && n < p.Cout && p.act != RSVLD_ACT_GEGLU) {
+    if (p.residual != nullptr && n < p.Cout && p.act != RSVLD_ACT_GEGLU && !p.split) {
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const int row = rr + j * RPP;
@@ -347,6 +368,50 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
             const float* rv = p.rowvec + (int64_t)img * p.rv_stride + n;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        if (p.split) {   // fp32 residual; fp32 or planes (lo | hi per row) out
+            if (p.act == RSVLD_ACT_GEGLU) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = p.alpha * v[2 * e] * gelu_erf_f(v[2 * e + 1]);
+                if (p.out_f32) {
+                    *(f32x4*)((float*)p.out + (int64_t)m * p.Cout_out + (n >> 1)) = (f32x4){o[0], o[1], o[2], o[3]};
+                } else {
+                    typename Mfma<T>::v4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { oh[e] = (T)o[e]; ol[e] = (T)(o[e] - (float)oh[e]); }
+                    T* ob = (T*)p.out + (int64_t)m * (2 * p.Cout_out) + (n >> 1);
+                    *(typename Mfma<T>::v4*)ob = ol;
+                    *(typename Mfma<T>::v4*)(ob + p.Cout_out) = oh;
+                }
+                continue;
+            }
+            if (p.act == RSVLD_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+            if (p.residual != nullptr) {
+                const float* r = (const float*)p.residual + (int64_t)m * p.Cout_out + n;
+                const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += p.beta * r0[e]; v[4 + e] += p.beta * r1[e]; }
+            }
+            if (p.out_f32) {
+                float* o = (float*)p.out + (int64_t)m * p.Cout_out + n;
+                *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            } else {
+                float lo[8];
+                typename Mfma<T>::v8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { hv[e] = (T)v[e]; lo[e] = v[e] - (float)hv[e]; }
+                T* ob = (T*)p.out + (int64_t)m * (2 * p.Cout_out) + n;
+                *(u32x4*)ob = pack8<T>(lo);
+                *(u32x4*)(ob + p.Cout_out) = __builtin_bit_cast(u32x4, hv);
+            }
+            continue;
         }
         if (p.act == RSVLD_ACT_GEGLU) {
             // channels are (value, gate) interleaved: 4 outputs per 8 accumulators
@@ -457,8 +522,10 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     if (d->Cin <= 0 || d->Cin % 8 != 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
     if (d->Cin2 < 0 || d->Cin2 % 8 != 0 || ((d->Cin2 > 0) != (d->x2 != nullptr))) return RSVLD_EINVAL;
     if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return RSVLD_EINVAL;
-    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16) return RSVLD_EINVAL;
-    if (d->out_f32 && (d->Cout > 32 || d->act == RSVLD_ACT_GEGLU || d->residual != nullptr)) return RSVLD_EUNSUPPORTED;
+    const bool split = d->dtype == RSVLD_SPLIT;
+    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16 && !split) return RSVLD_EINVAL;
+    if (!split && d->out_f32 && (d->Cout > 32 || d->act == RSVLD_ACT_GEGLU || d->residual != nullptr)) return RSVLD_EUNSUPPORTED;
+    if (split && !d->out_f32 && d->residual != nullptr) return RSVLD_EINVAL;   // planes out: no residual (the stream stays fp32)
     if (d->act == RSVLD_ACT_GEGLU && (d->Cout % 16 != 0 || d->residual != nullptr)) return RSVLD_EINVAL;
     if ((int64_t)d->B * d->Ho * d->Wo >= (int64_t)1 << 31) return RSVLD_EUNSUPPORTED;
     if ((int64_t)d->B * d->H * d->W >= (int64_t)1 << 31) return RSVLD_EUNSUPPORTED;
@@ -492,11 +559,14 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     a.tune = d->tune;
     a.HoWo = d->Ho * d->Wo;
     a.C1_8 = d->Cin / 8;
-    a.Ctot8 = (d->Cin + d->Cin2) / 8;
+    a.C2_8 = d->Cin2 / 8;
+    a.split = split ? 1 : 0;
+    a.Cseg8 = (d->Cin + d->Cin2) / 8;
+    a.Ctot8 = (split ? 3 : 1) * a.Cseg8;
     a.KC = d->KH * d->KW * a.Ctot8;
     a.nk = (a.KC + 7) / 8;
     a.Cout_out = d->act == RSVLD_ACT_GEGLU ? d->Cout / 2 : d->Cout;
     a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == RSVLD_F16 ? dispatch_conv<f16>(a, s) : dispatch_conv<bf16>(a, s);
+    return d->dtype == RSVLD_F16 ? dispatch_conv<f16>(a, s) : dispatch_conv<bf16>(a, s);   // RSVLD_SPLIT runs the bf16 kernels
 }

@@ -16,6 +16,14 @@
 //     construction: tile t+3 is written one barrier after the last read of tile t-1 has RETURNED.
 // The MFMA A operand is the weight tile, the B operand the activation tile: a lane owns one output row (token) and,
 // per accumulator quad, four consecutive output channels (8-byte stores; GEGLU pairs are adjacent channels).
+//
+// SPLIT instantiation (round 4; dtype RSVLD_SPLIT): the split-operand precision on THIS tiling.  An fp32 activation x is stored as two
+// bf16 planes per row, [lo(K) | hi(K)] with hi = bf16(x), lo = bf16(x - hi); a weight row as the triple [W_hi(K) | W_lo(K) | W_hi(K)].
+// The product x W^T = x_lo W_hi + x_hi W_lo + x_hi W_hi (+ the dropped 2^-16 term) is then ONE bf16 GEMM over the concatenated
+// K' = 3 K: the K loop below runs 3 K / 32 tiles, the weight pointer walks its row linearly and the activation pointer walks
+// lo, hi and re-reads hi (one scalar select per LDS-DMA piece).  Small terms first.  Same ring, same ping-pong, same MFMA count
+// per product as any 3-MFMA scheme, and the epilogue is amortised over three times the K loop.  Output: fp32 [M][N_out]
+// (+ beta * fp32 residual) or bf16 planes [M][lo(N_out) | hi(N_out)] for a tensor that only feeds another matrix product.
 #include <stdlib.h>
 
 #include "rsvld_common.h"
@@ -32,6 +40,7 @@ struct GemmArgs {
     int M, N, K, N_out;
     int act;
     float alpha, beta;
+    int out_planes;        // SPLIT only: 1 = bf16 planes out, 0 = fp32 out
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -66,7 +75,7 @@ __device__ __forceinline__ int g_off(int row, int slot) { return row * 64 + ((sl
 
 template <int N> __device__ __forceinline__ void g_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     typedef typename Mfma<T>::v8 v8;
     typedef typename Mfma<T>::v4 v4;
@@ -88,8 +97,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         tile_m = t - tile_n * nmt;
     }
     const int m0 = tile_m * 256, n0 = tile_n * 256;
-    const int nk = (G_ABL & 4) ? 3 : (p.K >> 5);   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
-    const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T);
+    const int nk0 = p.K >> 5;
+    const int nk = (G_ABL & 4) ? 3 : (SPLIT ? 3 * nk0 : nk0);   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
+    const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 2 : 1);    // activation row: K values, or the planes lo | hi
+    const int64_t rowb_w = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 3 : 1);  // weight row: K values, or the triple hi | lo | hi
     if (G_STAGGER > 0) {
         const int lid = blockIdx.x + blockIdx.y * gridDim.x;
         if (lid < 256 && ((lid >> 3) & 1))
@@ -104,11 +115,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     for (int i = 0; i < 2; ++i) {
         const int r = 32 * wave + 16 * i + (lane >> 2);
         const uint32_t ch = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-        xvo[i] = (uint32_t)((int64_t)min(m0 + r, p.M - 1) * rowb) + ch;
-        wvo[i] = (uint32_t)((int64_t)min(n0 + r, p.N - 1) * rowb) + ch;
+        // offsets relative to the TILE's first row (the scalar bases below carry the 64-bit part): 256 rows x row bytes < 2^32
+        xvo[i] = (uint32_t)((int64_t)(min(m0 + r, p.M - 1) - m0) * rowb) + ch;
+        wvo[i] = (uint32_t)((int64_t)(min(n0 + r, p.N - 1) - n0) * rowb_w) + ch;
     }
-    const char* Xb = (const char*)p.x;
-    const char* Wb = (const char*)p.w;
+    const char* Xb = (const char*)p.x + (int64_t)m0 * rowb;
+    const char* Wb = (const char*)p.w + (int64_t)n0 * rowb_w;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     // j = 0..3: (X, W) x (rows 0..15, 16..31) of this wave's share of tile kt.
     // G_ASMDMA: the builtin made hipcc form a per-lane 64-bit address for every piece -- a v_lshl_add_u64 INTO the fragment
@@ -119,12 +131,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     auto dma_piece = [&](int kt, int j) {
 #if G_ASMDMA
         const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024);
-        const char* base = ((j & 1) ? Wb : Xb) + kt * 64;
+        // SPLIT: the activation planes are read lo, hi, hi (tiles >= 2 nk0 alias the hi plane); the weight triple is linear
+        const int ktx = (SPLIT && kt >= 2 * nk0) ? kt - nk0 : kt;
+        const char* base = (j & 1) ? Wb + kt * 64 : Xb + ktx * 64;
         const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[j >> 1];
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
 #else
         char* st = smem + (kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024;
-        const char* src = ((j & 1) ? Wb : Xb) + kt * 64;
+        const int ktx = (SPLIT && kt >= 2 * nk0) ? kt - nk0 : kt;
+        const char* src = (j & 1) ? Wb + kt * 64 : Xb + ktx * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)(src + ((j & 1) ? wvo[j >> 1] : xvo[j >> 1])), (lptr_t)st, 16, 0, 0);
 #endif
     };
@@ -297,6 +312,103 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #if G_ABL & 2
     if (p.M > 0) return;   // diagnostic build: no epilogue at all (the accumulators stay live for the compiler)
 #endif
+
+    if constexpr (SPLIT) {
+        // ---- SPLIT epilogue: the 256 x 256 fp32 tile (256 KiB; as planes lo | hi the same bytes) does not fit the 128 KiB ring, so it
+        // leaves in two halves of 128 rows = the rows of group 0, then of group 1: the owning group stages bias / activation / alpha
+        // in registers -> LDS (16-byte chunks XOR-swizzled by the row), all 512 threads move whole 16-byte chunks out as contiguous
+        // runs and add the fp32 residual on that side.  Twice the bytes of the 16-bit epilogue behind three times its K loop.
+        const bool geglu = p.act == RSVLD_ACT_GEGLU;
+        const int ncol = geglu ? 128 : 256;                       // columns of the stored tile
+        const int n_out0 = geglu ? (n0 >> 1) : n0;
+        const bool planes = p.out_planes != 0;
+        // fp32: row = ncol * 4 bytes = ncol / 4 chunks; planes: row = lo (ncol * 2 bytes) | hi (ncol * 2 bytes) = ncol / 4 chunks as well
+        const int rchunks = ncol >> 2;                            // 64 or 32 16-byte chunks per staged row
+        const int rbytes = rchunks << 4;
+        auto s_off = [&](int row, int chunk) { return row * rbytes + ((chunk ^ (row & 15)) << 4); };
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            if (grp == half) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = wn * 64 + ni * 32 + 8 * g + 4 * lh;                    // tile column of the quad
+                        const f32x4 bq = *(const f32x4*)(smem + G_RING + col * 4);             // zeros without a bias / past N
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) {
+                            const int row = mi * 32 + l31;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e] + bq[e];
+                            if (geglu) {   // (value, gate) interleaved: 2 outputs per quad, output column col / 2
+                                const float o0 = p.alpha * v[0] * gelu_erf_f(v[1]), o1 = p.alpha * v[2] * gelu_erf_f(v[3]);
+                                const int oc = col >> 1;
+                                if (planes) {
+                                    const bf16 h0 = (bf16)o0, h1 = (bf16)o1;
+                                    const bf16 lo2[2] = {(bf16)(o0 - (float)h0), (bf16)(o1 - (float)h1)}, hi2[2] = {h0, h1};
+                                    uint32_t pl, ph;
+                                    __builtin_memcpy(&pl, lo2, 4);
+                                    __builtin_memcpy(&ph, hi2, 4);
+                                    *(uint32_t*)(smem + s_off(row, oc >> 3) + (oc & 7) * 2) = pl;
+                                    *(uint32_t*)(smem + s_off(row, (rchunks >> 1) + (oc >> 3)) + (oc & 7) * 2) = ph;
+                                } else {
+                                    *(u32x2*)(smem + s_off(row, oc >> 2) + (oc & 3) * 4) =
+                                        (u32x2){__builtin_bit_cast(uint32_t, o0), __builtin_bit_cast(uint32_t, o1)};
+                                }
+                            } else {
+                                if (p.act == RSVLD_ACT_SILU) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                                }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+                                if (planes) {
+                                    bf16x4 h, l;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        h[e] = (bf16)v[e];
+                                        l[e] = (bf16)(v[e] - (float)h[e]);
+                                    }
+                                    *(bf16x4*)(smem + s_off(row, col >> 3) + (col & 7) * 2) = l;
+                                    *(bf16x4*)(smem + s_off(row, (rchunks >> 1) + (col >> 3)) + (col & 7) * 2) = h;
+                                } else {
+                                    *(f32x4*)(smem + s_off(row, col >> 2)) = (f32x4){v[0], v[1], v[2], v[3]};
+                                }
+                            }
+                        }
+                    }
+            }
+            __syncthreads();
+            // 128 rows x rchunks chunks; thread -> chunk tid % rchunks of rows tid / rchunks + i * (512 / rchunks)
+            const int chunk = tid & (rchunks - 1);
+            const int rstep = 512 / rchunks;                      // 8 or 16 rows per pass
+            const bool hi_sec = planes && chunk >= (rchunks >> 1);
+            // global column (elements) of this chunk: fp32 = 4 columns per chunk; planes = 8 columns per chunk inside its section
+            const int ocol = planes ? n_out0 + (chunk - (hi_sec ? (rchunks >> 1) : 0)) * 8 : n_out0 + chunk * 4;
+            if (ocol < p.N_out) {
+                for (int row = tid / rchunks; row < 128; row += rstep) {
+                    const int m = m0 + half * 128 + row;
+                    if (m >= p.M) break;
+                    u32x4 v = *(const u32x4*)(smem + s_off(row, chunk));
+                    if (planes) {
+                        bf16* o = (bf16*)p.out + (int64_t)m * (2 * p.N_out) + (hi_sec ? p.N_out : 0) + ocol;
+                        *(u32x4*)o = v;
+                    } else {
+                        f32x4 f = __builtin_bit_cast(f32x4, v);
+                        if (p.residual != nullptr) {
+                            const f32x4 r = *(const f32x4*)((const float*)p.residual + (int64_t)m * p.N_out + ocol);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) f[e] += p.beta * r[e];
+                        }
+                        *(f32x4*)((float*)p.out + (int64_t)m * p.N_out + ocol) = f;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // ---- epilogue through LDS (the ring is dead after the last barrier): a lane owns one output row and, per register
     // quad, four consecutive channels, i.e. 8-byte pieces 512 B apart -- stored like that the 128 KiB tile leaves the
     // CU in 16-byte fragments (measured: 17 us per tile, more than the K loop of a K = 640 layer).  So: bias / SiLU /
@@ -455,9 +567,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 // Eligibility + launch, called from rsvld_conv2d_nhwc for 1x1 / stride-1 / single-source layers.
 // Returns RSVLD_EUNSUPPORTED when the shape should stay on the implicit-GEMM kernel.
 int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
+    const bool split = d->dtype == RSVLD_SPLIT;
     if (d->tune & RSVLD_TUNE_NO_GEMM256) return RSVLD_EUNSUPPORTED;   // A/B switch
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad_t != 0 || d->pad_l != 0 || d->upsample) return RSVLD_EUNSUPPORTED;
-    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || d->out_f32) return RSVLD_EUNSUPPORTED;
+    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || (d->out_f32 && !split)) return RSVLD_EUNSUPPORTED;
     if (d->Cin % 32 != 0 || d->Cout % 8 != 0) return RSVLD_EUNSUPPORTED;
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     if (d->H != d->Ho || d->W != d->Wo) return RSVLD_EUNSUPPORTED;
@@ -466,13 +579,16 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     if (d->Cout < 256 || Mp < 4096) return RSVLD_EUNSUPPORTED;
     const int64_t tiles = ((Mp + 255) / 256) * ((d->Cout + 255) / 256);
     if (tiles < 128) return RSVLD_EUNSUPPORTED;   // one workgroup per CU; measured: from half the chip up it beats the 128x128 kernel
-    if (M * d->Cin * 2 >= ((int64_t)1 << 32) || (int64_t)d->Cout * d->Cin * 2 >= ((int64_t)1 << 32)) return RSVLD_EUNSUPPORTED;
+    // 32-bit lane offsets inside a tile: 256 rows of the activation tensor (planes: 2 K per row) / of the weights (triple: 3 K)
+    if ((int64_t)256 * d->Cin * (split ? 6 : 2) >= ((int64_t)1 << 32) || M >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
     if (d->act == RSVLD_ACT_GEGLU && (d->Cout % 16 != 0 || d->residual != nullptr)) return RSVLD_EINVAL;
+    if (split && !d->out_f32 && d->residual != nullptr) return RSVLD_EINVAL;   // planes out: no residual (the stream stays fp32)
     GemmArgs a;
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.residual = d->residual; a.out = d->out;
     a.M = (int)M; a.N = d->Cout; a.K = d->Cin;
     a.N_out = d->act == RSVLD_ACT_GEGLU ? d->Cout / 2 : d->Cout;
     a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
+    a.out_planes = (split && !d->out_f32) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((M + 255) / 256), (unsigned)((d->Cout + 255) / 256));
     auto go = [&](auto kern) -> int {
@@ -481,5 +597,6 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
         hipLaunchKernelGGL(kern, grid, dim3(512), G_SMEM, s, a);
         return rsvld_check_launch();
     };
-    return d->dtype == RSVLD_F16 ? go(gemm256_kernel<f16>) : go(gemm256_kernel<bf16>);
+    if (split) return go(gemm256_kernel<bf16, true>);
+    return d->dtype == RSVLD_F16 ? go(gemm256_kernel<f16, false>) : go(gemm256_kernel<bf16, false>);
 }

@@ -392,6 +392,229 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x1,
         }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// fp32-input forms for the split-operand product path (round 4; RSVLD_SPLIT): the residual stream of a network in the "split"
+// precision is fp32 NHWC, and every tensor that only feeds a matrix product leaves its producer as two bf16 planes per row,
+// [lo(C) | hi(C)] with hi = bf16(v), lo = bf16(v - hi).  Same thread <-> 8-channel-chunk mapping and the same two-level
+// deterministic reduction as the 16-bit kernels above; 32 bytes per lane and row.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+// planes row: lo at [c], hi at [C + c]
+__device__ __forceinline__ void st_planes8(bf16* row, int C, int c, const float (&f)[8]) {
+    bf16x8 hv;
+    float lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hv[e] = (bf16)f[e]; lo[e] = f[e] - (float)hv[e]; }
+    *(u32x4*)(row + c) = pack8<bf16>(lo);
+    *(u32x4*)(row + C + c) = __builtin_bit_cast(u32x4, hv);
+}
+
+__global__ __launch_bounds__(256) void gn_partial_f32_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                             float* __restrict__ part, int HW, int C1, int C2, int groups,
+                                                             int rows_per_chunk, int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sm = (float*)smem_raw;  // [rif][C][2]
+    const int C = C1 + C2, C8 = C >> 3, C1_8 = C1 >> 3;
+    const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
+    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
+    const int row_lo = chunk * rows_per_chunk, row_hi = min(HW, row_lo + rows_per_chunk);
+    const int tc = tid % TPR, rsub = tid / TPR;
+    if (rsub < rif) {
+        for (int cc = tc; cc < C8; cc += TPR) {
+            float s[8], ss[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+            const float* src;
+            int64_t cstride;
+            int coff;
+            if (cc < C1_8) { src = x1 + (int64_t)b * HW * C1; cstride = C1; coff = cc * 8; }
+            else { src = x2 + (int64_t)b * HW * C2; cstride = C2; coff = (cc - C1_8) * 8; }
+            int r = row_lo + rsub;
+            for (; r + rif < row_hi; r += 2 * rif) {   // two rows (4 x 16 B) in flight
+                float f0[8], f1[8];
+                ld8f(src + (int64_t)r * cstride + coff, f0);
+                ld8f(src + (int64_t)(r + rif) * cstride + coff, f1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f0[e]; ss[e] += f0[e] * f0[e]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f1[e]; ss[e] += f1[e] * f1[e]; }
+            }
+            for (; r < row_hi; r += rif) {
+                float f[8];
+                ld8f(src + (int64_t)r * cstride + coff, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+            }
+            float* dst = sm + ((int64_t)rsub * C + cc * 8) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dst[2 * e] = s[e]; dst[2 * e + 1] = ss[e]; }
+        }
+    }
+    __syncthreads();
+    const int gs = C / groups;
+    for (int g = tid; g < groups; g += 256) {
+        float s = 0.f, ss = 0.f;
+        for (int r = 0; r < rif; ++r) {
+            const float* src = sm + ((int64_t)r * C + g * gs) * 2;
+            for (int e = 0; e < gs; ++e) { s += src[2 * e]; ss += src[2 * e + 1]; }
+        }
+        float* o = part + (((int64_t)b * nchunks + chunk) * groups + g) * 2;
+        o[0] = s;
+        o[1] = ss;
+    }
+}
+
+// y = act(a[b,c] * v + s[b,c]) [* (1 + mod_scale) + mod_shift]; fp32 in (one or two sources), planes or fp32 out
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __restrict__ x1, const float* __restrict__ x2, void* __restrict__ y,
+                                                             const float* __restrict__ ab, const float* __restrict__ mod_scale,
+                                                             const float* __restrict__ mod_shift, int HW, int C1, int C2, int silu,
+                                                             int rows_per_block, int mod_stride) {
+    const int C = C1 + C2, C8 = C >> 3, C1_8 = C1 >> 3;
+    const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
+    const int tid = threadIdx.x, tc = tid % TPR, rsub = tid / TPR;
+    if (rsub >= rif) return;
+    const int b = blockIdx.y;
+    const int row_lo = blockIdx.x * rows_per_block, row_hi = min(HW, row_lo + rows_per_block);
+    for (int cc = tc; cc < C8; cc += TPR) {
+        float sa[8], sb[8];
+        {
+            const float* a = ab + ((int64_t)b * C + cc * 8) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sa[e] = a[2 * e]; sb[e] = a[2 * e + 1]; }
+        }
+        const float* src;
+        int64_t cstride;
+        int coff;
+        if (cc < C1_8) { src = x1 + (int64_t)b * HW * C1; cstride = C1; coff = cc * 8; }
+        else { src = x2 + (int64_t)b * HW * C2; cstride = C2; coff = (cc - C1_8) * 8; }
+        auto emit = [&](int r, float (&f)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = f[e] * sa[e] + sb[e];
+                f[e] = silu ? silu_f(t) : t;
+            }
+            if (mod_scale != nullptr) {
+                const int64_t mo = ((int64_t)b * HW + r) * mod_stride + cc * 8;
+                float ms[8], mh[8];
+                ld8f(mod_scale + mo, ms);
+                ld8f(mod_shift + mo, mh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * (1.f + ms[e]) + mh[e];
+            }
+            const int64_t pix = (int64_t)b * HW + r;
+            if (OUT_F32) {
+                float* o = (float*)y + pix * C + cc * 8;
+                *(f32x4*)o = (f32x4){f[0], f[1], f[2], f[3]};
+                *(f32x4*)(o + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+            } else {
+                st_planes8((bf16*)y + pix * (2 * C), C, cc * 8, f);
+            }
+        };
+        int r = row_lo + rsub;
+        for (; r + rif < row_hi; r += 2 * rif) {
+            float f0[8], f1[8];
+            ld8f(src + (int64_t)r * cstride + coff, f0);
+            ld8f(src + (int64_t)(r + rif) * cstride + coff, f1);
+            emit(r, f0);
+            emit(r + rif, f1);
+        }
+        for (; r < row_hi; r += rif) {
+            float f[8];
+            ld8f(src + (int64_t)r * cstride + coff, f);
+            emit(r, f);
+        }
+    }
+}
+
+// LayerNorm of fp32 rows -> planes (or fp32): the 16-bit kernel's structure (one wave per row group, rows and the lane's
+// gamma / beta in registers, exact two-pass variance) with 32-byte pieces
+template <int MAXC, int ROWS, bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, void* __restrict__ y,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int64_t rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int C8 = C >> 3;
+    float ga[MAXC][8], be[MAXC][8];
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int cc = lane + 64 * j;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ga[j][e] = (gamma != nullptr && cc < C8) ? gamma[cc * 8 + e] : 1.f;
+            be[j][e] = (beta != nullptr && cc < C8) ? beta[cc * 8 + e] : 0.f;
+        }
+    }
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row0 = wave_id * ROWS; row0 < rows; row0 += nwaves * ROWS) {
+        float f[ROWS][MAXC][8];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) {
+                const int cc = lane + 64 * j;
+                if (cc < C8 && row0 + r < rows) ld8f(x + (row0 + r) * C + cc * 8, f[r][j]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[r][j][e] = 0.f;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if (row0 + r >= rows) break;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j)
+                if (lane + 64 * j < C8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s += f[r][j][e];
+                }
+            const float mean = wave_sum(s) / (float)C;
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j)
+                if (lane + 64 * j < C8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = f[r][j][e] - mean; ss += d * d; }
+                }
+            const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+            for (int j = 0; j < MAXC; ++j) {
+                const int cc = lane + 64 * j;
+                if (cc < C8) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (f[r][j][e] - mean) * rstd * ga[j][e] + be[j][e];
+                    if (OUT_F32) {
+                        float* d = (float*)y + (row0 + r) * C + cc * 8;
+                        *(f32x4*)d = (f32x4){o[0], o[1], o[2], o[3]};
+                        *(f32x4*)(d + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+                    } else {
+                        st_planes8((bf16*)y + (row0 + r) * (2 * (int64_t)C), C, cc * 8, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// (mean, biased variance) per (image, group) -> the per-channel affine (gamma rstd, beta - mean gamma rstd)
+__global__ void gn_ab_from_stats_kernel(const float* __restrict__ mean_var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        float* __restrict__ ab, int C, int groups, float eps, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (b, c)
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C, g = c / (C / groups);
+    const float mean = mean_var[((int64_t)b * groups + g) * 2], var = mean_var[((int64_t)b * groups + g) * 2 + 1];
+    const float a = (gamma ? gamma[c] : 1.f) * (1.0f / sqrtf(var + eps));
+    ab[2 * (int64_t)i] = a;
+    ab[2 * (int64_t)i + 1] = (beta ? beta[c] : 0.f) - mean * a;
+}
+
 bool gn_small_ok(int B, int HW, int C1, int C2, int groups) {
     const int C = C1 + C2, gs = C / groups;
     if (gs % 8) return false;
@@ -586,5 +809,96 @@ extern "C" int rsvld_layernorm(const void* x, void* y, const float* gamma, const
     if (dtype == RSVLD_F16) launch_layernorm<f16>(x, y, gamma, beta, rows, C, eps, s);
     else if (dtype == RSVLD_BF16) launch_layernorm<bf16>(x, y, gamma, beta, rows, C, eps, s);
     else return RSVLD_EINVAL;
+    return rsvld_check_launch();
+}
+
+// ---- split-operand product path (fp32 NHWC in; see the kernels above)
+extern "C" int rsvld_groupnorm_scale_shift_f32(const float* x, const float* x2, const float* gamma, const float* beta,
+                                               float* scale_shift, int B, int HW, int C1, int C2, int groups, float eps, void* ws,
+                                               void* stream) {
+    if (!x || !ws || !scale_shift || !gn_shape_ok(B, HW, C1, C2, groups) || ((C2 > 0) != (x2 != nullptr)) || B > 65535) return RSVLD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const GnPlan pl = gn_plan(B, HW);
+    const int C = C1 + C2, C8 = C / 8;
+    const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
+    const size_t smem = (size_t)rif * C * 2 * sizeof(float);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(gn_partial_f32_kernel, dim3(pl.nchunks, B), dim3(256), smem, s, x, x2, part, HW, C1, C2, groups,
+                       pl.rows_per_chunk, pl.nchunks);
+    const double inv_count = 1.0 / ((double)HW * (double)(C / groups));
+    hipLaunchKernelGGL(gn_ab_kernel<false>, dim3(groups, B), dim3(256), 0, s, part, pl.nchunks, C, nullptr, 0, 0, gamma, beta,
+                       scale_shift, nullptr, groups, eps, inv_count);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_groupnorm_apply_split(const float* x, const float* x2, void* out, const float* scale_shift,
+                                           const float* mod_scale1p, const float* mod_shift, int mod_stride, int B, int HW, int C1,
+                                           int C2, int silu, int out_f32, void* stream) {
+    if (!x || !out || !scale_shift || B <= 0 || B > 65535 || HW <= 0 || C1 <= 0 || C1 % 8 || C2 < 0 || C2 % 8 || ((C2 > 0) != (x2 != nullptr)))
+        return RSVLD_EINVAL;
+    if ((mod_scale1p != nullptr) != (mod_shift != nullptr) || mod_stride < 0 || (mod_stride & 3)) return RSVLD_EINVAL;
+    const int C = C1 + C2, C8 = C / 8;
+    const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
+    int max_blocks = 2048 / B;
+    if (max_blocks < 1) max_blocks = 1;
+    int rpb = (HW + max_blocks - 1) / max_blocks;
+    if (rpb < 2 * rif) rpb = 2 * rif;
+    const int nblk = (HW + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_f32)
+        hipLaunchKernelGGL(gn_apply_split_kernel<true>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
+                           mod_shift, HW, C1, C2, silu, rpb, mod_stride > 0 ? mod_stride : C);
+    else
+        hipLaunchKernelGGL(gn_apply_split_kernel<false>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
+                           mod_shift, HW, C1, C2, silu, rpb, mod_stride > 0 ? mod_stride : C);
+    return rsvld_check_launch();
+}
+
+template <bool OUT_F32>
+static void launch_layernorm_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                                   hipStream_t s) {
+    const int chunks_per_lane = (C / 8 + 63) / 64;
+    auto blocks = [&](int rows_per_block) {
+        const int64_t n = cdiv64(rows, rows_per_block);
+        return (unsigned)(n < 4096 ? n : 4096);
+    };
+    if (chunks_per_lane <= 2) hipLaunchKernelGGL((layernorm_split_kernel<2, 2, OUT_F32>), dim3(blocks(8)), dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+    else if (chunks_per_lane == 3) hipLaunchKernelGGL((layernorm_split_kernel<3, 2, OUT_F32>), dim3(blocks(8)), dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+    else if (chunks_per_lane <= 4) hipLaunchKernelGGL((layernorm_split_kernel<4, 1, OUT_F32>), dim3(blocks(4)), dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+    else hipLaunchKernelGGL((layernorm_split_kernel<8, 1, OUT_F32>), dim3(blocks(4)), dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
+}
+
+extern "C" int rsvld_layernorm_split(const float* x, void* out, const float* gamma, const float* beta, int64_t rows, int C, float eps,
+                                     int out_f32, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || C % 8 || C > 4096) return RSVLD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_f32) launch_layernorm_split<true>(x, out, gamma, beta, rows, C, eps, s);
+    else launch_layernorm_split<false>(x, out, gamma, beta, rows, C, eps, s);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_groupnorm_stats_f32_fast(const float* x, const float* x2, float* mean_var, int B, int HW, int C1, int C2, int groups,
+                                              void* ws, void* stream) {
+    if (!x || !mean_var || !ws || !gn_shape_ok(B, HW, C1, C2, groups) || ((C2 > 0) != (x2 != nullptr)) || B > 65535) return RSVLD_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const GnPlan pl = gn_plan(B, HW);
+    const int C = C1 + C2, C8 = C / 8;
+    const int TPR = C8 < 256 ? C8 : 256, rif = 256 / TPR;
+    const size_t smem = (size_t)rif * C * 2 * sizeof(float);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(gn_partial_f32_kernel, dim3(pl.nchunks, B), dim3(256), smem, s, x, x2, part, HW, C1, C2, groups,
+                       pl.rows_per_chunk, pl.nchunks);
+    const int total = B * groups;
+    const double inv_count = 1.0 / ((double)HW * (double)(C / groups));
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s, part, mean_var, groups, pl.nchunks, inv_count, total);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_groupnorm_scale_shift_from_stats(const float* mean_var, const float* gamma, const float* beta, float* scale_shift,
+                                                      int B, int C, int groups, float eps, void* stream) {
+    if (!mean_var || !scale_shift || B <= 0 || C <= 0 || groups <= 0 || C % groups) return RSVLD_EINVAL;
+    const int total = B * C;
+    hipLaunchKernelGGL(gn_ab_from_stats_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean_var, gamma, beta,
+                       scale_shift, C, groups, eps, total);
     return rsvld_check_launch();
 }

@@ -1,0 +1,482 @@
+// split.hip — producers / consumers of bf16 PLANES around the RSVLD_SPLIT matrix kernels (round 4), and the split-operand
+// flash attention for d = 64.
+//
+// The "split" precision (models/SR_model.py:28-33 run without autocast is what it has to match: the reference's CPU path is fp32):
+// an fp32 value v is carried as hi = bf16(v), lo = bf16(v - hi) (16 mantissa bits, fp32's exponent range) and a product of two such
+// numbers as three bf16 MFMAs, a_lo b_hi + a_hi b_lo + a_hi b_hi, into an fp32 accumulator.  Round 3 did the split on the fly inside
+// the fp32 family's simple kernels; here the planes are DATA: a tensor that only feeds matrix products leaves its producer as
+// [rows][lo(C) | hi(C)], weights are packed once as [W_hi | W_lo | W_hi], and the tuned 16-bit kernels (gemm.hip, conv_halo.hip,
+// conv_igemm.hip) run the three terms as one contraction over 3 K.  This file holds what surrounds them:
+//   split / merge / weight-triple packing, plane re-packs for attention run as GEMMs (single-head d = 512), the row softmax
+//   that turns fp32 scores into P planes, and attn_split_d64_kernel -- flash attention on planes for the SDXL blocks.
+#include "rsvld_common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+__device__ __forceinline__ void split8v(const float (&f)[8], u32x4& lo, u32x4& hi) {
+    bf16x8 hv;
+    float l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hv[e] = (bf16)f[e]; l[e] = f[e] - (float)hv[e]; }
+    lo = pack8<bf16>(l);
+    hi = __builtin_bit_cast(u32x4, hv);
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, bf16* __restrict__ y, int64_t items, int C8) {
+    const int C = C8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        float f[8];
+        ld8f(x + row * C + c, f);
+        u32x4 lo, hi;
+        split8v(f, lo, hi);
+        *(u32x4*)(y + row * (2 * (int64_t)C) + c) = lo;
+        *(u32x4*)(y + row * (2 * (int64_t)C) + C + c) = hi;
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_planes_kernel(const bf16* __restrict__ y, float* __restrict__ x, int64_t items, int C8) {
+    const int C = C8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        float l[8], h[8];
+        unpack8<bf16>(*(const u32x4*)(y + row * (2 * (int64_t)C) + c), l);
+        unpack8<bf16>(*(const u32x4*)(y + row * (2 * (int64_t)C) + C + c), h);
+        float* o = x + row * C + c;
+        *(f32x4*)o = (f32x4){h[0] + l[0], h[1] + l[1], h[2] + l[2], h[3] + l[3]};
+        *(f32x4*)(o + 4) = (f32x4){h[4] + l[4], h[5] + l[5], h[6] + l[6], h[7] + l[7]};
+    }
+}
+
+// w [R][Ctot] fp32 (R = Cout * taps) -> [R][hi | lo | hi]
+__global__ __launch_bounds__(256) void split_pack_weights_kernel(const float* __restrict__ w, bf16* __restrict__ o, int64_t items, int C8) {
+    const int C = C8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        float f[8];
+        ld8f(w + row * C + c, f);
+        u32x4 lo, hi;
+        split8v(f, lo, hi);
+        bf16* d = o + row * (3 * (int64_t)C) + c;
+        *(u32x4*)d = hi;
+        *(u32x4*)(d + C) = lo;
+        *(u32x4*)(d + 2 * C) = hi;
+    }
+}
+
+// planes [rows][ld] (lo at c, hi at C + c) -> [rows_p][hi | lo | hi]; rows past `rows` are zero
+__global__ __launch_bounds__(256) void planes_to_triple_kernel(const bf16* __restrict__ y, bf16* __restrict__ o, int64_t rows, int64_t items,
+                                                               int C8, int64_t ld) {
+    const int C = C8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        u32x4 lo = {0u, 0u, 0u, 0u}, hi = {0u, 0u, 0u, 0u};
+        if (row < rows) {
+            lo = *(const u32x4*)(y + row * ld + c);
+            hi = *(const u32x4*)(y + row * ld + C + c);
+        }
+        bf16* d = o + row * (3 * (int64_t)C) + c;
+        *(u32x4*)d = hi;
+        *(u32x4*)(d + C) = lo;
+        *(u32x4*)(d + 2 * C) = hi;
+    }
+}
+
+// planes [rows][ld] -> transposed triple [C][hi^T(rows_p) | lo^T(rows_p) | hi^T(rows_p)]: 64 rows x 64 channels per workgroup
+// through LDS (rows of 66 halfwords: the column walk of the store side hits distinct banks)
+__global__ __launch_bounds__(256) void planes_transpose_triple_kernel(const uint16_t* __restrict__ y, uint16_t* __restrict__ o, int64_t rows,
+                                                                      int64_t rows_p, int C, int64_t ld) {
+    __shared__ uint16_t tl[2][64][66];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 3) + 32 * i, c = (tid & 7) * 8;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r0 + r < rows && c0 + c < C) v = *(const u32x4*)(y + (r0 + r) * ld + pl * C + c0 + c);
+            uint16_t h[8];
+            __builtin_memcpy(h, &v, 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tl[pl][r][c + e] = h[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (tid >> 3) + 32 * i, r = (tid & 7) * 8;
+        if (c0 + c >= C || r0 + r >= rows_p) continue;   // rows_p % 8 == 0: an 8-row piece is inside or outside as a whole
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            uint16_t h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = tl[pl][r + e][c];
+            u32x4 v;
+            __builtin_memcpy(&v, h, 16);
+            uint16_t* d = o + (int64_t)(c0 + c) * (3 * rows_p) + r0 + r;
+            if (pl == 0) {
+                *(u32x4*)(d + rows_p) = v;             // lo -> segment 1
+            } else {
+                *(u32x4*)d = v;                        // hi -> segments 0 and 2
+                *(u32x4*)(d + 2 * rows_p) = v;
+            }
+        }
+    }
+}
+
+// row softmax of fp32 scores -> P planes.  One workgroup of 256 threads per row; pass 1: per-thread online (max, sum) over 8-wide
+// pieces, merged through LDS; pass 2: p = exp2((s - m) c) / l written as lo | hi.  Pad columns [cols, cols_p) are written as zeros.
+__global__ __launch_bounds__(256) void softmax_rows_split_kernel(const float* __restrict__ s, bf16* __restrict__ pp, int cols, int cols_p,
+                                                                 int64_t ld, float scale_log2e) {
+    __shared__ float red[2][4];
+    const int64_t row = blockIdx.x;
+    const float* sr = s + row * ld;
+    const int tid = threadIdx.x;
+    float m = -INFINITY, l = 0.f;
+    for (int c = tid * 8; c < cols; c += 2048) {
+        float f[8];
+        ld8f(sr + c, f);   // ld >= cols_p >= c + 8: inside the row
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f[e] = (c + e < cols) ? f[e] * scale_log2e : -INFINITY;
+            mx = fmaxf(mx, f[e]);
+        }
+        const float mn = fmaxf(m, mx);
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += __builtin_amdgcn_exp2f(f[e] - mn);
+        l = l * __builtin_amdgcn_exp2f(m - mn) + a;
+        m = mn;
+    }
+    // wave merge, then the four waves through LDS (fixed order)
+    const float wm = wave_max(m);
+    l = wave_sum(m == -INFINITY ? 0.f : l * __builtin_amdgcn_exp2f(m - wm));
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wm; red[1][tid >> 6] = l; }
+    __syncthreads();
+    const float M = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) L += red[0][w] == -INFINITY ? 0.f : red[1][w] * __builtin_amdgcn_exp2f(red[0][w] - M);
+    const float inv = 1.0f / L;
+    bf16* pr = pp + row * (2 * (int64_t)cols_p);
+    for (int c = tid * 8; c < cols_p; c += 2048) {
+        float f[8];
+        ld8f(sr + c, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (c + e < cols) ? __builtin_amdgcn_exp2f(f[e] * scale_log2e - M) * inv : 0.f;
+        u32x4 lo, hi;
+        split8v(f, lo, hi);
+        *(u32x4*)(pr + c) = lo;
+        *(u32x4*)(pr + cols_p + c) = hi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Flash attention on planes, d = 64 (the Stage-2 transformer blocks under diffusion_dtype "split").
+//
+// The structure of attn_d64b (attention.hip): 4 waves x 32 query rows per workgroup, S^T = K Q^T computed swapped so that the
+// softmax is register-local and P is consumed as the next MFMA's B operand straight from the score registers, K / V tiles of 64
+// keys by LDS-DMA into a double buffer, V read through the hardware transpose.  What changes: every tile has FOUR planes
+// (K_lo, K_hi, V_lo, V_hi: 32 KiB per stage, two workgroups per CU), Q is held as hi + lo fragments (pre-multiplied by
+// scale log2 e in fp32, then re-split), P is split in registers after the fp32 softmax, and both contractions issue three MFMAs per
+// fragment pair, small terms first: 48 MFMAs per wave and tile against ~230 vector instructions -- the matrix pipe is the long side
+// here (in the 16-bit kernel the vector port is), so the softmax is the plain exact online form and the MFMAs are compiler-scheduled
+// builtins; two waves per SIMD give each other cover.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct AttnSplitArgs {
+    const bf16* q; const bf16* k; const bf16* v; void* out;
+    int Nq, Nk;
+    int64_t q_bs, q_ts, q_pl, k_bs, k_ts, k_pl, v_bs, v_ts, v_pl, o_bs, o_ts, o_pl;
+    float scale_log2e;
+    int out_f32;
+};
+constexpr int AS_TILE = 64 * 128;           // 64 keys x 64 d, bf16
+constexpr int AS_SMEM = 8 * AS_TILE;        // (K_lo, K_hi, V_lo, V_hi) x 2 buffers
+
+__device__ __forceinline__ f32x16 mma_bf16(const bf16x8& a, const bf16x8& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + w) * 32, h = blockIdx.y, b = blockIdx.z;
+    const bf16* Qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * 64;
+    const bf16* Kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * 64;
+    const bf16* Vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * 64;
+    const int nt = (p.Nk + 63) >> 6;
+
+    // ---- tile DMA: wave w moves key rows 16 w .. 16 w + 15 of each of the four planes, two pieces of 8 rows x 128 B each.
+    // Lane (row = lane>>3, pos = lane&7) fills LDS chunk `pos` of its row with source chunk pos ^ ((r16>>1)&7) for K and
+    // pos ^ (((r16>>1)&1)<<2) for V (r16 = tile row & 15): the images the fragment reads below expect (attention.hip).
+    auto dma_tile = [&](int t) {
+        const int buf = t & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = 16 * w + 8 * i + (lane >> 3), r16 = rr & 15;
+            const int key = min(t * 64 + rr, p.Nk - 1);            // rows past Nk re-read the last key; their scores are masked
+            const int kc = ((lane & 7) ^ ((r16 >> 1) & 7)) * 8, vc = ((lane & 7) ^ (((r16 >> 1) & 1) << 2)) * 8;
+            const bf16* ks = Kb + (int64_t)key * p.k_ts + kc;
+            const bf16* vs = Vb + (int64_t)key * p.v_ts + vc;
+            char* dst = smem + (16 * w + 8 * i) * 128;
+            __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(dst + (0 + buf) * AS_TILE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(ks + p.k_pl), (lptr_t)(dst + (2 + buf) * AS_TILE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(dst + (4 + buf) * AS_TILE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vs + p.v_pl), (lptr_t)(dst + (6 + buf) * AS_TILE), 16, 0, 0);
+        }
+    };
+    dma_tile(0);
+
+    // ---- Q fragments (B operand: column = the lane's query row, k = d), scaled in fp32 and re-split
+    const int qrow = q0 + l31;
+    bf16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        if (qrow < p.Nq) {
+            const bf16* qp = Qb + (int64_t)qrow * p.q_ts + ks * 16 + lh * 8;
+            float l[8], hh[8];
+            unpack8<bf16>(*(const u32x4*)qp, l);
+            unpack8<bf16>(*(const u32x4*)(qp + p.q_pl), hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (hh[e] + l[e]) * p.scale_log2e;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qh[ks][e] = (bf16)f[e];
+            ql[ks][e] = (bf16)(f[e] - (float)qh[ks][e]);
+        }
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + lh) ^ ((l31 >> 1) & 7)) << 4);
+    // V (transposed read): lane 16g + 4q + p supplies row 16 s4 + 8 hf + 4 lh + q, d = 32 dt + 16 (g&1) + 4p .. +3
+    int voff[2];
+    {
+        const int qq = (lane >> 2) & 3, pp = lane & 3, g1 = (lane >> 4) & 1;
+        const int row = 4 * lh + qq;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            voff[dt] = row * 128 + (((4 * dt + 2 * g1 + (pp >> 1)) ^ (((row >> 1) & 1) << 2)) << 4) + ((pp & 1) << 3);
+    }
+    auto read_vt = [&](const char* base, int off) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off + 1024));
+        typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    __syncthreads();   // (compiler: vmcnt(0) in front) tile 0 landed
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) dma_tile(t + 1);
+        const char* Kl = smem + (0 + buf) * AS_TILE;
+        const char* Kh = smem + (2 + buf) * AS_TILE;
+        const char* Vl = smem + (4 + buf) * AS_TILE;
+        const char* Vh = smem + (6 + buf) * AS_TILE;
+
+        // ---- S^T[key][q] = K Q^T: two 32-key halves x 4 k-steps x 3 terms
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kl = *(const bf16x8*)(Kl + kt * 4096 + koff[ks]);
+                const bf16x8 kh = *(const bf16x8*)(Kh + kt * 4096 + koff[ks]);
+                sacc[kt] = mma_bf16(kl, qh[ks], sacc[kt]);
+                sacc[kt] = mma_bf16(kh, ql[ks], sacc[kt]);
+                sacc[kt] = mma_bf16(kh, qh[ks], sacc[kt]);
+            }
+        }
+        if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (kv >= p.Nk) sacc[kt][r] = -INFINITY;
+                }
+        }
+
+        // ---- exact online softmax in fp32 (this lane: 32 of its query's 64 scores, lane ^ 32 the rest)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
+        {
+            const uint32_t mb = __builtin_bit_cast(uint32_t, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+        }
+        const float m_new = fmaxf(m_run, mx);            // finite: every tile holds at least one valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 0 on the first tile (m_run = -inf), 1 where the maximum stays
+        m_run = m_new;
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 ph[4], pl[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[kt][r] - m_new);
+                r4[r >> 2] += pv;
+                const bf16 hv = (bf16)pv;
+                ph[2 * kt + (r >> 3)][r & 7] = hv;
+                pl[2 * kt + (r >> 3)][r & 7] = (bf16)(pv - (float)hv);
+            }
+        l_run = l_run * alpha + ((r4[0] + r4[1]) + (r4[2] + r4[3]));
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
+
+        // ---- O^T[d][q] += V^T P^T: 4 key steps x 2 d-halves x 3 terms.  A operand (row = d, k = key in P's register order):
+        // elements 0..3 = keys 16 s4 + 4 lh + 0..3, elements 4..7 = keys 16 s4 + 8 + 4 lh + 0..3
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 vl = read_vt(Vl, voff[dt] + s4 * 2048);
+                const bf16x8 vh = read_vt(Vh, voff[dt] + s4 * 2048);
+                oacc[dt] = mma_bf16(vh, pl[s4], oacc[dt]);
+                oacc[dt] = mma_bf16(vl, ph[s4], oacc[dt]);
+                oacc[dt] = mma_bf16(vh, ph[s4], oacc[dt]);
+            }
+        __syncthreads();   // next tile landed (vmcnt(0) in front of the barrier); everyone done with this buffer
+    }
+
+    if (qrow >= p.Nq) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (p.out_f32) {
+        float* Ob = (float*)p.out + (int64_t)b * p.o_bs + (int64_t)h * 64 + (int64_t)qrow * p.o_ts;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(Ob + dt * 32 + 8 * g + 4 * lh) = (f32x4){oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv,
+                                                                  oacc[dt][4 * g + 3] * inv};
+    } else {
+        bf16* Ob = (bf16*)p.out + (int64_t)b * p.o_bs + (int64_t)h * 64 + (int64_t)qrow * p.o_ts;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = oacc[dt][4 * g + e] * inv;
+                    hv[e] = (bf16)o;
+                    lv[e] = (bf16)(o - (float)hv[e]);
+                }
+                *(bf16x4*)(Ob + dt * 32 + 8 * g + 4 * lh) = lv;
+                *(bf16x4*)(Ob + p.o_pl + dt * 32 + 8 * g + 4 * lh) = hv;
+            }
+    }
+}
+
+static unsigned ew_blocks(int64_t items) {
+    int64_t b = cdiv64(items, 256);
+    return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+}
+
+}  // namespace
+
+extern "C" int rsvld_split_planes(const float* x, void* planes, int64_t rows, int C, void* stream) {
+    if (!x || !planes || rows < 1 || C < 8 || C % 8) return RSVLD_EINVAL;
+    const int64_t items = rows * (C / 8);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)planes, items, C / 8);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_merge_planes(const void* planes, float* x, int64_t rows, int C, void* stream) {
+    if (!x || !planes || rows < 1 || C < 8 || C % 8) return RSVLD_EINVAL;
+    const int64_t items = rows * (C / 8);
+    hipLaunchKernelGGL(merge_planes_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, (const bf16*)planes, x, items, C / 8);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_split_pack_weights(const float* w, void* w3, int64_t Cout, int taps, int Ctot, void* stream) {
+    if (!w || !w3 || Cout < 1 || taps < 1 || Ctot < 8 || Ctot % 8) return RSVLD_EINVAL;
+    const int64_t items = Cout * taps * (Ctot / 8);
+    hipLaunchKernelGGL(split_pack_weights_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)w3, items, Ctot / 8);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_planes_to_triple(const void* planes, void* w3, int64_t rows, int64_t rows_p, int C, int64_t ld, void* stream) {
+    if (!planes || !w3 || rows < 1 || rows_p < rows || C < 8 || C % 8 || ld < 2 * C || ld % 8) return RSVLD_EINVAL;
+    const int64_t items = rows_p * (C / 8);
+    hipLaunchKernelGGL(planes_to_triple_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, (const bf16*)planes, (bf16*)w3, rows,
+                       items, C / 8, ld);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_planes_transpose_triple(const void* planes, void* w3, int64_t rows, int64_t rows_p, int C, int64_t ld, void* stream) {
+    if (!planes || !w3 || rows < 1 || rows_p < rows || rows_p % 8 || C < 8 || C % 8 || ld < 2 * C || ld % 8) return RSVLD_EINVAL;
+    const int64_t gx = cdiv64(rows_p, 64);
+    if (gx > 0x7fffffffLL) return RSVLD_EUNSUPPORTED;
+    hipLaunchKernelGGL(planes_transpose_triple_kernel, dim3((unsigned)gx, (unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)planes, (uint16_t*)w3, rows, rows_p, C, ld);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_softmax_rows_split(const float* s, void* p_planes, int64_t rows, int cols, int cols_p, int64_t ld, float scale,
+                                        void* stream) {
+    if (!s || !p_planes || rows < 1 || rows > 0x7fffffffLL || cols < 1 || cols_p < cols || cols_p % 8 || ld < cols_p || ld % 4) return RSVLD_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_split_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16*)p_planes, cols, cols_p, ld,
+                       scale * 1.44269504088896340736f);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_attention_split_d64(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
+                                         int64_t q_batch_stride, int64_t q_tok_stride, int64_t q_plane, int64_t k_batch_stride,
+                                         int64_t k_tok_stride, int64_t k_plane, int64_t v_batch_stride, int64_t v_tok_stride,
+                                         int64_t v_plane, int64_t o_batch_stride, int64_t o_tok_stride, int64_t o_plane, float scale,
+                                         int out_f32, void* stream) {
+    if (!q || !k || !v || !out || B < 1 || heads < 1 || Nq < 1 || Nk < 1) return RSVLD_EINVAL;
+    if (heads > 65535 || B > 65535) return RSVLD_EUNSUPPORTED;
+    if ((q_batch_stride | q_tok_stride | q_plane | k_batch_stride | k_tok_stride | k_plane | v_batch_stride | v_tok_stride | v_plane) % 8 != 0)
+        return RSVLD_EINVAL;   // 16-byte vector accesses
+    if ((o_batch_stride | o_tok_stride | o_plane) % 4 != 0) return RSVLD_EINVAL;
+    AttnSplitArgs a;
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = out; a.Nq = Nq; a.Nk = Nk;
+    a.q_bs = q_batch_stride; a.q_ts = q_tok_stride; a.q_pl = q_plane; a.k_bs = k_batch_stride; a.k_ts = k_tok_stride; a.k_pl = k_plane;
+    a.v_bs = v_batch_stride; a.v_ts = v_tok_stride; a.v_pl = v_plane; a.o_bs = o_batch_stride; a.o_ts = o_tok_stride; a.o_pl = o_plane;
+    a.scale_log2e = scale * 1.44269504088896340736f;
+    a.out_f32 = out_f32 ? 1 : 0;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)attn_split_d64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AS_SMEM);
+    if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(attn_split_d64_kernel, grid, dim3(256), AS_SMEM, (hipStream_t)stream, a);
+    return rsvld_check_launch();
+}

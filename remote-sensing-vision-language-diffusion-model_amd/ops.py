@@ -80,6 +80,102 @@ def f32_split(on):
         _F32_SPLIT = old
 
 
+# Which kernels run the split mode.  "planes" (round 4, default): the product path -- bf16 planes + weight triples through the tuned
+# 16-bit kernels (gemm256, conv_halo, conv_igemm with dtype RSVLD_SPLIT), the fused split attention for d = 64, attention as two
+# split GEMMs + a row softmax otherwise.  "f32": round 3's on-the-fly split inside the fp32 family's simple kernels (csrc/f32.hip),
+# kept as an independent implementation of the same arithmetic for tests and A/B runs.
+SPLIT_IMPL = os.environ.get("RSVLD_SPLIT_IMPL", "planes")
+
+
+def _split_fast():
+    return _F32_SPLIT and SPLIT_IMPL == "planes"
+
+
+class Planes:
+    """The split form of an fp32 tensor ``[..., C]``: ``t`` is a bf16 tensor ``[..., 2, C]`` with plane 0 = lo, plane 1 = hi
+    (hi = bf16(v), lo = bf16(v - hi)); contiguous planes are rows ``lo(C) | hi(C)``, the layout RSVLD_SPLIT kernels read and write.
+    A tensor that only feeds matrix products travels like this (same bytes as fp32, nothing lost that the product would keep).
+    Duck-types the few tensor members the network code touches between ops: shape, reshape, last-dim slices."""
+
+    __slots__ = ("t", "_gn_part", "_nhwc")
+    dtype = torch.float32      # the LOGICAL dtype: code that asks ``x.dtype == torch.float32`` means "the fp32 / split families"
+
+    def __init__(self, t):
+        self.t = t
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape[:-2]) + (self.t.shape[-1],)
+
+    @property
+    def device(self):
+        return self.t.device
+
+    @property
+    def is_cuda(self):
+        return self.t.is_cuda
+
+    def dim(self):
+        return self.t.dim() - 1
+
+    def numel(self):
+        return self.t.numel() // 2
+
+    def element_size(self):
+        return 4
+
+    def is_contiguous(self):
+        return self.t.is_contiguous()
+
+    def contiguous(self):
+        return self if self.t.is_contiguous() else Planes(self.t.contiguous())
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        return Planes(self.t.reshape(*shape[:-1], 2, self.t.shape[-1] if shape[-1] == -1 else shape[-1]))
+
+    def __getitem__(self, idx):
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        if Ellipsis in idx:
+            i = idx.index(Ellipsis)
+            idx = idx[:i] + (slice(None),) * (self.dim() - (len(idx) - 1)) + idx[i + 1:]
+        idx = idx + (slice(None),) * (self.dim() - len(idx))
+        return Planes(self.t[idx[:-1] + (slice(None), idx[-1])])
+
+    def index_select(self, dim, index):
+        return Planes(self.t.index_select(dim, index))
+
+    def f32(self):
+        """-> the fp32 tensor hi + lo (rsvld_merge_planes)."""
+        t = self.t.contiguous()
+        Cc = t.shape[-1]
+        out = torch.empty(tuple(t.shape[:-2]) + (Cc,), device=t.device, dtype=torch.float32)
+        L.check(L.load().rsvld_merge_planes(_ptr(t), _ptr(out), t.numel() // (2 * Cc), Cc, _stream()), "rsvld_merge_planes")
+        if out.dim() == 4:
+            out._nhwc = True
+        return out
+
+
+def to_planes(x):
+    """fp32 ``[..., C]`` (C % 8 == 0, contiguous) -> Planes (rsvld_split_planes); a Planes passes through."""
+    if isinstance(x, Planes):
+        return x
+    _need_gpu(x)
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.shape[-1] % 8:
+        raise L.RsvldError("to_planes: a contiguous fp32 tensor with C % 8 == 0 expected")
+    Cc = x.shape[-1]
+    t = torch.empty(tuple(x.shape[:-1]) + (2, Cc), device=x.device, dtype=torch.bfloat16)
+    _launch("split_planes", 0.0, 8.0 * x.numel(), lambda: L.check(L.load().rsvld_split_planes(_ptr(x), _ptr(t), x.numel() // Cc, Cc, _stream()),
+                                                                  "rsvld_split_planes"))
+    return Planes(t)
+
+
+def as_f32(x):
+    return x.f32() if isinstance(x, Planes) else x
+
+
 def _tune_from_env():
     """Developer A/B switches -> rsvld_conv_desc.tune.  The environment is read HERE, once, by the Python tools layer;
     the C ABI itself reads no environment (it is stateless)."""
@@ -147,10 +243,11 @@ def _launch(name, flops, nbytes, fn):
 class PackedConv:
     """K-major 16-bit weights of a Conv2d / Linear: ``w[Cout_p, KH*KW*Cin_p]``, bias fp32."""
 
-    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu")
+    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu", "w3")
 
     def __init__(self, w, bias, cin, cout, cin_p, cout_p, kh, kw, geglu=False):
         self.w, self.bias = w, bias
+        self.w3 = None     # split product path: bf16 triples [Cout_p][KH*KW][W_hi | W_lo | W_hi], packed on first use from the fp32 ``w``
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.kh, self.kw, self.geglu = kh, kw, geglu
 
@@ -202,7 +299,7 @@ HALO_MIN_WGS = int(os.environ.get("RSVLD_HALO_MIN_WGS", "256"))   # below one wo
 
 
 def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, residual=None,
-           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False):
+           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False, out_planes=False):
     """NHWC convolution.  ``pad`` = int or (top, left, bottom, right).
 
     ``norm=(gamma, beta, groups, eps, silu)``: a GroupNorm(+SiLU) over the input ([x | x2]) precedes the
@@ -211,8 +308,14 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
 
     ``stats=True``: the caller will feed the output to a GroupNorm; when the halo kernel runs it also writes
     per-tile per-channel (sum, sumsq) of the output from its epilogue and attaches them to the returned tensor
-    (``_gn_part``), so the consumer's ``norm=`` needs no statistics pass at all."""
+    (``_gn_part``), so the consumer's ``norm=`` needs no statistics pass at all.
+
+    ``out_planes=True`` (honoured in the split precision only, ignored otherwise): the output only feeds another matrix
+    product (q|k|v, GEGLU, ...) and is returned as ``Planes``."""
     _need_gpu(x, x2, pc.w, rowvec, residual)
+    if isinstance(x, Planes) or (x.dtype == torch.float32 and _split_fast()):
+        return _conv2d_split(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
+                             act=act, alpha=alpha, beta=beta, norm=norm, stats=stats, out_planes=out_planes)
     if x.dtype == torch.float32:
         return _conv2d_f32(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
                            act=act, alpha=alpha, beta=beta, norm=norm)
@@ -297,7 +400,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     Mp = -(-M // _PLAN_DIV)
     if (pc.kh == 1 and pc.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not upsample and x2 is None and rowvec is None
             and not out_f32 and Cin % 32 == 0 and pc.cout_p >= 256 and Mp >= 4096
-            and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128 and M * Cin * 2 < 2 ** 32
+            and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128 and 256 * Cin * 2 < 2 ** 32
             and not (TUNE & L.TUNE_NO_GEMM256)):   # mirrors rsvld_gemm256_try in csrc/gemm.hip (profiler label only)
         variant = "gemm_256x256"
     elif pc.cout_p <= 32:
@@ -356,19 +459,164 @@ def _conv2d_f32(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alph
     return out
 
 
-def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0):
+
+def _w3(pc):
+    """bf16 weight triples of a PackedConv (fp32 K-major ``w``), packed once on the device."""
+    if pc.w3 is None:
+        if pc.w.dtype != torch.float32:
+            raise L.RsvldError("split precision: weights must be packed in fp32 (the owning network's compute_dtype)")
+        taps = pc.kh * pc.kw
+        w3 = torch.empty((pc.cout_p, taps * 3 * pc.cin_p), device=pc.w.device, dtype=torch.bfloat16)
+        L.check(L.load().rsvld_split_pack_weights(_ptr(pc.w), _ptr(w3), pc.cout_p, taps, pc.cin_p, _stream()), "rsvld_split_pack_weights")
+        pc.w3 = w3
+    return pc.w3
+
+
+def _gn_scale_shift_f32(x, x2, gamma, nbeta, groups, eps):
+    """(scale, shift) fp32 ``[B, C1+C2, 2]`` of a GroupNorm over fp32 NHWC ``[x | x2]``: from the producers' epilogue partials when
+    every source carries them (no pass over the tensors), else one statistics pass."""
+    B, H, W, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    lib = L.load()
+    ab = torch.empty((B, C1 + C2, 2), device=x.device, dtype=torch.float32)
+    part1 = getattr(x, "_gn_part", None)
+    part2 = None if x2 is None else getattr(x2, "_gn_part", None)
+    if part1 is not None and (x2 is None or part2 is not None):
+        _launch("groupnorm_ab_from_partials", 0.0, 0.0, lambda: L.check(lib.rsvld_groupnorm_scale_shift_from_partials(
+            _ptr(part1[0]), part1[1], C1, None if part2 is None else _ptr(part2[0]), 0 if part2 is None else part2[1],
+            C2, _ptr(gamma), _ptr(nbeta), _ptr(ab), B, H * W, groups, eps, _stream()), "rsvld_groupnorm_scale_shift_from_partials"))
+        return ab
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise L.RsvldError("group_norm (split): contiguous fp32 NHWC inputs expected")
+    ws = torch.empty(lib.rsvld_groupnorm_ws_bytes(B, H * W, C1 + C2, groups), device=x.device, dtype=torch.uint8)
+    _launch("groupnorm_stats_split", 0.0, 4.0 * (x.numel() + (0 if x2 is None else x2.numel())), lambda: L.check(
+        lib.rsvld_groupnorm_scale_shift_f32(_ptr(x), _ptr(x2), _ptr(gamma), _ptr(nbeta), _ptr(ab), B, H * W, C1, C2, groups, eps,
+                                            _ptr(ws), _stream()), "rsvld_groupnorm_scale_shift_f32"))
+    return ab
+
+
+def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None):
+    B, H, W, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    Cc = C1 + C2
+    mod_stride = 0
+    if mod_scale1p is not None:
+        mod_stride = mod_scale1p.stride(-2)
+        if (mod_shift.stride(-2) != mod_stride or mod_scale1p.stride(-1) != 1 or mod_shift.stride(-1) != 1
+                or mod_scale1p.dtype != torch.float32 or mod_shift.dtype != torch.float32):
+            raise L.RsvldError("group_norm: modulation tensors must be fp32, share a row stride and be channel-contiguous")
+    if planes:
+        out = torch.empty((B, H, W, 2, Cc), device=x.device, dtype=torch.bfloat16)
+    else:
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+    _launch("groupnorm_apply_split", 0.0, 8.0 * B * H * W * Cc, lambda: L.check(L.load().rsvld_groupnorm_apply_split(
+        _ptr(x), _ptr(x2), _ptr(out), _ptr(ab), _ptr(mod_scale1p), _ptr(mod_shift), mod_stride, B, H * W, C1, C2, int(silu),
+        int(not planes), _stream()), "rsvld_groupnorm_apply_split"))
+    if planes:
+        return Planes(out)
+    out._nhwc = True
+    return out
+
+
+def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm, stats, out_planes):
+    """The split-operand product path of conv2d / linear: bf16 planes in (split here when the caller hands fp32), weight triples,
+    the 16-bit kernels with dtype RSVLD_SPLIT; fp32 (or Planes) out, fp32 residual."""
+    if norm is not None:      # GroupNorm(+SiLU) over [x | x2]: its own apply pass writes ONE planes tensor (no concat, no fp32 copy)
+        gamma, nbeta, groups, eps, silu = norm
+        if isinstance(x, Planes) or isinstance(x2, Planes):
+            raise L.RsvldError("conv2d (split): norm= needs the fp32 tensors")
+        ab = _gn_scale_shift_f32(x, x2, gamma, nbeta, groups, eps)
+        x, x2 = _gn_apply_split(x, x2, ab, silu, planes=True), None
+    x = to_planes(x)
+    x2 = None if x2 is None else to_planes(x2)
+    B, H, W, Cin = x.shape
+    Cin2 = 0 if x2 is None else x2.shape[-1]
+    if Cin + Cin2 != pc.cin_p:
+        raise L.RsvldError(f"conv2d: input channels {Cin}+{Cin2} != packed {pc.cin_p}")
+    if pad is None:
+        pad = pc.kh // 2
+    pt, pl, pb, pr = (pad,) * 4 if isinstance(pad, int) else pad
+    Hin, Win = (2 * H, 2 * W) if upsample else (H, W)
+    Ho = (Hin + pt + pb - pc.kh) // stride + 1
+    Wo = (Win + pl + pr - pc.kw) // stride + 1
+    geglu = act == L.ACT_GEGLU
+    c_out = pc.cout_p // 2 if geglu else pc.cout_p
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise L.RsvldError("conv2d (split): inputs must be contiguous planes")
+    if residual is not None:
+        if out_planes:
+            raise L.RsvldError("conv2d (split): a planes output takes no residual (the residual stream stays fp32)")
+        if isinstance(residual, Planes) or residual.dtype != torch.float32 or tuple(residual.shape) != (B, Ho, Wo, c_out) \
+                or not residual.is_contiguous():
+            raise L.RsvldError("conv2d (split): residual must be fp32 and match the output shape")
+    if out_planes:
+        out = torch.empty((B, Ho, Wo, 2, c_out), device=x.device, dtype=torch.bfloat16)
+    else:
+        out = torch.empty((B, Ho, Wo, c_out), device=x.device, dtype=torch.float32)
+    rv_stride = 0
+    if rowvec is not None:
+        if tuple(rowvec.shape) != (B, pc.cout_p) or rowvec.dtype != torch.float32 or rowvec.stride(1) != 1:
+            raise L.RsvldError("conv2d: rowvec must be fp32 [B, Cout] with unit inner stride")
+        rv_stride = rowvec.stride(0) if B > 1 else pc.cout_p
+    w3 = _w3(pc)
+    d = L.ConvDesc(
+        x=x.t.data_ptr(), x2=None if x2 is None else x2.t.data_ptr(), w=w3.data_ptr(),
+        bias=None if pc.bias is None else pc.bias.data_ptr(), rowvec=None if rowvec is None else rowvec.data_ptr(),
+        residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
+        B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo,
+        upsample=int(upsample), dtype=L.SPLIT, out_f32=int(not out_planes), act=act, alpha=alpha, beta=beta,
+        rowvec_stride=rv_stride, plan_div=_PLAN_DIV, tune=TUNE)
+    lib = L.load()
+    flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
+    nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + out.numel() / (2 if out_planes else 1)
+                    + (0 if residual is None else residual.numel())) + 6.0 * pc.w.numel()
+    Bp = -(-B // _PLAN_DIV)
+    halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
+    if halo:
+        bn = 64 if pc.cout_p <= 64 else 128
+        halo = Bp * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= HALO_MIN_WGS
+    if halo:
+        part_out = None
+        if stats and not out_planes:
+            ntiles = ((Ho + 7) // 8) * ((Wo + 31) // 32)
+            part_out = torch.empty((B, ntiles, pc.cout_p, 2), device=x.device, dtype=torch.float32)
+        _launch("conv_halo_64_split" if pc.cout_p <= 64 else "conv_halo_128_split", flops, nbytes, lambda: L.check(
+            lib.rsvld_conv3x3_halo_nhwc(C.byref(d), None, 0, _ptr(part_out), _stream()), "rsvld_conv3x3_halo_nhwc"))
+        if part_out is not None:
+            out._gn_part = (part_out, ntiles)
+    else:
+        M = B * Ho * Wo
+        Mp = -(-M // _PLAN_DIV)
+        g256 = (pc.kh == 1 and pc.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not upsample and x2 is None and rowvec is None
+                and Cin % 32 == 0 and pc.cout_p >= 256 and Mp >= 4096 and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128
+                and 256 * Cin * 6 < 2 ** 32 and not (TUNE & L.TUNE_NO_GEMM256))   # mirrors rsvld_gemm256_try
+        _launch("gemm_256x256_split" if g256 else "conv_igemm_split", flops, nbytes,
+                lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
+    if out_planes:
+        return Planes(out)
+    out._nhwc = True
+    return out
+
+
+def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0, out_planes=False):
     """``[..., Cin] -> [..., Cout]`` on token-major tensors (a 1x1 conv over rows)."""
     shp = x.shape
     rows = x.numel() // shp[-1]
     res = None if residual is None else residual.reshape(1, 1, rows, residual.shape[-1])
-    y = conv2d(x.reshape(1, 1, rows, shp[-1]), pc, pad=0, residual=res, act=act, alpha=alpha, beta=beta)
+    y = conv2d(x.reshape(1, 1, rows, shp[-1]), pc, pad=0, residual=res, act=act, alpha=alpha, beta=beta, out_planes=out_planes)
     return y.reshape(*shp[:-1], y.shape[-1])
 
 
 # ----------------------------------------------------------------------------- norms
-def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None):
+def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None, planes=False):
     """GroupNorm(+SiLU) over NHWC ``x`` (or the channel concat [x | x2]).  ``mod_scale1p`` / ``mod_shift``
-    (ZeroSFT) may be channel slices of one stacked tensor: only their row stride must agree."""
+    (ZeroSFT) may be channel slices of one stacked tensor: only their row stride must agree.
+    ``planes=True`` (split precision only, ignored otherwise): the result only feeds a matrix product -> ``Planes``."""
+    if x.dtype == torch.float32 and _split_fast() and not isinstance(x, Planes):
+        _need_gpu(x, x2, gamma, beta)
+        ab = _gn_scale_shift_f32(x, x2, gamma, beta, groups, eps)
+        return _gn_apply_split(x, x2, ab, silu, planes, as_f32(mod_scale1p) if mod_scale1p is not None else None,
+                               as_f32(mod_shift) if mod_shift is not None else None)
     mod_stride = 0
     if mod_scale1p is not None:
         mod_stride = mod_scale1p.stride(-2)
@@ -399,6 +647,15 @@ def group_norm_stats(x, groups, *, x2=None):
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
     lib = L.load()
+    if x.dtype == torch.float32 and _split_fast():
+        if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+            raise L.RsvldError("group_norm_stats (split): contiguous fp32 NHWC tensors expected")
+        ws = torch.empty(lib.rsvld_groupnorm_ws_bytes(B, H * W, C1 + C2, groups), device=x.device, dtype=torch.uint8)
+        st = torch.empty((B, groups, 2), device=x.device, dtype=torch.float32)
+        _launch("groupnorm_stats_split", 0.0, 4.0 * (x.numel() + (0 if x2 is None else x2.numel())), lambda: L.check(
+            lib.rsvld_groupnorm_stats_f32_fast(_ptr(x), _ptr(x2), _ptr(st), B, H * W, C1, C2, groups, _ptr(ws), _stream()),
+            "rsvld_groupnorm_stats_f32_fast"))
+        return st
     if x.dtype == torch.float32:
         if x2 is not None or not x.is_contiguous():
             raise L.RsvldError("group_norm_stats (fp32): one contiguous NHWC tensor expected")
@@ -414,9 +671,17 @@ def group_norm_stats(x, groups, *, x2=None):
     return st
 
 
-def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None):
-    """``mod_*`` (ZeroSFT modulation) with supplied statistics exists in the fp32 family only."""
+def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None, planes=False):
+    """``mod_*`` (ZeroSFT modulation) with supplied statistics exists in the fp32 family only.
+    ``planes=True`` (split precision only): the result only feeds a matrix product -> ``Planes``."""
     _need_gpu(x, x2, stats, gamma, beta)
+    if x.dtype == torch.float32 and _split_fast() and not isinstance(x, Planes):
+        B, H, W, C1 = x.shape
+        Cc = C1 + (0 if x2 is None else x2.shape[-1])
+        ab = torch.empty((B, Cc, 2), device=x.device, dtype=torch.float32)
+        L.check(L.load().rsvld_groupnorm_scale_shift_from_stats(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(ab), B, Cc, groups, eps,
+                                                                _stream()), "rsvld_groupnorm_scale_shift_from_stats")
+        return _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p, mod_shift)
     if mod_scale1p is not None and x.dtype != torch.float32:
         raise L.RsvldError("group_norm_apply: modulation with supplied statistics is an fp32-family feature (use group_norm)")
     B, H, W, C1 = x.shape
@@ -442,10 +707,21 @@ def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False,
     return y
 
 
-def layer_norm(x, gamma, beta, eps=1e-5):
+def layer_norm(x, gamma, beta, eps=1e-5, planes=False):
+    """``planes=True`` (split precision only, ignored otherwise): the result only feeds matrix products -> ``Planes``."""
     _need_gpu(x, gamma, beta)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
+    if x.dtype == torch.float32 and _split_fast():
+        if not x.is_contiguous():
+            raise L.RsvldError("layer_norm (split): contiguous rows expected")
+        if planes:
+            y = torch.empty(tuple(x.shape[:-1]) + (2, Cc), device=x.device, dtype=torch.bfloat16)
+        else:
+            y = torch.empty_like(x)
+        _launch("layernorm_split", 0.0, 8.0 * x.numel(), lambda: L.check(L.load().rsvld_layernorm_split(
+            _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, int(not planes), _stream()), "rsvld_layernorm_split"))
+        return Planes(y) if planes else y
     y = torch.empty_like(x)
     if x.dtype == torch.float32:
         if not x.is_contiguous():
@@ -462,6 +738,8 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 def attention(q, k, v, heads, scale=None):
     """q ``[B, Nq, heads*D]``, k/v ``[B, Nk, heads*D]`` (views with a token stride are fine, e.g.
     slices of a fused qkv tensor) -> ``[B, Nq, heads*D]`` contiguous."""
+    if any(isinstance(t, Planes) for t in (q, k, v)) or (q.dtype == torch.float32 and _split_fast()):
+        return _attention_split(q, k, v, heads, scale)
     _need_gpu(q, k, v)
     B, Nq, HD = q.shape
     Nk = k.shape[1]
@@ -496,6 +774,84 @@ def attention(q, k, v, heads, scale=None):
                                   out.stride(0), out.stride(1), scale, _dt(q), _PLAN_DIV, _ptr(ws), _stream(), tune),
         "rsvld_attention"))
     return out
+
+
+SPLIT_ATTN_S_BYTES = int(os.environ.get("RSVLD_SPLIT_ATTN_S_BYTES", str(32 << 30)))   # fp32 score block of the GEMM form (P planes: as much again)
+
+
+def _split_gemm(xt, w3, out, M, K, N, out_f32, name):
+    """``out[M, N] = x[M, K] w[N, K]^T`` in the split precision: ``xt`` contiguous planes ``[M, 2, K]``, ``w3`` triples ``[N, 3K]``,
+    ``out`` fp32 ``[M, N]`` or planes ``[M, 2, N]`` (rsvld_conv2d_nhwc as a 1x1 layer; plans on the whole call)."""
+    d = L.ConvDesc(x=xt.data_ptr(), x2=None, w=w3.data_ptr(), bias=None, rowvec=None, residual=None, out=out.data_ptr(),
+                   B=1, H=1, W=M, Cin=K, Cin2=0, Cout=N, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, Ho=1, Wo=M, upsample=0,
+                   dtype=L.SPLIT, out_f32=int(out_f32), act=L.ACT_NONE, alpha=1.0, beta=1.0, rowvec_stride=0, plan_div=1, tune=TUNE)
+    _launch(name, 2.0 * M * K * N, 4.0 * M * K + 6.0 * N * K + 4.0 * M * N,
+            lambda: L.check(L.load().rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
+
+
+def _attention_split(q, k, v, heads, scale):
+    """Attention in the split precision -> ``Planes [B, Nq, heads*D]`` (its consumer is always a projection).
+    D = 64: the fused flash kernel on planes (rsvld_attention_split_d64).  Other head sizes (single-head d = 512 of SR3 and the
+    VAE): two split GEMMs around a row softmax per block of query rows -- S = Q K^T (fp32) -> P = softmax(scale S) (planes) ->
+    O = P V -- with K and V re-packed once as the GEMMs' weight triples."""
+    shared = k is v
+    def prep(t):
+        if isinstance(t, Planes):
+            return t
+        return to_planes(t.contiguous())
+    q = prep(q)
+    k = prep(k)
+    v = k if shared else prep(v)
+    _need_gpu(q.t, k.t, v.t)
+    B, Nq, HD = q.shape
+    Nk = k.shape[1]
+    D = HD // heads
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    lib = L.load()
+    out = torch.empty((B, Nq, 2, HD), device=q.t.device, dtype=torch.bfloat16)
+    flops = 4.0 * B * heads * Nq * Nk * D
+    if D == 64:
+        for t in (q.t, k.t, v.t):
+            if t.stride(3) != 1:
+                raise L.RsvldError("attention (split): last dim must be contiguous")
+        nbytes = 4.0 * (2 * B * Nq * HD + 2 * B * Nk * HD)
+        _launch("attention_split_d64" + ("_cross" if Nk != Nq else ""), flops, nbytes, lambda: L.check(lib.rsvld_attention_split_d64(
+            _ptr(q.t), _ptr(k.t), _ptr(v.t), _ptr(out), B, heads, Nq, Nk,
+            q.t.stride(0), q.t.stride(1), q.t.stride(2), k.t.stride(0), k.t.stride(1), k.t.stride(2),
+            v.t.stride(0), v.t.stride(1), v.t.stride(2), out.stride(0), out.stride(1), out.stride(2), scale, 0, _stream()),
+            "rsvld_attention_split_d64"))
+        return Planes(out)
+    if D % 8:
+        raise L.RsvldError("attention (split): head dim must be a multiple of 8")
+    Nk_p = (Nk + 7) // 8 * 8
+    rows_blk = max(256, min(Nq, (SPLIT_ATTN_S_BYTES // (4 * Nk_p)) // 256 * 256))
+    dev = q.t.device
+    for b in range(B):
+        for h in range(heads):
+            def head(t):      # contiguous planes [N, 2, D] of (b, h)
+                th = t[b, :, :, h * D:(h + 1) * D]
+                return th if th.is_contiguous() else th.contiguous()
+            qh, kh = head(q.t), head(k.t)
+            vh = kh if shared else head(v.t)
+            w1 = torch.empty((Nk_p, 3 * D), device=dev, dtype=torch.bfloat16)
+            L.check(lib.rsvld_planes_to_triple(_ptr(kh), _ptr(w1), Nk, Nk_p, D, 2 * D, _stream()), "rsvld_planes_to_triple")
+            w2 = torch.empty((D, 3 * Nk_p), device=dev, dtype=torch.bfloat16)
+            L.check(lib.rsvld_planes_transpose_triple(_ptr(vh), _ptr(w2), Nk, Nk_p, D, 2 * D, _stream()), "rsvld_planes_transpose_triple")
+            oh = out[b] if heads == 1 else torch.empty((Nq, 2, D), device=dev, dtype=torch.bfloat16)
+            for r0 in range(0, Nq, rows_blk):
+                m = min(rows_blk, Nq - r0)
+                s_blk = torch.empty((m, Nk_p), device=dev, dtype=torch.float32)
+                _split_gemm(qh[r0:r0 + m], w1, s_blk, m, D, Nk_p, True, f"attention_split_gemm_qk_d{D}")
+                p_blk = torch.empty((m, 2, Nk_p), device=dev, dtype=torch.bfloat16)
+                _launch("attention_split_softmax", 0.0, 12.0 * m * Nk_p, lambda: L.check(lib.rsvld_softmax_rows_split(
+                    _ptr(s_blk), _ptr(p_blk), m, Nk, Nk_p, Nk_p, scale, _stream()), "rsvld_softmax_rows_split"))
+                del s_blk
+                _split_gemm(p_blk, w2, oh[r0:r0 + m], m, Nk_p, D, False, f"attention_split_gemm_pv_d{D}")
+                del p_blk
+            if heads != 1:
+                out[b, :, :, h * D:(h + 1) * D] = oh
+    return Planes(out)
 
 
 def gemv(w, x, bias=None):

@@ -1,0 +1,296 @@
+"""GPU parity of the split-operand PRODUCT path (round 4: csrc/split.hip, the RSVLD_SPLIT instantiations of gemm256 / conv_halo /
+conv_igemm, the fp32-input GroupNorm / LayerNorm that write planes) against plain torch on the host in fp64 -- every kernel through
+the C ABI (rsvld_amd.ops).  What the mode must reproduce: the reference's CPU path, which runs without autocast
+(models/SR_model.py:28-33,57-85; sgm/modules/diffusionmodules/wrappers.py:84-110).
+Tolerance: three bf16 products per fp32 product, fp32 accumulation -> ~1e-5 relative per product; asserted at 1e-4 of the tensor's
+range (measured figures are printed), the bound test_gpu_f32.py uses for round 3's on-the-fly split kernels."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _cmp(got, want, rel, what):
+    got = got.double().cpu()
+    want = want.double()
+    s = float(want.abs().max())
+    e = float((got - want).abs().max())
+    print(f"{what}: max|d| = {e:.3e} (range {s:.2f}, rel {e / max(s, 1e-30):.2e})")
+    assert e <= rel * max(s, 1e-6), f"{what}: max|d| = {e:.3e}, range {s:.3e}"
+    return e
+
+
+def _nhwc(x, dev):
+    return x.permute(0, 2, 3, 1).contiguous().to(dev)
+
+
+def test_split_merge_round_trip_and_weight_triples(cuda):
+    from rsvld_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(37, 5, 72, generator=g) * torch.logspace(-6, 4, 72)).to(cuda)
+    pl = ops.to_planes(x)
+    assert pl.shape == (37, 5, 72) and pl.t.shape == (37, 5, 2, 72) and pl.t.dtype == torch.bfloat16
+    hi, lo = pl.t[..., 1, :].float(), pl.t[..., 0, :].float()
+    assert torch.equal(hi, x.bfloat16().float()) and torch.equal(lo, (x - hi).bfloat16().float())
+    back = pl.f32()
+    assert float(((back - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+    # weight triples: [Cout][taps][hi | lo | hi]
+    w = torch.randn(24, 3 * 3 * 16, generator=g).to(cuda)
+    w3 = torch.empty(24, 9 * 48, device=cuda, dtype=torch.bfloat16)
+    L.check(L.load().rsvld_split_pack_weights(ops._ptr(w), ops._ptr(w3), 24, 9, 16, ops._stream()), "pack")
+    w3 = w3.view(24, 9, 3, 16).float()
+    wr = w.view(24, 9, 16)
+    h = wr.bfloat16().float()
+    assert torch.equal(w3[:, :, 0], h) and torch.equal(w3[:, :, 2], h) and torch.equal(w3[:, :, 1], (wr - h).bfloat16().float())
+
+
+LINEAR_CASES = [
+    # rows, K, N, residual, geglu, out_planes          (gemm256 needs rows >= 4096, N >= 256, >= 128 tiles, K % 32 == 0)
+    (8192, 640, 1920, False, False, True),      # fused q|k|v -> planes
+    (8192 + 77, 1280, 1280, True, False, False),  # to_out with the residual, ragged rows
+    (16384, 320, 2560, False, True, True),      # GEGLU feed-forward -> planes
+    (16384, 1280, 320, True, False, False),     # N = 320: two 256-wide tiles, the second mostly padding
+    (4096, 5120, 1280, True, False, False),     # long K
+    (300, 640, 640, True, False, False),        # small M: the implicit-GEMM kernel
+    (1000, 72, 40, False, False, True),         # K, N multiples of 8 only
+    (2048, 640, 5120, False, True, False),      # GEGLU on the implicit-GEMM kernel, fp32 out
+]
+
+
+@pytest.mark.parametrize("case", LINEAR_CASES)
+def test_linear_split(cuda, case):
+    from rsvld_amd import _lib as L, ops
+    rows, K, N, use_res, geglu, out_planes = case
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    y = x.double() @ w.double().t() + b.double()
+    if geglu:
+        y = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    res = torch.randn(y.shape, generator=g) if use_res else None
+    if use_res:
+        y = y * 0.5 + res.double()
+    pc = ops.pack_conv(w, b, torch.float32, cuda, geglu=geglu)
+    xd = x.to(cuda)
+    with ops.f32_split(True):
+        got_p = ops.linear(ops.to_planes(xd), pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
+                           alpha=0.5 if use_res else 1.0, out_planes=out_planes)
+        got_f = ops.linear(xd, pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
+                           alpha=0.5 if use_res else 1.0)
+    if out_planes:
+        assert isinstance(got_p, ops.Planes) and got_p.shape == tuple(y.shape)
+        got_p = got_p.f32()
+    _cmp(got_p, y, REL, f"linear split (planes in) {case}")
+    _cmp(got_f, y, REL, f"linear split (fp32 in)   {case}")
+    # the round-3 implementation of the same arithmetic (on-the-fly split inside the fp32 family): an independent check
+    old, ops.SPLIT_IMPL = ops.SPLIT_IMPL, "f32"
+    try:
+        with ops.f32_split(True):
+            ref = ops.linear(xd, pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
+                             alpha=0.5 if use_res else 1.0)
+    finally:
+        ops.SPLIT_IMPL = old
+    _cmp(got_f, ref.cpu(), REL, "  planes path vs the fp32 family's split kernel")
+
+
+CONV_CASES = [
+    # B, Cin, Cin2, Cout, H, W, k, stride, pad, upsample, residual, rowvec, stats
+    # (the halo kernels take grids of >= 256 workgroups of 8 x 32 pixels x 128 channels; smaller maps run the gather kernel)
+    (1, 64, 0, 64, 250, 260, 3, 1, 1, False, True, True, True),      # conv_halo_64 (full-resolution SR3 layers), ragged tiles
+    (2, 128, 0, 128, 128, 250, 3, 1, 1, False, True, True, True),    # conv_halo32, NW = 4
+    (1, 192, 64, 128, 512, 256, 3, 1, 1, False, False, False, True),  # two-source (skip concat), NW = 8 (K >= 192, >= 192 16-row tiles)
+    (1, 256, 0, 256, 100, 128, 3, 1, 1, True, False, False, False),  # nearest x2 folded into the halo patch
+    (1, 64, 0, 64, 96, 128, 3, 1, 1, False, True, True, False),      # small map: the gather kernel with the same epilogue
+    (2, 128, 0, 128, 33, 41, 3, 2, (0, 0, 1, 1), False, False, False, False),   # Downsample: stride 2 (implicit GEMM), ragged
+    (1, 8, 0, 128, 40, 40, 3, 1, 1, False, False, False, False),     # conv_in: 3 channels padded to 8
+    (1, 128, 0, 8, 64, 64, 3, 1, 1, False, False, False, False),     # conv_out
+    (1, 320, 0, 640, 24, 24, 1, 1, 0, False, True, False, False),    # 1x1 skip connection with residual
+    (1, 72, 48, 40, 20, 20, 3, 1, 1, False, True, True, False),      # multiples of 8 only, two sources on the gather kernel
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_split(cuda, case):
+    from rsvld_amd import ops
+    B, Cin, Cin2, Cout, H, W, k, stride, pad, up, use_res, use_rv, stats = case
+    g = torch.Generator().manual_seed(abs(hash(case)) % 1000)
+    cin_real = 3 if Cin == 8 else Cin
+    cout_real = 3 if Cout == 8 else Cout
+    x = torch.randn(B, cin_real, H, W, generator=g)
+    x2 = torch.randn(B, Cin2, H, W, generator=g) if Cin2 else None
+    ct = cin_real + Cin2
+    w = torch.randn(cout_real, ct, k, k, generator=g) / math.sqrt(ct * k * k)
+    b = torch.randn(cout_real, generator=g) * 0.1
+    pc = ops.pack_conv(w, b, torch.float32, cuda, cin_split=(cin_real, Cin2) if Cin2 else None)
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    xin, wd, bd = xin.double(), w.double(), b.double()
+    if isinstance(pad, tuple):
+        pt, pl, pb, pr = pad
+        want = F.conv2d(F.pad(xin, (pl, pr, pt, pb)), wd, bd, stride=stride)
+    else:
+        want = F.conv2d(xin, wd, bd, stride=stride, padding=pad)
+    rv = torch.randn(B, cout_real, generator=g) if use_rv else None
+    if use_rv:
+        want = want + rv.double()[:, :, None, None]
+    res = torch.randn(want.shape, generator=g) if use_res else None
+    if use_res:
+        want = want + res.double()
+    xd = ops.nchw_to_nhwc(x.to(cuda), torch.float32)
+    x2d = None if x2 is None else ops.nchw_to_nhwc(x2.to(cuda), torch.float32)
+    rvd = None
+    if use_rv:
+        rvd = torch.zeros(B, pc.cout_p, device=cuda)
+        rvd[:, :cout_real] = rv.to(cuda)
+    with ops.f32_split(True):
+        got = ops.conv2d(xd, pc, x2=x2d, stride=stride, pad=pad, upsample=up, rowvec=rvd, residual=None if res is None else _nhwc(res, cuda),
+                         stats=stats)
+    assert got.dtype == torch.float32 and got.shape == (B, want.shape[2], want.shape[3], pc.cout_p)
+    _cmp(got[..., :cout_real].permute(0, 3, 1, 2), want, REL, f"conv split {case}")
+    if cout_real != pc.cout_p:
+        assert float(got[..., cout_real:].abs().max()) == 0.0
+    if stats:   # (grids large enough for the halo kernels by construction) the epilogue's per-tile (sum, sum of squares) of the stored tensor, merged: what the next GroupNorm consumes
+        part, ntiles = got._gn_part
+        assert part.shape == (B, ntiles, pc.cout_p, 2)
+        tot = part.double().sum(1).cpu()
+        _cmp(tot[..., 0], want.sum((2, 3)), 1e-5 * want[0, 0].numel() ** 0.5, "  epilogue partials: sum")
+        _cmp(tot[..., 1], (want * want).sum((2, 3)), 1e-5, "  epilogue partials: sum of squares")
+
+
+@pytest.mark.parametrize("shape,silu,two", [((2, 128, 19, 23), True, False), ((1, 64, 70, 66), True, True), ((1, 640, 32, 32), False, False),
+                                            ((1, 1920, 16, 16), True, True)])
+def test_group_norm_split(cuda, shape, silu, two):
+    """fp32 NHWC in -> fp32 and planes out; two sources = the skip concat, never materialised; conv2d(norm=) through the same kernels"""
+    from rsvld_amd import ops
+    B, Cc, H, W = shape
+    g = torch.Generator().manual_seed(Cc + H)
+    x = torch.randn(shape, generator=g) * 3.0 + 0.7
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    want = F.group_norm(x.double(), 32, gamma.double(), beta.double(), eps=1e-6)
+    if silu:
+        want = F.silu(want)
+    c1 = Cc // 2 if two else Cc
+    xd = _nhwc(x[:, :c1], cuda)
+    x2d = _nhwc(x[:, c1:], cuda) if two else None
+    with ops.f32_split(True):
+        got = ops.group_norm(xd, gamma.to(cuda), beta.to(cuda), 32, 1e-6, x2=x2d, silu=silu)
+        gp = ops.group_norm(xd, gamma.to(cuda), beta.to(cuda), 32, 1e-6, x2=x2d, silu=silu, planes=True)
+    assert got.dtype == torch.float32 and isinstance(gp, ops.Planes)
+    _cmp(got.permute(0, 3, 1, 2), want, 2e-5, f"group_norm split {shape} fp32 out")
+    _cmp(gp.f32().permute(0, 3, 1, 2), want, 3e-5, f"group_norm split {shape} planes out")
+
+
+def test_group_norm_split_modulated(cuda):
+    """ZeroSFT: norm(x) * (1 + gamma) + beta with gamma | beta two channel slices of one stacked conv output (SR_modules.py:100-106)"""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, Cc, H, W = 2, 320, 16, 24
+    x = torch.randn(B, Cc, H, W, generator=g) * 2 + 0.3
+    gb = torch.randn(B, H, W, 2 * Cc, generator=g) * 0.5
+    want = F.group_norm(x.double(), 32, None, None, eps=1e-5) * (1 + gb[..., :Cc].permute(0, 3, 1, 2).double()) + gb[..., Cc:].permute(0, 3, 1, 2).double()
+    gbd = gb.to(cuda)
+    with ops.f32_split(True):
+        got = ops.group_norm(_nhwc(x, cuda), None, None, 32, 1e-5, mod_scale1p=gbd[..., :Cc], mod_shift=gbd[..., Cc:])
+    _cmp(got.permute(0, 3, 1, 2), want, 2e-5, "group_norm split, modulated")
+
+
+@pytest.mark.parametrize("rows,Cc", [(1000, 640), (4099, 1280), (77, 320), (50, 2048)])
+def test_layer_norm_split(cuda, rows, Cc):
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, Cc, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    want = F.layer_norm(x.double(), (Cc,), gamma.double(), beta.double(), 1e-5)
+    with ops.f32_split(True):
+        got = ops.layer_norm(x.to(cuda), gamma.to(cuda), beta.to(cuda), 1e-5)
+        gp = ops.layer_norm(x.to(cuda), gamma.to(cuda), beta.to(cuda), 1e-5, planes=True)
+    _cmp(got, want, 1e-5, f"layer_norm split {rows}x{Cc} fp32 out")
+    _cmp(gp.f32(), want, 2e-5, f"layer_norm split {rows}x{Cc} planes out")
+
+
+def _attn_ref(q, k, v, heads, scale):
+    B, Nq, HD = q.shape
+    D = HD // heads
+    qh = q.double().view(B, Nq, heads, D).transpose(1, 2)
+    kh = k.double().view(B, -1, heads, D).transpose(1, 2)
+    vh = v.double().view(B, -1, heads, D).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1)
+    return (p @ vh).transpose(1, 2).reshape(B, Nq, HD)
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,peaky", [(2, 5, 300, 300, False), (1, 10, 1024, 1024, True), (2, 20, 200, 77, False), (1, 3, 129, 65, True),
+                                                 (1, 2, 4096, 4096, False)])
+def test_attention_split_d64(cuda, B, heads, Nq, Nk, peaky):
+    """the fused split flash kernel; q | k | v are column slices of ONE fused projection in planes (token stride 2 * 3 * heads * 64),
+    the cross-attention form takes k | v from a second tensor; ``peaky``: large logits (one key dominates a row)"""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(Nq + Nk)
+    HD = heads * 64
+    amp = 3.0 if peaky else 1.0
+    q = torch.randn(B, Nq, HD, generator=g) * amp
+    k = torch.randn(B, Nk, HD, generator=g) * amp
+    v = torch.randn(B, Nk, HD, generator=g)
+    want = _attn_ref(q, k, v, heads, 0.125)
+    if Nq == Nk:
+        qkv = ops.to_planes(torch.cat([q, k, v], -1).to(cuda))
+        qp, kp, vp = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
+    else:
+        qp = ops.to_planes(q.to(cuda))
+        kv = ops.to_planes(torch.cat([k, v], -1).to(cuda))
+        kp, vp = kv[..., :HD], kv[..., HD:]
+    with ops.f32_split(True):
+        got = ops.attention(qp, kp, vp, heads=heads, scale=0.125)
+        got32 = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), heads=heads, scale=0.125)   # fp32 in: split on demand
+    assert isinstance(got, ops.Planes) and got.shape == (B, Nq, HD)
+    _cmp(got.f32(), want, REL, f"attention split d64 B{B} h{heads} {Nq}x{Nk}")
+    _cmp(got32.f32(), want, REL, "  fp32 inputs")
+
+
+@pytest.mark.parametrize("B,Nq,Nk,D,shared", [(1, 200, 200, 512, True), (2, 64, 64, 128, False), (1, 33, 1000, 512, False), (1, 4096, 4096, 512, True),
+                                              (1, 5000, 333, 512, False)])
+def test_attention_split_gemm_form(cuda, B, Nq, Nk, D, shared):
+    """single-head attention (SR3 / VAE: d = 512) as S = Q K^T -> row softmax -> P V on the split GEMMs, keys padded to 8"""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(Nq + Nk + D)
+    q = torch.randn(B, Nq, D, generator=g) * 0.5
+    k = torch.randn(B, Nk, D, generator=g) * 0.5
+    v = k if shared else torch.randn(B, Nk, D, generator=g)
+    want = _attn_ref(q, k, v, 1, D ** -0.5)
+    kd = ops.to_planes(k.to(cuda))
+    with ops.f32_split(True):
+        got = ops.attention(ops.to_planes(q.to(cuda)), kd, kd if shared else ops.to_planes(v.to(cuda)), heads=1, scale=D ** -0.5)
+    _cmp(got.f32(), want, REL, f"attention split (GEMM form) d{D} {Nq}x{Nk} shared={shared}")
+
+
+def test_transformer_block_split_planes_vs_fp32_family(cuda):
+    """one BasicTransformerBlock-shaped chain through the product path (LayerNorm -> planes -> q|k|v -> fused attention -> to_out +
+    residual -> LayerNorm -> GEGLU -> planes -> linear + residual) against the fp32-operand family on the same device"""
+    from rsvld_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(11)
+    N, Cc, heads = 4096, 640, 10
+    x = (torch.randn(1, N, Cc, generator=g)).to(cuda)
+    def lin(o, i):
+        return ops.pack_conv(torch.randn(o, i, generator=g) / math.sqrt(i), torch.randn(o, generator=g) * 0.1, torch.float32, cuda)
+    wqkv, wo, w2 = lin(3 * Cc, Cc), lin(Cc, Cc), lin(Cc, 4 * Cc)
+    wg = ops.pack_conv(torch.randn(8 * Cc, Cc, generator=g) / math.sqrt(Cc), torch.randn(8 * Cc, generator=g) * 0.1, torch.float32, cuda, geglu=True)
+    ga, be = torch.ones(Cc, device=cuda), torch.zeros(Cc, device=cuda)
+
+    def run(planes):
+        n = ops.layer_norm(x, ga, be, planes=planes)
+        qkv = ops.linear(n, wqkv, out_planes=planes)
+        o = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads=heads, scale=0.125)
+        h = ops.linear(o, wo, residual=x)
+        n = ops.layer_norm(h, ga, be, planes=planes)
+        gg = ops.linear(n, wg, act=L.ACT_GEGLU, out_planes=planes)
+        return ops.linear(gg, w2, residual=h)
+
+    want = run(False).cpu()                      # fp32 family
+    with ops.f32_split(True):
+        got = run(True)
+    _cmp(got, want, REL, "transformer block: split product path vs fp32 family")
