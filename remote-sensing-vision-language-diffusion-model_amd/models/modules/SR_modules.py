@@ -47,8 +47,9 @@ class ZeroSFT(nn.Module):
         if h_ori is not None and not self.pre_concat:
             raise NotImplementedError("post-concat ZeroSFT is not instantiated by LightGLVUNet")
         cat = h_ori is not None and self.pre_concat
+        c = ops.maybe_planes(c)                                                      # (split precision: two convs read it)
         hz = ops.conv2d(c, rt.pk(self.zero_conv), pad=0, residual=h)                 # h + zero_conv(c)
-        actv = ops.conv2d(c, rt.pk(self.mlp_shared[0]), pad=1, act=ACT_SILU)
+        actv = ops.conv2d(c, rt.pk(self.mlp_shared[0]), pad=1, act=ACT_SILU, out_planes=True)
         gb = ops.conv2d(actv, rt.pk_cat([self.zero_mul, self.zero_add], "gamma_beta"), pad=1)
         Cn = self.param_free_norm.num_channels
         gn = self.param_free_norm
@@ -73,8 +74,8 @@ class ZeroCrossAttn(nn.Module):
         assert self.mask is False
         B, H, W, Cq = x.shape
         n1, n2 = self.norm1, self.norm2
-        xq = ops.group_norm(x, n1.weight, n1.bias, n1.num_groups, n1.eps).reshape(B, H * W, Cq)
-        ctx = ops.group_norm(context, n2.weight, n2.bias, n2.num_groups, n2.eps)
+        xq = ops.group_norm(x, n1.weight, n1.bias, n1.num_groups, n1.eps, planes=True).reshape(B, H * W, Cq)   # feed linears only
+        ctx = ops.group_norm(context, n2.weight, n2.bias, n2.num_groups, n2.eps, planes=True)
         ctx = ctx.reshape(B, ctx.shape[1] * ctx.shape[2], ctx.shape[3])
         cache, rt.cache_context_kv = rt.cache_context_kv, False   # the control features change every step
         try:

@@ -147,6 +147,9 @@ class Planes:
     def index_select(self, dim, index):
         return Planes(self.t.index_select(dim, index))
 
+    def float(self):
+        return self.f32()
+
     def f32(self):
         """-> the fp32 tensor hi + lo (rsvld_merge_planes)."""
         t = self.t.contiguous()
@@ -174,6 +177,14 @@ def to_planes(x):
 
 def as_f32(x):
     return x.f32() if isinstance(x, Planes) else x
+
+
+def maybe_planes(x):
+    """In the split precision: the planes of an fp32 tensor that SEVERAL matrix products are about to read (split it once instead
+    of once per product); any other mode / tensor passes through."""
+    if _split_fast() and not isinstance(x, Planes) and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 8 == 0:
+        return to_planes(x)
+    return x
 
 
 def _tune_from_env():

@@ -46,7 +46,7 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim))
 
     def run(self, rt, x_norm, residual):
-        g = ops.linear(x_norm, rt.pk(self.net[0].proj, "geglu", geglu=True), act=ACT_GEGLU)
+        g = ops.linear(x_norm, rt.pk(self.net[0].proj, "geglu", geglu=True), act=ACT_GEGLU, out_planes=True)   # feeds a linear only
         return ops.linear(g, rt.pk(self.net[2]), residual=residual)
 
 
@@ -66,21 +66,23 @@ class CrossAttention(nn.Module):
         """x ``[B,N,C]`` (already normalised), context ``[B,M,Cc]`` or None -> to_out(attn)*alpha + residual."""
         inner = self.heads * self.dim_head
         if context is None:
-            qkv = ops.linear(x, rt.pk_cat([self.to_q, self.to_k, self.to_v], "qkv"))
+            qkv = ops.linear(x, rt.pk_cat([self.to_q, self.to_k, self.to_v], "qkv"), out_planes=True)   # feeds the attention only
             q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
         else:
-            q = ops.linear(x, rt.pk(self.to_q))
+            q = ops.linear(x, rt.pk(self.to_q), out_planes=True)
             rows = None
             if isinstance(context, RowSubset):   # a sub-batch of a cached context: project the full one, pick rows
                 context, rows = context.full, context.rows
             # valid only while the very same tensor object (held alive here) is passed, unmodified
-            ent = rt._pk.get(("ctx_kv", id(self))) if rt.cache_context_kv else None
+            # (keyed on the precision too: fp32 and split share one pack dictionary, and a cached K/V is a tensor of ONE of them)
+            ckey = ("ctx_kv", id(self), ops._split_fast())
+            ent = rt._pk.get(ckey) if rt.cache_context_kv else None
             if ent is not None and ent[0] is context and ent[1] == context._version:
                 kv = ent[2]
             else:
-                kv = ops.linear(context, rt.pk_cat([self.to_k, self.to_v], "kv"))
+                kv = ops.linear(context, rt.pk_cat([self.to_k, self.to_v], "kv"), out_planes=True)
                 if rt.cache_context_kv:
-                    rt._pk[("ctx_kv", id(self))] = (context, context._version, kv)
+                    rt._pk[ckey] = (context, context._version, kv)
             if rows is not None:
                 kv = kv.index_select(0, rows)
             k, v = kv[..., :inner], kv[..., inner:]
@@ -107,11 +109,11 @@ class BasicTransformerBlock(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
 
     def run(self, rt, x, context=None):
-        n = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        n = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, planes=True)
         x = self.attn1.run(rt, n, context if self.disable_self_attn else None, residual=x)
-        n = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        n = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, planes=True)
         x = self.attn2.run(rt, n, context, residual=x)
-        n = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        n = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps, planes=True)
         return self.ff.run(rt, n, residual=x)
 
 
@@ -144,7 +146,7 @@ class SpatialTransformer(nn.Module):
         """x NHWC ``[B,H,W,C]`` -> same shape."""
         B, H, W, Cc = x.shape
         contexts = context if isinstance(context, list) else [context]
-        h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps)
+        h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, planes=True)
         h = ops.linear(h.reshape(B, H * W, Cc), rt.pk(self.proj_in))
         for i, blk in enumerate(self.transformer_blocks):
             h = blk.run(rt, h, contexts[i if len(contexts) > 1 else 0])

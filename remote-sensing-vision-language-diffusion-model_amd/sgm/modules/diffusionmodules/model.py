@@ -82,9 +82,10 @@ class ResnetBlock(nn.Module):
 
 
 def _gn(x, norm, silu, stats=None):
+    """(planes=True: honoured in the split precision only -- every GroupNorm of the VAE feeds a convolution)"""
     if stats is None:
-        return ops.group_norm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
-    return ops.group_norm_apply(x, stats, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
+        return ops.group_norm(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, planes=True)
+    return ops.group_norm_apply(x, stats, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, planes=True)
 
 
 class AttnBlock(nn.Module):
@@ -102,7 +103,7 @@ class AttnBlock(nn.Module):
     def run(self, rt, x, norm_stats=None):
         B, H, W, Cc = x.shape
         h = _gn(x, self.norm, False, norm_stats)
-        qkv = ops.conv2d(h, rt.pk_cat([self.q, self.k, self.v], "qkv"), pad=0).reshape(B, H * W, 3 * Cc)
+        qkv = ops.conv2d(h, rt.pk_cat([self.q, self.k, self.v], "qkv"), pad=0, out_planes=True).reshape(B, H * W, 3 * Cc)
         o = ops.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads=1, scale=Cc ** -0.5)
         return ops.conv2d(o.reshape(B, H, W, Cc), rt.pk(self.proj_out), pad=0, residual=x)
 

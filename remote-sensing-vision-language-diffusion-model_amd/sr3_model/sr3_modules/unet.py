@@ -278,8 +278,9 @@ class UNet(nn.Module):
 
     def _attention(self, at, x):
         B, H, W, Cc = x.shape
-        n = ops.group_norm(x, at.norm.weight, at.norm.bias, at.norm.num_groups, at.norm.eps)
-        q = ops.conv2d(n, self._pk[("attn_q", id(at))], pad=0).reshape(B, H * W, Cc)
+        # (planes / out_planes: honoured in the split precision only -- n feeds the query conv and the attention, q the attention)
+        n = ops.group_norm(x, at.norm.weight, at.norm.bias, at.norm.num_groups, at.norm.eps, planes=True)
+        q = ops.conv2d(n, self._pk[("attn_q", id(at))], pad=0, out_planes=True).reshape(B, H * W, Cc)
         kv = n.reshape(B, H * W, Cc)              # keys and values are the normalised input itself (_pack_attention)
         o = ops.attention(q, kv, kv, heads=1, scale=1.0 / math.sqrt(Cc))  # scale uses the full channel count (unet.py:135)
         return ops.conv2d(o.reshape(B, H, W, Cc), self._pk[("attn_out", id(at))], pad=0, residual=x)

@@ -74,7 +74,7 @@ def merge_stats(stats, pixels):
 # ---- per-tile programs (generators yielding (tensor, norm_layer) at every GroupNorm) -----------------
 def _norm(x, norm, silu):
     stats = yield (x, norm)
-    return ops.group_norm_apply(x, stats, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu)
+    return ops.group_norm_apply(x, stats, norm.weight, norm.bias, norm.num_groups, norm.eps, silu=silu, planes=True)   # feeds a conv
 
 
 def _resblock(rt, blk, x):
@@ -88,7 +88,7 @@ def _resblock(rt, blk, x):
 def _attn(rt, at, x):
     B, H, W, Cc = x.shape
     h = yield from _norm(x, at.norm, False)
-    qkv = ops.conv2d(h, rt.pk_cat([at.q, at.k, at.v], "qkv"), pad=0).reshape(B, H * W, 3 * Cc)
+    qkv = ops.conv2d(h, rt.pk_cat([at.q, at.k, at.v], "qkv"), pad=0, out_planes=True).reshape(B, H * W, 3 * Cc)
     o = ops.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads=1, scale=Cc ** -0.5)
     return ops.conv2d(o.reshape(B, H, W, Cc), rt.pk(at.proj_out), pad=0, residual=x)
 
