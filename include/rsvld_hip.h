@@ -397,6 +397,13 @@ int rsvld_attention_split_d64(const void* q, const void* k, const void* v, void*
                               int64_t v_batch_stride, int64_t v_tok_stride, int64_t v_plane,
                               int64_t o_batch_stride, int64_t o_tok_stride, int64_t o_plane,
                               float scale, int out_f32, void* stream);
+/* The same for ONE head of D = 512 whose keys and values are the SAME planes tensor x (SR3 SelfAttention after the pack-time
+ * re-association, sr3_modules/unet.py:114-143): two waves share 32 query rows, each owning half of the head dimension. */
+int rsvld_attention_split_d512_shared(const void* q, const void* x, void* out, int B, int Nq, int Nk,
+                                      int64_t q_batch_stride, int64_t q_tok_stride, int64_t q_plane,
+                                      int64_t x_batch_stride, int64_t x_tok_stride, int64_t x_plane,
+                                      int64_t o_batch_stride, int64_t o_tok_stride, int64_t o_plane,
+                                      float scale, int out_f32, void* stream);
 
 #ifdef __cplusplus
 }

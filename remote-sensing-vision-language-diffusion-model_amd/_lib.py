@@ -106,6 +106,7 @@ SIGNATURES = {
     "rsvld_groupnorm_scale_shift_from_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "rsvld_groupnorm_apply_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "rsvld_layernorm_split": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
+    "rsvld_attention_split_d512_shared": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _vp]),
     "rsvld_attention_split_d64": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i, _vp]),
 }

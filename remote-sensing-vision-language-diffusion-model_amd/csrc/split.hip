@@ -405,6 +405,260 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Flash attention on planes, single head, d = 512, keys and values THE SAME tensor X (SR3's SelfAttention after the pack-time
+// re-association of sr3_modules/unet.py:114-143: keys and values are the normalised input itself, csrc/attention.hip "SH").
+//
+// The 16-bit kernel gives one wave 32 query rows over the whole head dimension: Q in 128 registers, O^T in 256.  With split
+// operands Q is two planes (256 registers) and the register file cannot hold that next to O^T.  Here TWO waves share 32 query rows,
+// each owning HALF of the head dimension -- its 256 channels of Q_hi | Q_lo (128 registers) and of O^T (128 registers):
+//   S^T  : a wave contracts its own 256 channels (16 k-steps x 3 terms = 48 MFMAs) -> a PARTIAL score tile; the two partials
+//          are exchanged through LDS (4 KiB per wave) and added -- both waves then hold the same scores bit for bit (a + b = b + a)
+//          and take identical softmax decisions;
+//   PV   : P (hi | lo split in registers after the fp32 softmax) times the wave's own 256 channels of X: 8 x 2 x 3 = 48 MFMAs.
+// No MFMA is issued twice; the softmax (16 scores per lane) is -- 96 MFMAs per wave and 32-key tile against ~150 vector instructions.
+// X tiles (32 keys x 512, planes lo | hi = 64 KiB) are double-buffered by LDS-DMA into the dual-use image of the 16-bit kernel
+// (chunk c of row r at c ^ f(r): conflict-free for the row-wise K reads AND the transposed V reads), one workgroup (4 waves, 64
+// query rows) per CU.  Two barriers per tile (score exchange; ring), the first one only behind the 48 MFMAs of the S chain.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct AttnSplit512Args {
+    const bf16* q; const bf16* x; void* out;
+    int Nq, Nk;
+    int64_t q_bs, q_ts, q_pl, x_bs, x_ts, x_pl, o_bs, o_ts, o_pl;
+    float scale_log2e;
+    int out_f32;
+};
+constexpr int A5S_IMG = 32 * 1024;            // one plane of a 32-key tile
+constexpr int A5S_STAGE = 2 * A5S_IMG;        // lo | hi
+constexpr int A5S_XCH = 2 * A5S_STAGE;        // score exchange: 4 waves x 4 KiB
+constexpr int A5S_SMEM = A5S_XCH + 4 * 4096;
+__host__ __device__ constexpr int a5s_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+__global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = w >> 1, half = w & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * 64 + pair * 32, b = blockIdx.y;
+    const bf16* Qb = p.q + (int64_t)b * p.q_bs;
+    const bf16* Xb = p.x + (int64_t)b * p.x_bs;
+    const int nt = (p.Nk + 31) >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+
+    // ---- tile DMA (inline asm: the compiler must not know of it, or it drains vmcnt in front of every LDS read that follows; M0 is
+    // saved and restored inside the statement).  Wave w moves key rows 8w .. 8w+7 of both planes, one 1-KiB row per piece; lane ->
+    // LDS chunk position `lane`, source chunk lane ^ f(row & 15).
+    auto dma_one = [&](const char* base, uint32_t voff, uint32_t dst) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    };
+    const int64_t rowb = p.x_ts * (int64_t)sizeof(bf16), plb = p.x_pl * (int64_t)sizeof(bf16);
+    uint32_t xvo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xvo[i] = (uint32_t)(i * rowb) + (uint32_t)((lane ^ a5s_f((w * 8 + i) & 15)) << 4);
+    const char* x_tile0 = (const char*)(Xb + (int64_t)(w * 8) * p.x_ts);
+    auto dma_piece = [&](int t, int j) {   // j = 0..15: row 8w + (j >> 1) of plane j & 1 of tile t -> stage t & 1
+        const int i = j >> 1, pl = j & 1, r = w * 8 + i;
+        const uint32_t dst = lds0 + (t & 1) * A5S_STAGE + pl * A5S_IMG + r * 1024;
+        if (t * 32 + 32 <= p.Nk) {
+            dma_one(x_tile0 + (int64_t)t * 32 * rowb + pl * plb, xvo[i], dst);
+        } else {   // ragged last tile: rows past Nk re-read the last key; their scores are masked
+            const int key = min(t * 32 + r, p.Nk - 1);
+            dma_one((const char*)(Xb + (int64_t)key * p.x_ts) + pl * plb, (uint32_t)((lane ^ a5s_f(r & 15)) << 4), dst);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma_piece(0, j);
+
+    // ---- Q fragments of this wave's 256 channels (B operand: column = the lane's query row), scaled in fp32 and re-split
+    const int qrow = q0 + l31;
+    bf16x8 qh[16], ql[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        if (qrow < p.Nq) {
+            const bf16* qp = Qb + (int64_t)qrow * p.q_ts + (16 * half + ks) * 16 + lh * 8;
+            float l[8], hh[8];
+            unpack8<bf16>(*(const u32x4*)qp, l);
+            unpack8<bf16>(*(const u32x4*)(qp + p.q_pl), hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (hh[e] + l[e]) * p.scale_log2e;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qh[ks][e] = (bf16)f[e];
+            ql[ks][e] = (bf16)(f[e] - (float)qh[ks][e]);
+        }
+    }
+    f32x16 oacc[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // per-lane read offsets.  K: row l31, chunk 2 ksg + lh (ksg = 16 half + ks) = 16 a + (2 c + lh): off = kbase[c] + 256 a
+    int kbase[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) kbase[c] = l31 * 1024 + (((2 * c + lh) ^ a5s_f(l31 & 15)) << 4);
+    // V (transposed read): lane 16g + 4q + p supplies row (4 lh + q) + {16 s + 8 hf}, d = 32 dtg + 16 (g&1) + 4p .. +3 (dtg = 8 half + dt);
+    // with dtg = 4 e + f: off = vbase[f] + 256 e + 1024 (16 s), the hf = 1 rows at (off ^ 32) + 8 * 1024
+    int vbase[4];
+    {
+        const int qq = (lane >> 2) & 3, pp = lane & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            vbase[f] = (4 * lh + qq) * 1024 + ((f ^ qq) << 6) + (((2 * g1 + (pp >> 1)) ^ lh) << 4) + ((pp & 1) << 3);
+    }
+    auto read_vt = [&](const char* img, int off) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + (off ^ 32) + 8 * 1024));
+        typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    char* xch_own = smem + A5S_XCH + w * 4096 + lane * 16;
+    const char* xch_peer = smem + A5S_XCH + (w ^ 1) * 4096 + lane * 16;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tile 0 landed
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int t = 0; t < nt; ++t) {
+        const char* Il = smem + (t & 1) * A5S_STAGE;
+        const char* Ih = Il + A5S_IMG;
+        const bool more = t + 1 < nt;
+
+        // ---- partial S^T over this wave's 256 channels; the 16 LDS-DMA pieces of tile t + 1 are issued between the k-steps (the
+        // other stage was last read in iteration t - 1, behind its closing barrier).  Fragments of k-step ks + 1 are requested
+        // before the MFMAs of k-step ks.
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        bf16x8 kl[2], kh[2];
+        {
+            const int o = kbase[0] + 256 * (2 * half);
+            kl[0] = *(const bf16x8*)(Il + o);
+            kh[0] = *(const bf16x8*)(Ih + o);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 1 < 16) {
+                const int o = kbase[(ks + 1) & 7] + 256 * (2 * half + ((ks + 1) >> 3));
+                kl[(ks + 1) & 1] = *(const bf16x8*)(Il + o);
+                kh[(ks + 1) & 1] = *(const bf16x8*)(Ih + o);
+            }
+            sacc = mma_bf16(kl[ks & 1], qh[ks], sacc);
+            sacc = mma_bf16(kh[ks & 1], ql[ks], sacc);
+            sacc = mma_bf16(kh[ks & 1], qh[ks], sacc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) dma_piece(t + 1, ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- exchange the partials with the other half's wave
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(f32x4*)(xch_own + g * 1024) = (f32x4){sacc[4 * g], sacc[4 * g + 1], sacc[4 * g + 2], sacc[4 * g + 3]};
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 o = *(const f32x4*)(xch_peer + g * 1024);
+            sacc[4 * g] += o[0]; sacc[4 * g + 1] += o[1]; sacc[4 * g + 2] += o[2]; sacc[4 * g + 3] += o[3];
+        }
+        if ((t + 1) * 32 > p.Nk) {   // ragged last tile (uniform branch)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (kv >= p.Nk) sacc[r] = -INFINITY;
+            }
+        }
+        // ---- online softmax in fp32, deferred maximum (the reference point moves only when a row outgrows it by 2^8: P <= 2^8 is
+        // as good a bf16 hi | lo pair as P <= 1, and the rescale of O is skipped on almost every tile)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+        {
+            const uint32_t mb = __builtin_bit_cast(uint32_t, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+        }
+        float alpha = 1.0f;
+        const bool need = mx > m_run + 8.0f;   // true on the first tile (m_run = -inf)
+        if (need) {
+            alpha = __builtin_amdgcn_exp2f(m_run - mx);
+            m_run = mx;
+        }
+        float rs = 0.f;
+        bf16x8 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(sacc[r] - m_run);
+            rs += pv;
+            const bf16 hv = (bf16)pv;
+            ph[r >> 3][r & 7] = hv;
+            pl[r >> 3][r & 7] = (bf16)(pv - (float)hv);
+        }
+        l_run = l_run * alpha + rs;
+        if (__builtin_expect(__any(need), 0)) {
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
+        // ---- O^T[d][q] += X^T P^T over this wave's 8 d-blocks: 2 key steps x 3 terms each, fragments one pair ahead
+        bf16x8 vl[2], vh[2];
+        auto vreq = [&](int n, int slot) {   // n = 2 dt + s
+            const int dtg = 8 * half + (n >> 1), s2 = n & 1;
+            const int off = vbase[dtg & 3] + (dtg >> 2) * 256 + (16 * s2) * 1024;
+            vl[slot] = read_vt(Il, off);
+            vh[slot] = read_vt(Ih, off);
+        };
+        vreq(0, 0);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            if (n + 1 < 16) vreq(n + 1, (n + 1) & 1);
+            oacc[n >> 1] = mma_bf16(vh[n & 1], pl[n & 1], oacc[n >> 1]);
+            oacc[n >> 1] = mma_bf16(vl[n & 1], ph[n & 1], oacc[n >> 1]);
+            oacc[n >> 1] = mma_bf16(vh[n & 1], ph[n & 1], oacc[n >> 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile t + 1 landed; everyone done with this stage and the exchange
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (qrow >= p.Nq) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int d0 = 256 * half;
+    if (p.out_f32) {
+        float* Ob = (float*)p.out + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_ts + d0;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(Ob + dt * 32 + 8 * g + 4 * lh) = (f32x4){oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv,
+                                                                  oacc[dt][4 * g + 3] * inv};
+    } else {
+        bf16* Ob = (bf16*)p.out + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_ts + d0;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = oacc[dt][4 * g + e] * inv;
+                    hv[e] = (bf16)o;
+                    lv[e] = (bf16)(o - (float)hv[e]);
+                }
+                *(bf16x4*)(Ob + dt * 32 + 8 * g + 4 * lh) = lv;
+                *(bf16x4*)(Ob + p.o_pl + dt * 32 + 8 * g + 4 * lh) = hv;
+            }
+    }
+}
+
 static unsigned ew_blocks(int64_t items) {
     int64_t b = cdiv64(items, 256);
     return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -478,5 +732,26 @@ extern "C" int rsvld_attention_split_d64(const void* q, const void* k, const voi
     if (attr != hipSuccess) return RSVLD_ELAUNCH;
     dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
     hipLaunchKernelGGL(attn_split_d64_kernel, grid, dim3(256), AS_SMEM, (hipStream_t)stream, a);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_attention_split_d512_shared(const void* q, const void* x, void* out, int B, int Nq, int Nk,
+                                                 int64_t q_batch_stride, int64_t q_tok_stride, int64_t q_plane, int64_t x_batch_stride,
+                                                 int64_t x_tok_stride, int64_t x_plane, int64_t o_batch_stride, int64_t o_tok_stride,
+                                                 int64_t o_plane, float scale, int out_f32, void* stream) {
+    if (!q || !x || !out || B < 1 || Nq < 1 || Nk < 1) return RSVLD_EINVAL;
+    if (B > 65535) return RSVLD_EUNSUPPORTED;
+    if ((q_batch_stride | q_tok_stride | q_plane | x_batch_stride | x_tok_stride | x_plane) % 8 != 0) return RSVLD_EINVAL;
+    if ((o_batch_stride | o_tok_stride | o_plane) % 4 != 0) return RSVLD_EINVAL;
+    if (x_tok_stride * 2 * 8 >= ((int64_t)1 << 32)) return RSVLD_EUNSUPPORTED;   // 32-bit lane offsets inside a piece group
+    AttnSplit512Args a;
+    a.q = (const bf16*)q; a.x = (const bf16*)x; a.out = out; a.Nq = Nq; a.Nk = Nk;
+    a.q_bs = q_batch_stride; a.q_ts = q_tok_stride; a.q_pl = q_plane; a.x_bs = x_batch_stride; a.x_ts = x_tok_stride; a.x_pl = x_plane;
+    a.o_bs = o_batch_stride; a.o_ts = o_tok_stride; a.o_pl = o_plane;
+    a.scale_log2e = scale * 1.44269504088896340736f;
+    a.out_f32 = out_f32 ? 1 : 0;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)attn_split_d512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, A5S_SMEM);
+    if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    hipLaunchKernelGGL(attn_split_d512_kernel, dim3((unsigned)((Nq + 63) / 64), (unsigned)B), dim3(256), A5S_SMEM, (hipStream_t)stream, a);
     return rsvld_check_launch();
 }

@@ -787,6 +787,7 @@ def attention(q, k, v, heads, scale=None):
     return out
 
 
+SPLIT_D512_FUSED_MIN = int(os.environ.get("RSVLD_SPLIT_D512_FUSED_MIN", "2048"))   # query rows from which the fused d = 512 kernel runs (64 per workgroup)
 SPLIT_ATTN_S_BYTES = int(os.environ.get("RSVLD_SPLIT_ATTN_S_BYTES", str(32 << 30)))   # fp32 score block of the GEMM form (P planes: as much again)
 
 
@@ -832,6 +833,14 @@ def _attention_split(q, k, v, heads, scale):
             q.t.stride(0), q.t.stride(1), q.t.stride(2), k.t.stride(0), k.t.stride(1), k.t.stride(2),
             v.t.stride(0), v.t.stride(1), v.t.stride(2), out.stride(0), out.stride(1), out.stride(2), scale, 0, _stream()),
             "rsvld_attention_split_d64"))
+        return Planes(out)
+    if D == 512 and heads == 1 and shared and Nq >= SPLIT_D512_FUSED_MIN:
+        # keys and values are ONE planes tensor (SR3's re-associated SelfAttention): the fused kernel, two waves per 32 query rows
+        nbytes = 4.0 * (2 * B * Nq * HD + B * Nk * HD)
+        _launch("attention_split_d512", flops, nbytes, lambda: L.check(lib.rsvld_attention_split_d512_shared(
+            _ptr(q.t), _ptr(k.t), _ptr(out), B, Nq, Nk, q.t.stride(0), q.t.stride(1), q.t.stride(2),
+            k.t.stride(0), k.t.stride(1), k.t.stride(2), out.stride(0), out.stride(1), out.stride(2), scale, 0, _stream()),
+            "rsvld_attention_split_d512_shared"))
         return Planes(out)
     if D % 8:
         raise L.RsvldError("attention (split): head dim must be a multiple of 8")

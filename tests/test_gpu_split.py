@@ -294,3 +294,26 @@ def test_transformer_block_split_planes_vs_fp32_family(cuda):
     with ops.f32_split(True):
         got = run(True)
     _cmp(got, want, REL, "transformer block: split product path vs fp32 family")
+
+
+@pytest.mark.parametrize("B,Nq,Nk", [(1, 64, 64), (2, 200, 333), (1, 4096, 4096), (1, 1000, 8200)])
+def test_attention_split_d512_fused(cuda, B, Nq, Nk):
+    """the fused split kernel for ONE head of d = 512 with keys = values = the same planes tensor (SR3's re-associated SelfAttention):
+    two waves share 32 query rows, each contracting half of the head dimension; against fp64 on the host and the GEMM form"""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q = torch.randn(B, Nq, 512, generator=g) * 0.7
+    x = torch.randn(B, Nk, 512, generator=g) * 0.7
+    want = _attn_ref(q, x, x, 1, 512 ** -0.5)
+    qp, xp = ops.to_planes(q.to(cuda)), ops.to_planes(x.to(cuda))
+    old = ops.SPLIT_D512_FUSED_MIN
+    try:
+        with ops.f32_split(True):
+            ops.SPLIT_D512_FUSED_MIN = 1
+            got = ops.attention(qp, xp, xp, heads=1, scale=512 ** -0.5)
+            ops.SPLIT_D512_FUSED_MIN = 1 << 30
+            ref = ops.attention(qp, xp, xp, heads=1, scale=512 ** -0.5)
+    finally:
+        ops.SPLIT_D512_FUSED_MIN = old
+    _cmp(got.f32(), want, REL, f"attention split d512 fused B{B} {Nq}x{Nk}")
+    _cmp(got.f32(), ref.f32().cpu(), REL, "  fused vs GEMM form")
