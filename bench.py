@@ -180,6 +180,8 @@ def build_stage2(dev, tile_vae, live_conditioner=False):
     _seed_stage2_on_device(torch.nn.ModuleList([mod for mod in keep if isinstance(mod, (torch.nn.Linear, torch.nn.Conv2d))]), dev)
     if PRECISION in ("fp32", "split"):
         m.set_precision(PRECISION, PRECISION)
+    elif PRECISION == "vae-split":      # model_configs/juggernautXL_vae_split.yaml: the four VAE passes in the split precision only
+        m.set_precision("split", "fp16")
     if tile_vae:   # SR_model.py:95-125: encoder tiles of 512 px, decoder tiles of 64 latent px, cross-tile GroupNorm
         m.init_tile_vae(512, 64)
     return m
@@ -545,7 +547,8 @@ def bench_headline(args, dev, rank, world):
             "metric": METRIC if is_metric_cfg else f"two-stage SR images/sec @{T} steps, {args.lr_side}px x{args.scale} (secondary workload)",
             "value": round(value, 6), "unit": "img/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "split": "f32 tensors, bf16 hi+lo split operands (3 MFMAs per product)"}.get(
+            "dtype": {"fp32": "f32", "split": "f32 tensors, bf16 hi+lo split operands (3 MFMAs per product)",
+                      "vae-split": "f16 (UNets, fp32 accumulate); VAE: f32 tensors, bf16 hi+lo split operands"}.get(
                 PRECISION, "f16 (UNets, fp32 accumulate), bf16 (VAE)"), "data": "synthetic",
             "config": {
                 "workload": ((f"BASELINE configs[3]/[4] shape = the metric's configuration: " if is_metric_cfg else
@@ -772,7 +775,7 @@ def main():
     ap.add_argument("--cached-cond", action="store_true", help="c4 / c4full: cached text embeddings (PreparedConditioner) and no "
                                                                 "caption pass, as rounds 1-2 measured (default: live LLaVA-NeXT "
                                                                 "caption + live text towers, BASELINE configs[3])")
-    ap.add_argument("--precision", default="default", choices=["default", "fp32", "split"],
+    ap.add_argument("--precision", default="default", choices=["default", "fp32", "split", "vae-split"],
                     help="fp32: both stages on the fp32-operand kernel family (the reference's CPU-path precision); split: fp32 tensors "
                          "with every matrix product as three 16-bit MFMAs on hi + lo bf16 operands; secondary measurements only -- the "
                          "metric is quoted on the reference's GPU policy (fp16 UNets, bf16 VAE)")

@@ -237,6 +237,7 @@ class LaunchProfiler:
 
 
 _PROFILER = None
+PROFILE_DETAIL = bool(os.environ.get("RSVLD_PROFILE_DETAIL"))   # tools: append the layer shape to the profiler group name
 
 
 def set_profiler(p):
@@ -529,6 +530,12 @@ def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None):
     return out
 
 
+def _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample):
+    if not PROFILE_DETAIL:
+        return ""
+    return f" [{B}x{Ho}x{Wo} {Cin}+{Cin2}->{pc.cout_p} k{pc.kh} s{stride}{' up' if upsample else ''}]"
+
+
 def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm, stats, out_planes):
     """The split-operand product path of conv2d / linear: bf16 planes in (split here when the caller hands fp32), weight triples,
     the 16-bit kernels with dtype RSVLD_SPLIT; fp32 (or Planes) out, fp32 residual."""
@@ -591,7 +598,7 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
         if stats and not out_planes:
             ntiles = ((Ho + 7) // 8) * ((Wo + 31) // 32)
             part_out = torch.empty((B, ntiles, pc.cout_p, 2), device=x.device, dtype=torch.float32)
-        _launch("conv_halo_64_split" if pc.cout_p <= 64 else "conv_halo_128_split", flops, nbytes, lambda: L.check(
+        _launch(("conv_halo_64_split" if pc.cout_p <= 64 else "conv_halo_128_split") + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes, lambda: L.check(
             lib.rsvld_conv3x3_halo_nhwc(C.byref(d), None, 0, _ptr(part_out), _stream()), "rsvld_conv3x3_halo_nhwc"))
         if part_out is not None:
             out._gn_part = (part_out, ntiles)
@@ -601,7 +608,7 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
         g256 = (pc.kh == 1 and pc.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not upsample and x2 is None and rowvec is None
                 and Cin % 32 == 0 and pc.cout_p >= 256 and Mp >= 4096 and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128
                 and 256 * Cin * 6 < 2 ** 32 and not (TUNE & L.TUNE_NO_GEMM256))   # mirrors rsvld_gemm256_try
-        _launch("gemm_256x256_split" if g256 else "conv_igemm_split", flops, nbytes,
+        _launch(("gemm_256x256_split" if g256 else "conv_igemm_split") + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes,
                 lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
     if out_planes:
         return Planes(out)

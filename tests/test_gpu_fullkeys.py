@@ -29,8 +29,10 @@ def test_attention_d512_262144_keys_vs_host_fp32(cuda, shared):
     from rsvld_amd import ops
     N, D = 262144, 512
     g = torch.Generator(device="cuda").manual_seed(17 + int(shared))
-    q = (torch.randn(1, N, D, device=cuda, generator=g) * 0.6).half()
-    k = (torch.randn(1, N, D, device=cuda, generator=g) * 0.6).half()
+    # (amplitude 1.5: scores of standard deviation 2.25, i.e. a softmax that a few hundred of the 262 144 keys dominate -- with
+    #  near-uniform weights every output would be the mean of V and any kernel would pass)
+    q = (torch.randn(1, N, D, device=cuda, generator=g) * 1.5).half()
+    k = (torch.randn(1, N, D, device=cuda, generator=g) * 1.5).half()
     v = k if shared else torch.randn(1, N, D, device=cuda, generator=g).half()
     out = ops.attention(q, k, v, heads=1, scale=D ** -0.5)
     rows = torch.randint(0, N, (256,), device=cuda, generator=g)
@@ -38,7 +40,7 @@ def test_attention_d512_262144_keys_vs_host_fp32(cuda, shared):
     got = out[0, rows].float().cpu()
     e, r = float((got - want).abs().max()), float(want.abs().max())
     print(f"d512 attention, 262 144 keys, shared={shared}: 256 sampled rows vs host fp32: max|d| = {e:.3e} (range {r:.3f})")
-    assert e <= TOL * max(r, 1.0)
+    assert r > 0.3 and e <= TOL * r
 
 
 def test_attention_d64_65536_tokens_pingpong_grid_vs_host_fp32(cuda):
@@ -47,7 +49,7 @@ def test_attention_d64_65536_tokens_pingpong_grid_vs_host_fp32(cuda):
     from rsvld_amd import ops
     N, heads, D = 65536, 8, 64
     g = torch.Generator(device="cuda").manual_seed(23)
-    qkv = torch.randn(1, N, 3 * heads * D, device=cuda, generator=g).half()
+    qkv = (torch.randn(1, N, 3 * heads * D, device=cuda, generator=g) * 1.7).half()    # scores of standard deviation ~2.9: a peaked softmax
     HD = heads * D
     q, k, v = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
     out = ops.attention(q, k, v, heads=heads, scale=D ** -0.5)
@@ -60,7 +62,7 @@ def test_attention_d64_65536_tokens_pingpong_grid_vs_host_fp32(cuda):
         got = out[0, rows][:, sl].float().cpu()
         worst, rng = max(worst, float((got - want).abs().max())), max(rng, float(want.abs().max()))
     print(f"d64 attention, 65 536 tokens x 8 heads (ping-pong grid): 256 sampled rows vs host fp32: max|d| = {worst:.3e} (range {rng:.3f})")
-    assert worst <= TOL * max(rng, 1.0)
+    assert rng > 0.5 and worst <= TOL * rng
 
 
 @pytest.mark.parametrize("cin,cout,H,W,norm", [(192, 128, 512, 4096, False),   # conv_halo32, NW = 8: 16 x 32-pixel tiles (>= 192 of them, K >= 192)

@@ -261,3 +261,13 @@ def test_tiled_sampler_oracle_single_tile_equals_untiled(model):
         x, _ = O.restore_edm_step(sd, table, None, x, i, sigmas, c, uc, xc, opt, 0.0, lambda shape: next(it))
     assert torch.isfinite(tiled).all()
     assert _d(tiled, x) < 1e-5 * max(1.0, float(x.abs().max()))
+
+
+def test_vae_split_yaml_is_the_shipped_yaml_with_one_change():
+    """model_configs/juggernautXL_vae_split.yaml = the shipped plugin registry with ``ae_dtype: split`` and nothing else changed."""
+    import yaml
+    base = yaml.safe_load(open(S.YAML))
+    alt = yaml.safe_load(open(os.path.join(os.path.dirname(S.YAML), "juggernautXL_vae_split.yaml")))
+    assert alt["model"]["params"]["ae_dtype"] == "split" and base["model"]["params"]["ae_dtype"] == "bf16"
+    alt["model"]["params"]["ae_dtype"] = "bf16"
+    assert alt == base
