@@ -221,27 +221,47 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
     const bf16* Kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * 64;
     const bf16* Vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * 64;
     const int nt = (p.Nk + 63) >> 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
 
-    // ---- tile DMA: wave w moves key rows 16 w .. 16 w + 15 of each of the four planes, two pieces of 8 rows x 128 B each.
-    // Lane (row = lane>>3, pos = lane&7) fills LDS chunk `pos` of its row with source chunk pos ^ ((r16>>1)&7) for K and
-    // pos ^ (((r16>>1)&1)<<2) for V (r16 = tile row & 15): the images the fragment reads below expect (attention.hip).
-    auto dma_tile = [&](int t) {
-        const int buf = t & 1;
+    // ---- tile DMA (inline asm: a DMA the compiler knows of makes it drain vmcnt in front of the transposed V reads of the SAME
+    // iteration; M0 saved / restored inside the statement).  Wave w moves key rows 16 w .. 16 w + 15 of each of the four planes, two
+    // pieces of 8 rows x 128 B each = 8 pieces per tile.  Lane (row = lane>>3, pos = lane&7) fills LDS chunk `pos` of its row with
+    // source chunk pos ^ ((r16>>1)&7) for K and pos ^ (((r16>>1)&1)<<2) for V (r16 = tile row & 15): the images the fragment
+    // reads below expect (attention.hip).  Full tiles: one scalar base per tensor + a 32-bit lane offset.
+    auto dma_one = [&](const char* base, uint32_t voff, uint32_t dst) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    };
+    const int64_t k_rowb = p.k_ts * (int64_t)sizeof(bf16), v_rowb = p.v_ts * (int64_t)sizeof(bf16);
+    const int64_t k_plb = p.k_pl * (int64_t)sizeof(bf16), v_plb = p.v_pl * (int64_t)sizeof(bf16);
+    uint32_t kvo[2], vvo[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rr = 16 * w + 8 * i + (lane >> 3), r16 = rr & 15;
-            const int key = min(t * 64 + rr, p.Nk - 1);            // rows past Nk re-read the last key; their scores are masked
-            const int kc = ((lane & 7) ^ ((r16 >> 1) & 7)) * 8, vc = ((lane & 7) ^ (((r16 >> 1) & 1) << 2)) * 8;
-            const bf16* ks = Kb + (int64_t)key * p.k_ts + kc;
-            const bf16* vs = Vb + (int64_t)key * p.v_ts + vc;
-            char* dst = smem + (16 * w + 8 * i) * 128;
-            __builtin_amdgcn_global_load_lds((gptr_t)ks, (lptr_t)(dst + (0 + buf) * AS_TILE), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(ks + p.k_pl), (lptr_t)(dst + (2 + buf) * AS_TILE), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)vs, (lptr_t)(dst + (4 + buf) * AS_TILE), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(vs + p.v_pl), (lptr_t)(dst + (6 + buf) * AS_TILE), 16, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+        const int rr = 8 * i + (lane >> 3), r16 = (16 * w + rr) & 15;
+        kvo[i] = (uint32_t)(rr * k_rowb) + (uint32_t)(((lane & 7) ^ ((r16 >> 1) & 7)) << 4);
+        vvo[i] = (uint32_t)(rr * v_rowb) + (uint32_t)(((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4);
+    }
+    const char* k_tile0 = (const char*)(Kb + (int64_t)(16 * w) * p.k_ts);
+    const char* v_tile0 = (const char*)(Vb + (int64_t)(16 * w) * p.v_ts);
+    auto dma_piece = [&](int t, int j) {   // j = 0..7: tensor j >> 2 (K, V), plane (j >> 1) & 1 (lo, hi), row group j & 1
+        const int tens = j >> 2, pl = (j >> 1) & 1, i = j & 1;
+        const uint32_t dst = lds0 + (4 * tens + 2 * pl + (t & 1)) * AS_TILE + (16 * w + 8 * i) * 128;
+        if (t * 64 + 64 <= p.Nk) {
+            if (tens == 0) dma_one(k_tile0 + (int64_t)t * 64 * k_rowb + pl * k_plb, kvo[i], dst);
+            else dma_one(v_tile0 + (int64_t)t * 64 * v_rowb + pl * v_plb, vvo[i], dst);
+        } else {   // ragged last tile: rows past Nk re-read the last key (their scores are masked); per-lane 64-bit addresses
+            const int rr = 8 * i + (lane >> 3), r16 = (16 * w + rr) & 15;
+            const int key = min(t * 64 + 16 * w + rr, p.Nk - 1);
+            const char* src = tens == 0 ? (const char*)(Kb + (int64_t)key * p.k_ts) + pl * k_plb + (((lane & 7) ^ ((r16 >> 1) & 7)) << 4)
+                                        : (const char*)(Vb + (int64_t)key * p.v_ts) + pl * v_plb + (((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         }
     };
-    dma_tile(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_piece(0, j);
 
     // ---- Q fragments (B operand: column = the lane's query row, k = d), scaled in fp32 and re-split
     const int qrow = q0 + l31;
@@ -291,31 +311,47 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
-    __syncthreads();   // (compiler: vmcnt(0) in front) tile 0 landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tile 0 landed
+    __builtin_amdgcn_sched_barrier(0);
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) dma_tile(t + 1);
+        const bool more = t + 1 < nt;
         const char* Kl = smem + (0 + buf) * AS_TILE;
         const char* Kh = smem + (2 + buf) * AS_TILE;
         const char* Vl = smem + (4 + buf) * AS_TILE;
         const char* Vh = smem + (6 + buf) * AS_TILE;
 
-        // ---- S^T[key][q] = K Q^T: two 32-key halves x 4 k-steps x 3 terms
+        // ---- S^T[key][q] = K Q^T: two 32-key halves x 4 k-steps x 3 terms.  The fragments of step n + 1 are requested before the
+        // MFMAs of step n, and one of the 8 LDS-DMA pieces of tile t + 1 is issued behind every step (the other buffer was last
+        // read in iteration t - 1, behind its closing barrier).
         f32x16 sacc[2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+        bf16x8 kl[2], kh[2];
+        kl[0] = *(const bf16x8*)(Kl + koff[0]);
+        kh[0] = *(const bf16x8*)(Kh + koff[0]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kl = *(const bf16x8*)(Kl + kt * 4096 + koff[ks]);
-                const bf16x8 kh = *(const bf16x8*)(Kh + kt * 4096 + koff[ks]);
-                sacc[kt] = mma_bf16(kl, qh[ks], sacc[kt]);
-                sacc[kt] = mma_bf16(kh, ql[ks], sacc[kt]);
-                sacc[kt] = mma_bf16(kh, qh[ks], sacc[kt]);
+        for (int n = 0; n < 8; ++n) {   // n = 4 kt + ks
+            if (n + 1 < 8) {
+                const int o = ((n + 1) >> 2) * 4096 + koff[(n + 1) & 3];
+                kl[(n + 1) & 1] = *(const bf16x8*)(Kl + o);
+                kh[(n + 1) & 1] = *(const bf16x8*)(Kh + o);
             }
+            sacc[n >> 2] = mma_bf16(kl[n & 1], qh[n & 3], sacc[n >> 2]);
+            sacc[n >> 2] = mma_bf16(kh[n & 1], ql[n & 3], sacc[n >> 2]);
+            sacc[n >> 2] = mma_bf16(kh[n & 1], qh[n & 3], sacc[n >> 2]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) dma_piece(t + 1, n);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // first V fragments of PV(t): in flight behind the softmax
+        bf16x8 vl[2], vh[2];
+        vl[0] = read_vt(Vl, voff[0]);
+        vh[0] = read_vt(Vh, voff[0]);
         if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -326,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
                 }
         }
 
-        // ---- exact online softmax in fp32 (this lane: 32 of its query's 64 scores, lane ^ 32 the rest)
+        // ---- exact online softmax in fp32 (this lane: 32 of its query's 64 scores, lane ^ 32 the rest), deferred maximum
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -337,42 +373,49 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
             const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
             mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
         }
-        const float m_new = fmaxf(m_run, mx);            // finite: every tile holds at least one valid key
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 0 on the first tile (m_run = -inf), 1 where the maximum stays
-        m_run = m_new;
+        float alpha = 1.0f;
+        const bool need = mx > m_run + 8.0f;   // true on the first tile (m_run = -inf); P <= 2^8 otherwise: as good a bf16 pair as P <= 1
+        if (need) {
+            alpha = __builtin_amdgcn_exp2f(m_run - mx);
+            m_run = mx;
+        }
         float r4[4] = {0.f, 0.f, 0.f, 0.f};
         bf16x8 ph[4], pl[4];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(sacc[kt][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(sacc[kt][r] - m_run);
                 r4[r >> 2] += pv;
                 const bf16 hv = (bf16)pv;
                 ph[2 * kt + (r >> 3)][r & 7] = hv;
                 pl[2 * kt + (r >> 3)][r & 7] = (bf16)(pv - (float)hv);
             }
         l_run = l_run * alpha + ((r4[0] + r4[1]) + (r4[2] + r4[3]));
-        if (__any(alpha != 1.0f)) {
+        if (__builtin_expect(__any(need), 0)) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
         }
 
-        // ---- O^T[d][q] += V^T P^T: 4 key steps x 2 d-halves x 3 terms.  A operand (row = d, k = key in P's register order):
-        // elements 0..3 = keys 16 s4 + 4 lh + 0..3, elements 4..7 = keys 16 s4 + 8 + 4 lh + 0..3
+        // ---- O^T[d][q] += V^T P^T: 4 key steps x 2 d-halves x 3 terms, fragments one pair ahead.  A operand (row = d, k = key in
+        // P's register order): elements 0..3 = keys 16 s4 + 4 lh + 0..3, elements 4..7 = keys 16 s4 + 8 + 4 lh + 0..3
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 vl = read_vt(Vl, voff[dt] + s4 * 2048);
-                const bf16x8 vh = read_vt(Vh, voff[dt] + s4 * 2048);
-                oacc[dt] = mma_bf16(vh, pl[s4], oacc[dt]);
-                oacc[dt] = mma_bf16(vl, ph[s4], oacc[dt]);
-                oacc[dt] = mma_bf16(vh, ph[s4], oacc[dt]);
+        for (int n = 0; n < 8; ++n) {   // n = 2 s4 + dt
+            if (n + 1 < 8) {
+                const int o = voff[(n + 1) & 1] + ((n + 1) >> 1) * 2048;
+                vl[(n + 1) & 1] = read_vt(Vl, o);
+                vh[(n + 1) & 1] = read_vt(Vh, o);
             }
-        __syncthreads();   // next tile landed (vmcnt(0) in front of the barrier); everyone done with this buffer
+            oacc[n & 1] = mma_bf16(vh[n & 1], pl[n >> 1], oacc[n & 1]);
+            oacc[n & 1] = mma_bf16(vl[n & 1], ph[n >> 1], oacc[n & 1]);
+            oacc[n & 1] = mma_bf16(vh[n & 1], ph[n >> 1], oacc[n & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile t + 1 landed; everyone done with this buffer
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     if (qrow >= p.Nq) return;
@@ -404,7 +447,6 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
             }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Flash attention on planes, single head, d = 512, keys and values THE SAME tensor X (SR3's SelfAttention after the pack-time
@@ -538,22 +580,24 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        bf16x8 kl[2], kh[2];
-        {
-            const int o = kbase[0] + 256 * (2 * half);
-            kl[0] = *(const bf16x8*)(Il + o);
-            kh[0] = *(const bf16x8*)(Ih + o);
+        // (fragments TWO k-steps ahead: three MFMAs = 96 cycles do not cover an LDS round trip on one wave per SIMD)
+        bf16x8 kl[3], kh[3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int o = kbase[ks & 7] + 256 * (2 * half + (ks >> 3));
+            kl[ks] = *(const bf16x8*)(Il + o);
+            kh[ks] = *(const bf16x8*)(Ih + o);
         }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 1 < 16) {
-                const int o = kbase[(ks + 1) & 7] + 256 * (2 * half + ((ks + 1) >> 3));
-                kl[(ks + 1) & 1] = *(const bf16x8*)(Il + o);
-                kh[(ks + 1) & 1] = *(const bf16x8*)(Ih + o);
+            if (ks + 2 < 16) {
+                const int o = kbase[(ks + 2) & 7] + 256 * (2 * half + ((ks + 2) >> 3));
+                kl[(ks + 2) % 3] = *(const bf16x8*)(Il + o);
+                kh[(ks + 2) % 3] = *(const bf16x8*)(Ih + o);
             }
-            sacc = mma_bf16(kl[ks & 1], qh[ks], sacc);
-            sacc = mma_bf16(kh[ks & 1], ql[ks], sacc);
-            sacc = mma_bf16(kh[ks & 1], qh[ks], sacc);
+            sacc = mma_bf16(kl[ks % 3], qh[ks], sacc);
+            sacc = mma_bf16(kh[ks % 3], ql[ks], sacc);
+            sacc = mma_bf16(kh[ks % 3], qh[ks], sacc);
             __builtin_amdgcn_sched_barrier(0);
             if (more) dma_piece(t + 1, ks);
             __builtin_amdgcn_sched_barrier(0);
@@ -608,7 +652,7 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
         }
         // ---- O^T[d][q] += X^T P^T over this wave's 8 d-blocks: 2 key steps x 3 terms each, fragments one pair ahead
-        bf16x8 vl[2], vh[2];
+        bf16x8 vl[3], vh[3];
         auto vreq = [&](int n, int slot) {   // n = 2 dt + s
             const int dtg = 8 * half + (n >> 1), s2 = n & 1;
             const int off = vbase[dtg & 3] + (dtg >> 2) * 256 + (16 * s2) * 1024;
@@ -616,12 +660,13 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
             vh[slot] = read_vt(Ih, off);
         };
         vreq(0, 0);
+        vreq(1, 1);
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
-            if (n + 1 < 16) vreq(n + 1, (n + 1) & 1);
-            oacc[n >> 1] = mma_bf16(vh[n & 1], pl[n & 1], oacc[n >> 1]);
-            oacc[n >> 1] = mma_bf16(vl[n & 1], ph[n & 1], oacc[n >> 1]);
-            oacc[n >> 1] = mma_bf16(vh[n & 1], ph[n & 1], oacc[n >> 1]);
+            if (n + 2 < 16) vreq(n + 2, (n + 2) % 3);
+            oacc[n >> 1] = mma_bf16(vh[n % 3], pl[n & 1], oacc[n >> 1]);
+            oacc[n >> 1] = mma_bf16(vl[n % 3], ph[n & 1], oacc[n >> 1]);
+            oacc[n >> 1] = mma_bf16(vh[n % 3], ph[n & 1], oacc[n >> 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile t + 1 landed; everyone done with this stage and the exchange
