@@ -238,7 +238,12 @@ def kernel_table(summ):
 # group's time) run the ping-pong kernel attn_d64c; the short cross-attention launches (group attention_d64_cross) stay on
 # attn_d64b (row "attn_d64")
 PMC_ALIAS = {"attention_d64": ("attn_d64c", "attn_d64"), "attention_d64_cross": ("attn_d64",), "attention_d512": ("attn_d512",),
-             "gemm_256x256": ("gemm256",)}
+             "gemm_256x256": ("gemm256",),
+             # the split-operand pass (profiles/r04_c4_split_pmc_traffic.json): the RSVLD_SPLIT instantiations keep their kernels' names
+             "attention_split_d64": ("attn_split_d64",), "attention_split_d64_cross": ("attn_split_d64",),
+             "attention_split_d512": ("attn_split_d512",), "gemm_256x256_split": ("gemm256",), "conv_halo_128_split": ("conv_halo_128",),
+             "conv_halo_64_split": ("conv_halo_64",), "conv_igemm_split": ("conv_igemm_64x128",), "groupnorm_apply_split": ("gn_apply_split",),
+             "groupnorm_stats_split": ("gn_partial_f32",), "layernorm_split": ("layernorm_split",), "split_planes": ("split_planes",)}
 
 
 def _pmc_row(kern, name):
@@ -540,7 +545,8 @@ def bench_headline(args, dev, rank, world):
         torch.cuda.synchronize()
         ops.set_profiler(None)
         summ = prof.summary()
-        pmc = "r03_c4_pmc_traffic.json" if is_metric_cfg else "none (PMC passes exist for the metric's configuration only)"
+        pmc = ({"default": "r04_c4_pmc_traffic.json", "split": "r04_c4_split_pmc_traffic.json"}.get(PRECISION, "none (no PMC pass for this mode)")
+               if is_metric_cfg else "none (PMC passes exist for the metric's configuration only)")
         roof = roofline_of(summ, pmc)
         tf_img = (S1_TF_PER_IMAGE_STEP.get(side, 0) + S2_TF_PER_IMAGE_STEP.get(latent, 0)) * T
         line = {
