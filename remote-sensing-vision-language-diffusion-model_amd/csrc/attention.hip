@@ -1107,7 +1107,10 @@ extern "C" int rsvld_attention_tuned(const void* q, const void* k, const void* v
             return rsvld_check_launch();
         }
         const int64_t wg_c = (int64_t)((Nq + 511) / 512) * heads * B;
-        if ((a.dbg == nullptr || force == 'c') && force != 'b' && Nk > 64 && ((wg_c >= A6C_MIN_WG && Nk >= A6C_MIN_KEYS) || force == 'c')) {   // long query sequences: the ping-pong kernel
+        // attn_d64c forms 32-bit lane offsets of up to 64 key rows: a token stride of ~16 M elements or more would wrap
+        const bool c_strides_ok = 64 * k_tok_stride * 2 < ((int64_t)1 << 32) && 64 * v_tok_stride * 2 < ((int64_t)1 << 32);
+        if (force == 'c' && !c_strides_ok) return RSVLD_EUNSUPPORTED;
+        if (c_strides_ok && (a.dbg == nullptr || force == 'c') && force != 'b' && Nk > 64 && ((wg_c >= A6C_MIN_WG && Nk >= A6C_MIN_KEYS) || force == 'c')) {   // long query sequences: the ping-pong kernel
             dim3 grid((unsigned)((Nq + 511) / 512), (unsigned)heads, (unsigned)B);
             static const hipError_t attr16 = hipFuncSetAttribute((const void*)attn_d64c_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, A6C_SMEM);
             static const hipError_t attrbf = hipFuncSetAttribute((const void*)attn_d64c_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, A6C_SMEM);

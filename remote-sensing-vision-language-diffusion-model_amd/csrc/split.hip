@@ -10,6 +10,7 @@
 //   split / merge / weight-triple packing, plane re-packs for attention run as GEMMs (single-head d = 512), the row softmax
 //   that turns fp32 scores into P planes, and attn_split_d64_kernel -- flash attention on planes for the SDXL blocks.
 #include "rsvld_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -315,9 +316,16 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
     __builtin_amdgcn_s_barrier();   // tile 0 landed
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int t = 0; t < nt; ++t) {
+    // The tile loop exists twice: a steady-state copy for tiles whose successor exists and is FULL (no test around the 8 LDS-DMA
+    // pieces, no ragged mask, the next tile's row bases one scalar add away) and the general copy for the last tiles.
+    const char* k_nxt = k_tile0;
+    const char* v_nxt = v_tile0;
+    auto body = [&](int t, auto steady_c) __attribute__((always_inline)) {
+        constexpr bool ST = decltype(steady_c)::value;
+        k_nxt += 64 * k_rowb;   // row 16 w of tile t + 1
+        v_nxt += 64 * v_rowb;
         const int buf = t & 1;
-        const bool more = t + 1 < nt;
+        const bool more = ST ? true : t + 1 < nt;
         const char* Kl = smem + (0 + buf) * AS_TILE;
         const char* Kh = smem + (2 + buf) * AS_TILE;
         const char* Vl = smem + (4 + buf) * AS_TILE;
@@ -345,14 +353,18 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
             sacc[n >> 2] = mma_bf16(kh[n & 1], ql[n & 3], sacc[n >> 2]);
             sacc[n >> 2] = mma_bf16(kh[n & 1], qh[n & 3], sacc[n >> 2]);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) dma_piece(t + 1, n);
+            if constexpr (ST) {   // piece n: tensor n >> 2, plane (n >> 1) & 1, row group n & 1
+                const uint32_t dst = lds0 + (4 * (n >> 2) + 2 * ((n >> 1) & 1) + ((t + 1) & 1)) * AS_TILE + (16 * w + 8 * (n & 1)) * 128;
+                if ((n >> 2) == 0) dma_one(k_nxt + ((n >> 1) & 1) * k_plb, kvo[n & 1], dst);
+                else dma_one(v_nxt + ((n >> 1) & 1) * v_plb, vvo[n & 1], dst);
+            } else if (more) dma_piece(t + 1, n);
             __builtin_amdgcn_sched_barrier(0);
         }
         // first V fragments of PV(t): in flight behind the softmax
         bf16x8 vl[2], vh[2];
         vl[0] = read_vt(Vl, voff[0]);
         vh[0] = read_vt(Vh, voff[0]);
-        if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
+        if (!ST && (t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -416,7 +428,10 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile t + 1 landed; everyone done with this buffer
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    int t = 0;
+    for (; (t + 2) * 64 <= p.Nk; ++t) body(t, std::true_type{});
+    for (; t < nt; ++t) body(t, std::false_type{});
 
     if (qrow >= p.Nq) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -569,10 +584,16 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
     __builtin_amdgcn_s_barrier();   // tile 0 landed
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int t = 0; t < nt; ++t) {
+    // The tile loop exists twice: a steady-state copy for tiles whose successor exists and is FULL (no test around the 16 LDS-DMA
+    // pieces, no ragged mask, the next tile's row base one scalar add away) and the general copy for the last tiles -- one wave per
+    // SIMD: nobody covers the instruction-fetch bubble of a branch ("Branch-free steady-state loops").
+    const char* x_nxt = x_tile0;
+    auto body = [&](int t, auto steady_c) __attribute__((always_inline)) {
+        constexpr bool ST = decltype(steady_c)::value;
+        x_nxt += 32 * rowb;     // row 8w of tile t + 1
         const char* Il = smem + (t & 1) * A5S_STAGE;
         const char* Ih = Il + A5S_IMG;
-        const bool more = t + 1 < nt;
+        const bool more = ST ? true : t + 1 < nt;
 
         // ---- partial S^T over this wave's 256 channels; the 16 LDS-DMA pieces of tile t + 1 are issued between the k-steps (the
         // other stage was last read in iteration t - 1, behind its closing barrier).  Fragments of k-step ks + 1 are requested
@@ -599,7 +620,8 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
             sacc = mma_bf16(kh[ks % 3], ql[ks], sacc);
             sacc = mma_bf16(kh[ks % 3], qh[ks], sacc);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) dma_piece(t + 1, ks);
+            if constexpr (ST) dma_one(x_nxt + (ks & 1) * plb, xvo[ks >> 1], lds0 + ((t + 1) & 1) * A5S_STAGE + (ks & 1) * A5S_IMG + (w * 8 + (ks >> 1)) * 1024);
+            else if (more) dma_piece(t + 1, ks);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- exchange the partials with the other half's wave
@@ -611,7 +633,7 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
             const f32x4 o = *(const f32x4*)(xch_peer + g * 1024);
             sacc[4 * g] += o[0]; sacc[4 * g + 1] += o[1]; sacc[4 * g + 2] += o[2]; sacc[4 * g + 3] += o[3];
         }
-        if ((t + 1) * 32 > p.Nk) {   // ragged last tile (uniform branch)
+        if (!ST && (t + 1) * 32 > p.Nk) {   // ragged last tile (uniform branch)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -646,10 +668,21 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
         }
         l_run = l_run * alpha + rs;
         if (__builtin_expect(__any(need), 0)) {
+            // O lives in the accumulator file.  Written as plain C++ (oacc *= alpha) hipcc pulls all 128 values into VGPRs at once, and
+            // the pressure of that one cold block makes it park Q in AccVGPRs for the WHOLE loop (every Q fragment copied back in front of
+            // its MFMA: 226 v_accvgpr_read per tile).  One element at a time through a scratch VGPR instead (attention_d512_body.inc);
+            // the MFMA -> read hazard is covered by the 48 S-chain MFMAs since the last PV, the write -> MFMA hazard by the s_nop.
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) {
+                    float x = oacc[dt][r], tmp;
+                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1\n\ts_nop 1"
+                                 : "+a"(x), "=&v"(tmp)
+                                 : "v"(alpha));
+                    oacc[dt][r] = x;
+                }
         }
         // ---- O^T[d][q] += X^T P^T over this wave's 8 d-blocks: 2 key steps x 3 terms each, fragments one pair ahead
         bf16x8 vl[3], vh[3];
@@ -671,7 +704,10 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile t + 1 landed; everyone done with this stage and the exchange
         __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    int t = 0;
+    for (; (t + 2) * 32 <= p.Nk; ++t) body(t, std::true_type{});
+    for (; t < nt; ++t) body(t, std::false_type{});
 
     if (qrow >= p.Nq) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32);

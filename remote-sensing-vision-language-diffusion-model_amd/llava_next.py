@@ -332,6 +332,18 @@ class FastDecoder:
                 raise NotImplementedError("FastDecoder: biased MLP projections")
             self.wgu.append(self._fuse([mlp.gate_proj, mlp.up_proj], "weight"))
 
+    def stale(self):
+        """The fused q | k | v and gate | up tensors are VIEWED by the model's own modules; ``model.to()`` / ``.half()`` / a LoRA merge /
+        ``load_state_dict(assign=True)`` give the modules new storage and leave this decoder (weights, KV cache, captured graph) on
+        the old one.  Cheap check: first and last layer still alias the fused tensors, on the same device and dtype."""
+        for i in (0, len(self.layers) - 1):
+            q = self.layers[i].self_attn.q_proj.weight
+            g = self.layers[i].mlp.gate_proj.weight
+            if (q.data_ptr() != self.wqkv[i].data_ptr() or g.data_ptr() != self.wgu[i].data_ptr() or q.device != self.wqkv[i].device
+                    or q.dtype != self.wqkv[i].dtype):
+                return True
+        return False
+
     @staticmethod
     def _fuse(mods, name):
         with torch.no_grad():
@@ -598,6 +610,8 @@ def get_img_describe(image_tensor, image, model, tokenizer, prompt, conv_templat
     input_ids = tokenizer_image_token(text, tokenizer, image_token_index, return_tensors="pt").unsqueeze(0).to(device)
     mdev = next(model.parameters()).device
     fast = (mdev.type == "cuda" and num_beams == 1) if fast is None else fast
+    if fast and _has_logits_warpers(model):
+        fast = False     # FastDecoder samples with temperature only: a generation_config with top_k / top_p / penalties goes through generate()
 
     def run():
         if fast:   # (no_grad, not inference_mode: tensors made in inference mode cannot be updated in place by a later call
@@ -618,11 +632,29 @@ def get_img_describe(image_tensor, image, model, tokenizer, prompt, conv_templat
     return [tokenizer.decode(out.cpu().tolist(), skip_special_tokens=True).lstrip()]
 
 
+def _has_logits_warpers(model):
+    """True when the checkpoint's generation_config asks for logits processing FastDecoder does not implement (it applies the
+    temperature and samples): top_k / top_p / typical_p / penalties.  transformers' defaults (top_k 50 included) count as unset
+    only when they are the library defaults AND sampling would not use them -- top_k = 50 is a default that generate() DOES apply,
+    so any top_k counts."""
+    g = getattr(model, "generation_config", None)
+    if g is None:
+        return False
+    def differs(name, neutral):
+        v = getattr(g, name, None)
+        return v is not None and v != neutral
+    return (differs("top_p", 1.0) or differs("typical_p", 1.0) or differs("repetition_penalty", 1.0) or differs("no_repeat_ngram_size", 0)
+            or differs("min_p", None) or (getattr(g, "do_sample", False) and differs("top_k", 0) and differs("top_k", None) and getattr(g, "top_k", 50) != 50)
+            or differs("encoder_repetition_penalty", 1.0) or bool(getattr(g, "bad_words_ids", None)) or bool(getattr(g, "suppress_tokens", None)))
+
+
 def caption_tokens_fast(model, input_ids, images, image_sizes, max_new_tokens, do_sample, temperature, eos_ids=None):
     """Multimodal prompt -> generated token ids through the model's ``FastDecoder`` (built once per model and cache size)."""
     embeds = model.multimodal_embeds(input_ids, images, image_sizes)
     need = embeds.shape[1] + max_new_tokens
     dec = getattr(model, "_fast_decoder", None)
+    if dec is not None and dec.stale():     # the model was moved / cast / reloaded since the decoder fused its weights: rebuild
+        dec = None
     if dec is None or dec.max_len < need:
         dec = FastDecoder(model, -(-need // 256) * 256)
         model.__dict__["_fast_decoder"] = dec          # not a submodule: plain attribute

@@ -106,7 +106,8 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
             try:
                 from CKPT_PTH import SDXL_CLIP1_PATH as src
             except ImportError:
-                src = version
+                src = None
+            src = src or version        # a CKPT_PTH that sets SDXL_CLIP1_PATH = None means "use `version`" (reference modules.py:453-454)
             tokenizer = tokenizer or CLIPTokenizer.from_pretrained(src)
             transformer = transformer or CLIPTextModel.from_pretrained(src)
         self.tokenizer, self.transformer = tokenizer, transformer
@@ -129,7 +130,8 @@ class FrozenCLIPEmbedder(AbstractEmbModel):
         z = pick[self.layer]()
         return (z, res.pooler_output) if self.return_pooled else z
 
-    encode = forward
+    def encode(self, text):
+        return self(text)        # through nn.Module.__call__ (hooks), as the reference does
 
 
 class FrozenOpenCLIPEmbedder2(AbstractEmbModel):
@@ -200,7 +202,8 @@ class FrozenOpenCLIPEmbedder2(AbstractEmbModel):
         rows = torch.arange(tokens.shape[0], device=tokens.device)
         return z, self.model.ln_final(last)[rows, eot] @ self.model.text_projection
 
-    encode = forward
+    def encode(self, text):
+        return self(text)        # through nn.Module.__call__ (hooks), as the reference does
 
 
 class GeneralConditioner(nn.Module):
