@@ -390,7 +390,8 @@ int rsvld_layernorm_split(const float* x, void* out, const float* gamma, const f
 /* Flash attention on planes, D = 64 (sgm CrossAttention at sgm/modules/attention.py:357-359 under diffusion_dtype "split"):
  * q / k / v point at the LO plane of element (b, n, h, d) = base + b*batch_stride + n*tok_stride + h*64 + d, the HI plane sits
  * *_plane elements further; three bf16 MFMAs per product in both contractions, fp32 softmax.  out: planes (o_plane = distance of
- * its hi plane, out_f32 = 0) or fp32 (out_f32 = 1). */
+ * its hi plane, out_f32 = 0) or fp32 (out_f32 = 1).  out_f32 bit 2 (value 4, developer override like rsvld_attention_tuned): run the
+ * ping-pong form of the kernel (an experiment: bit-identical, 10-13 % slower). */
 int rsvld_attention_split_d64(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk,
                               int64_t q_batch_stride, int64_t q_tok_stride, int64_t q_plane,
                               int64_t k_batch_stride, int64_t k_tok_stride, int64_t k_plane,

@@ -464,6 +464,330 @@ __global__ __launch_bounds__(256, 2) void attn_split_d64_kernel(AttnSplitArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The ping-pong form of the split d = 64 attention -- an EXPERIMENT kept behind a developer override (rsvld_attention_split_d64, out_f32
+// bit 2), bit-identical to the 4-wave kernel and 10-13 % slower on MI355X; see the measurements at the end of this comment.
+//
+// In attn_split_d64_kernel a wave alternates  S chain (24 MFMAs) | softmax + hi|lo split of P (~230 vector instructions) | PV chain
+// (24 MFMAs), and the two waves of a SIMD belong to two unsynchronised workgroups: whenever both are in their vector phase the matrix
+// pipe idles (PMC: 0.55 busy).  Here ONE workgroup of 8 waves (two per SIMD: wave w and w + 4) runs the two groups of four in
+// ANTI-PHASE by construction (the scheme of attn_d64c): per 64-key tile a wave has a vector segment V(t) = softmax(t) and a matrix
+// segment M(t) = PV(t) + S(t+1) (48 MFMAs); ONE barrier per tile, between two barriers the early group runs M(k) then V(k+1), the late
+// group V(k) then M(k) -- on every SIMD one wave feeds the matrix pipe while the other computes exponentials, in both halves of the
+// period.  M(k) reads the V planes of tile k and the K planes of tile k + 1, so two tiles are live and the ring has three stages
+// (3 x 32 KiB): tile k + 2 is requested at the start of period k and waited for at its end.  256 query rows per K / V tile: half the
+// LDS-DMA traffic per row.  (First version: two barriers per tile, one segment per slot: 2 530 cycles per 48-MFMA segment -- barrier
+// release + the ramp of the fragment ring in every slot -- and 20 % SLOWER than the 4-wave kernel.)
+// Measured on 2 x 10 heads x 65 536 tokens (effective TFLOP/s; the 4-wave kernel: 391): two barriers per tile 319; + fragments two steps
+// ahead 341; + branch-free M copies 354; + fragments three steps ahead 344; one barrier per tile 349; accumulators interleaved pairwise
+// 342; the three possible pairings of waves into groups (w >> 2, w & 1, (w >> 1) & 1): 62.9 / 63.2 / 63.6 ms -- no difference.  Diagnostic
+// builds: matrix segments alone 2 530 cycles per 48 MFMAs (1 536 nominal), vector segments alone 1 130, both 3 170 per slot: the two
+// waves of a SIMD do not overlap their segments here whatever the grouping, and the unsynchronised 4-wave form does better by chance.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int ASP_SMEM = 12 * AS_TILE;      // 3 stages x (K_lo, K_hi, V_lo, V_hi)
+
+__global__ __launch_bounds__(512) void attn_split_d64pp_kernel(AttnSplitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef ASP_GRP
+#define ASP_GRP 0   // which waves form the two anti-phase groups: 0: w >> 2, 1: w & 1, 2: (w >> 1) & 1 (the two waves of a SIMD must differ)
+#endif
+    const int grp = ASP_GRP == 0 ? (w >> 2) : ASP_GRP == 1 ? (w & 1) : ((w >> 1) & 1);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = (blockIdx.x * 8 + w) * 32, h = blockIdx.y, b = blockIdx.z;
+    const bf16* Qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * 64;
+    const bf16* Kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * 64;
+    const bf16* Vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * 64;
+    const int nt = (p.Nk + 63) >> 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+
+    // ---- tile DMA: wave w moves key rows 8 w .. 8 w + 7 of each of the four planes (one 1-KiB piece per plane)
+    auto dma_one = [&](const char* base, uint32_t voff, uint32_t dst) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    };
+    const int64_t k_rowb = p.k_ts * (int64_t)sizeof(bf16), v_rowb = p.v_ts * (int64_t)sizeof(bf16);
+    const int64_t k_plb = p.k_pl * (int64_t)sizeof(bf16), v_plb = p.v_pl * (int64_t)sizeof(bf16);
+    const int drow = lane >> 3, r16 = (8 * w + drow) & 15;
+    const uint32_t kswz = (uint32_t)(((lane & 7) ^ ((r16 >> 1) & 7)) << 4), vswz = (uint32_t)(((lane & 7) ^ (((r16 >> 1) & 1) << 2)) << 4);
+    const uint32_t kvo = (uint32_t)(drow * k_rowb) + kswz, vvo = (uint32_t)(drow * v_rowb) + vswz;
+    const char* k_tile0 = (const char*)(Kb + (int64_t)(8 * w) * p.k_ts);
+    const char* v_tile0 = (const char*)(Vb + (int64_t)(8 * w) * p.v_ts);
+    auto dma_tile = [&](int t, int stage) {
+        const uint32_t dst = lds0 + (uint32_t)(stage * 4 * AS_TILE + 8 * w * 128);
+        if (t * 64 + 64 <= p.Nk) {
+            const char* kb = k_tile0 + (int64_t)t * 64 * k_rowb;
+            const char* vb = v_tile0 + (int64_t)t * 64 * v_rowb;
+            dma_one(kb, kvo, dst);
+            dma_one(kb + k_plb, kvo, dst + AS_TILE);
+            dma_one(vb, vvo, dst + 2 * AS_TILE);
+            dma_one(vb + v_plb, vvo, dst + 3 * AS_TILE);
+        } else {   // ragged last tile: rows past Nk re-read the last key (their scores are masked); per-lane 64-bit addresses
+            const int key = min(t * 64 + 8 * w + drow, p.Nk - 1);
+            const char* ks = (const char*)(Kb + (int64_t)key * p.k_ts) + kswz;
+            const char* vs = (const char*)(Vb + (int64_t)key * p.v_ts) + vswz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* src = j == 0 ? ks : j == 1 ? ks + k_plb : j == 2 ? vs : vs + v_plb;
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst + j * AS_TILE) : "memory");
+            }
+        }
+    };
+    dma_tile(0, 0);
+    if (nt > 1) dma_tile(1, 1);
+    if (nt > 2) dma_tile(2, 2);
+
+    // ---- Q fragments (B operand), scaled in fp32 and re-split
+    const int qrow = q0 + l31;
+    bf16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        if (qrow < p.Nq) {
+            const bf16* qp = Qb + (int64_t)qrow * p.q_ts + ks * 16 + lh * 8;
+            float l[8], hh[8];
+            unpack8<bf16>(*(const u32x4*)qp, l);
+            unpack8<bf16>(*(const u32x4*)(qp + p.q_pl), hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (hh[e] + l[e]) * p.scale_log2e;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qh[ks][e] = (bf16)f[e];
+            ql[ks][e] = (bf16)(f[e] - (float)qh[ks][e]);
+        }
+    }
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + lh) ^ ((l31 >> 1) & 7)) << 4);
+    int voff[2];
+    {
+        const int qq = (lane >> 2) & 3, pp = lane & 3, g1 = (lane >> 4) & 1;
+        const int row = 4 * lh + qq;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            voff[dt] = row * 128 + (((4 * dt + 2 * g1 + (pp >> 1)) ^ (((row >> 1) & 1) << 2)) << 4) + ((pp & 1) << 3);
+    }
+    auto read_vt = [&](const char* base, int off) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off + 1024));
+        typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x16 sacc[2];
+    bf16x8 ph[4], pl[4];
+    // S^T of tile 0 (prologue): two 32-key halves x 4 k-steps x 3 terms
+    auto s_chain0 = [&]() __attribute__((always_inline)) {
+        const char* Kl = smem;
+        const char* Kh = Kl + AS_TILE;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int o = (n >> 2) * 4096 + koff[n & 3];
+            const bf16x8 kl = *(const bf16x8*)(Kl + o), kh = *(const bf16x8*)(Kh + o);
+            sacc[n >> 2] = mma_bf16(kl, qh[n & 3], sacc[n >> 2]);
+            sacc[n >> 2] = mma_bf16(kh, ql[n & 3], sacc[n >> 2]);
+            sacc[n >> 2] = mma_bf16(kh, qh[n & 3], sacc[n >> 2]);
+        }
+    };
+    // ---- V(t): exact online softmax in fp32 with a deferred maximum, P split into hi | lo
+    auto v_seg = [&](int t) __attribute__((always_inline)) {
+        if ((t + 1) * 64 > p.Nk) {   // ragged last tile only (uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (kv >= p.Nk) sacc[kt][r] = -INFINITY;
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][r]);
+        {
+            const uint32_t mb = __builtin_bit_cast(uint32_t, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+        }
+        float alpha = 1.0f;
+        const bool need = mx > m_run + 8.0f;   // true on the first tile (m_run = -inf)
+        if (need) {
+            alpha = __builtin_amdgcn_exp2f(m_run - mx);
+            m_run = mx;
+        }
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[kt][r] - m_run);
+                r4[r >> 2] += pv;
+                const bf16 hv = (bf16)pv;
+                ph[2 * kt + (r >> 3)][r & 7] = hv;
+                pl[2 * kt + (r >> 3)][r & 7] = (bf16)(pv - (float)hv);
+            }
+        l_run = l_run * alpha + ((r4[0] + r4[1]) + (r4[2] + r4[3]));
+        if (__builtin_expect(__any(need), 0)) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
+    };
+    // ---- M(t): O^T += V^T P^T from the V planes of tile t (steps 0..7: n = 2 s4 + dt), then S^T of tile t + 1 from its K planes (steps
+    // 8..15: 8 + 4 kt + ks) as ONE sequence of 16 steps x 3 MFMAs, the fragment pair of step n + 3 requested before the MFMAs of step n --
+    // across the PV / S border too (fa = lo plane, fb = hi plane of the step's operand).  Two branch-free copies (MORE: tile t + 1 exists):
+    // a wave in its matrix segment has the pipe to feed, and every uniform branch is an instruction-fetch bubble of ~40 cycles.
+    // ``dma_u`` >= 0: this wave's four LDS-DMA pieces of tile dma_u are issued behind the first MFMAs.
+    auto m_seg = [&](int st_t, int dma_u, auto more_c) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;
+        constexpr int NSTEP = MORE ? 16 : 8;
+        // Steps are processed in PAIRS whose accumulators differ (PV: d-halves dt = 0, 1 of one key step; S: key halves kt = 0, 1 of one
+        // k-step) with their three terms interleaved, so that no MFMA reads the accumulator the previous one writes: a dependent MFMA
+        // waits at the head of the SIMD's issue port and blocks the vector wave behind it (what attn_d64c's step-major chains avoid).
+        constexpr int NPAIR = NSTEP / 2;
+        const char* Vl = smem + (st_t * 4 + 2) * AS_TILE;
+        const char* Vh = Vl + AS_TILE;
+        const char* Kl = smem + (st_t == 2 ? 0 : st_t + 1) * 4 * AS_TILE;
+        const char* Kh = Kl + AS_TILE;
+        bf16x8 fa[2][2], fb[2][2];     // [ring slot][member of the pair]
+        auto req = [&](int pr, int slot) __attribute__((always_inline)) {
+            if (pr < 4) {              // PV pair pr: key step s4 = pr, dt = 0, 1
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    fa[slot][j] = read_vt(Vl, voff[j] + pr * 2048);
+                    fb[slot][j] = read_vt(Vh, voff[j] + pr * 2048);
+                }
+            } else {                   // S pair: k-step ks = pr - 4, key halves kt = 0, 1
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    fa[slot][j] = *(const bf16x8*)(Kl + j * 4096 + koff[pr - 4]);
+                    fb[slot][j] = *(const bf16x8*)(Kh + j * 4096 + koff[pr - 4]);
+                }
+            }
+        };
+        req(0, 0);
+        if (MORE) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            if (pr + 1 < NPAIR) req(pr + 1, (pr + 1) & 1);
+            const int sl = pr & 1;
+            if (pr < 4) {
+                oacc[0] = mma_bf16(fb[sl][0], pl[pr], oacc[0]);
+                oacc[1] = mma_bf16(fb[sl][1], pl[pr], oacc[1]);
+                oacc[0] = mma_bf16(fa[sl][0], ph[pr], oacc[0]);
+                oacc[1] = mma_bf16(fa[sl][1], ph[pr], oacc[1]);
+                oacc[0] = mma_bf16(fb[sl][0], ph[pr], oacc[0]);
+                oacc[1] = mma_bf16(fb[sl][1], ph[pr], oacc[1]);
+            } else {
+                const int ks = pr - 4;
+                sacc[0] = mma_bf16(fa[sl][0], qh[ks], sacc[0]);
+                sacc[1] = mma_bf16(fa[sl][1], qh[ks], sacc[1]);
+                sacc[0] = mma_bf16(fb[sl][0], ql[ks], sacc[0]);
+                sacc[1] = mma_bf16(fb[sl][1], ql[ks], sacc[1]);
+                sacc[0] = mma_bf16(fb[sl][0], qh[ks], sacc[0]);
+                sacc[1] = mma_bf16(fb[sl][1], qh[ks], sacc[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (pr == 0) {
+                if (dma_u >= 0) dma_tile(dma_u, dma_u % 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tiles 0 .. 2 landed
+    __builtin_amdgcn_sched_barrier(0);
+    s_chain0();
+
+    // Time is cut into slots: group g runs V(t) in slot 2t + g and M(t) in slot 2t + g + 1, so in every slot one wave of a SIMD is in
+    // a matrix segment and the other in a vector segment.  ONE barrier per tile, at the end of the EVEN slots: between two barriers
+    // (slots 2k + 1, 2k + 2) the early group runs M(k) then V(k+1), the late group V(k) then M(k); nothing inside such a period depends
+    // on the other group.  Tile k + 2 is requested in slot 2k + 1 (k >= 1; its stage held tile k - 1, last read in slot 2k, before the
+    // barrier) and waited for at the period's end.  (One segment type per loop trip keeps ONE copy of V and two of M in the code:
+    // an if / else with both orders written out needed 256 registers + 112 spilled dwords.)
+    const int nslots = 2 * nt + 1;
+    int st_t = 0;                    // stage of this group's current tile (t % 3), advanced behind its M segment
+    for (int s = 0; s < nslots; ++s) {
+        const int u_dma = (s + 3) >> 1;
+        const bool do_dma = (s & 1) && s >= 3 && u_dma < nt;
+        bool dma_done = false;
+        const int rel = s - grp;
+        if (rel >= 0 && rel < 2 * nt) {
+            const int t = rel >> 1;
+            if ((rel & 1) == 0) {
+                if (do_dma) { dma_tile(u_dma, u_dma % 3); dma_done = true; }   // (the vector wave: at once)
+                v_seg(t);
+            } else {
+                if (t + 1 < nt) m_seg(st_t, do_dma ? u_dma : -1, std::true_type{});
+                else m_seg(st_t, do_dma ? u_dma : -1, std::false_type{});
+                dma_done = true;
+                st_t = st_t == 2 ? 0 : st_t + 1;
+            }
+        }
+        if (do_dma && !dma_done) dma_tile(u_dma, u_dma % 3);   // (a group idle in this slot still moves its rows)
+        if (!(s & 1)) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    if (qrow >= p.Nq) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (p.out_f32) {
+        float* Ob = (float*)p.out + (int64_t)b * p.o_bs + (int64_t)h * 64 + (int64_t)qrow * p.o_ts;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(Ob + dt * 32 + 8 * g + 4 * lh) = (f32x4){oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv,
+                                                                  oacc[dt][4 * g + 3] * inv};
+    } else {
+        bf16* Ob = (bf16*)p.out + (int64_t)b * p.o_bs + (int64_t)h * 64 + (int64_t)qrow * p.o_ts;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = oacc[dt][4 * g + e] * inv;
+                    hv[e] = (bf16)o;
+                    lv[e] = (bf16)(o - (float)hv[e]);
+                }
+                *(bf16x4*)(Ob + dt * 32 + 8 * g + 4 * lh) = lv;
+                *(bf16x4*)(Ob + p.o_pl + dt * 32 + 8 * g + 4 * lh) = hv;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Flash attention on planes, single head, d = 512, keys and values THE SAME tensor X (SR3's SelfAttention after the pack-time
 // re-association of sr3_modules/unet.py:114-143: keys and values are the normalised input itself, csrc/attention.hip "SH").
 //
@@ -808,9 +1132,17 @@ extern "C" int rsvld_attention_split_d64(const void* q, const void* k, const voi
     a.q_bs = q_batch_stride; a.q_ts = q_tok_stride; a.q_pl = q_plane; a.k_bs = k_batch_stride; a.k_ts = k_tok_stride; a.k_pl = k_plane;
     a.v_bs = v_batch_stride; a.v_ts = v_tok_stride; a.v_pl = v_plane; a.o_bs = o_batch_stride; a.o_ts = o_tok_stride; a.o_pl = o_plane;
     a.scale_log2e = scale * 1.44269504088896340736f;
-    a.out_f32 = out_f32 ? 1 : 0;
+    a.out_f32 = (out_f32 & 1) ? 1 : 0;
     static const hipError_t attr = hipFuncSetAttribute((const void*)attn_split_d64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AS_SMEM);
-    if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    static const hipError_t attr_pp = hipFuncSetAttribute((const void*)attn_split_d64pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ASP_SMEM);
+    if (attr != hipSuccess || attr_pp != hipSuccess) return RSVLD_ELAUNCH;
+    // out_f32 bit 2 (developer override, tests / A-B runs): the ping-pong form attn_split_d64pp_kernel.  NOT chosen by the library: on
+    // MI355X it runs 342-354 effective TFLOP/s where this 4-wave kernel runs 391 (2 x 10 heads x 65 536 tokens).
+    if ((out_f32 & 4) && Nk > 64 && 64 * k_tok_stride * 2 < ((int64_t)1 << 32) && 64 * v_tok_stride * 2 < ((int64_t)1 << 32)) {
+        hipLaunchKernelGGL(attn_split_d64pp_kernel, dim3((unsigned)((Nq + 255) / 256), (unsigned)heads, (unsigned)B), dim3(512), ASP_SMEM,
+                           (hipStream_t)stream, a);
+        return rsvld_check_launch();
+    }
     dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
     hipLaunchKernelGGL(attn_split_d64_kernel, grid, dim3(256), AS_SMEM, (hipStream_t)stream, a);
     return rsvld_check_launch();

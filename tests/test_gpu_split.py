@@ -317,3 +317,28 @@ def test_attention_split_d512_fused(cuda, B, Nq, Nk):
         ops.SPLIT_D512_FUSED_MIN = old
     _cmp(got.f32(), want, REL, f"attention split d512 fused B{B} {Nq}x{Nk}")
     _cmp(got.f32(), ref.f32().cpu(), REL, "  fused vs GEMM form")
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 20, 4096, 4096), (1, 16, 16384 + 77, 16384 + 77), (1, 40, 2048, 300)])
+def test_attention_split_d64_pingpong_vs_four_wave(cuda, B, heads, Nq, Nk):
+    """the ping-pong form (8 waves, anti-phase groups, three-stage ring; an experiment behind ``out_f32`` bit 2, see csrc/split.hip)
+    against the 4-wave kernel -- bit for bit -- and fp64 on the host for sampled rows; ragged query and key counts"""
+    from rsvld_amd import ops, _lib as L
+    g = torch.Generator(device="cuda").manual_seed(Nq + heads)
+    HD = heads * 64
+    qkv = torch.randn(B, max(Nq, Nk), 3 * HD, device=cuda, generator=g) * 1.3
+    pl = ops.to_planes(qkv)
+    q, k, v = pl[:, :Nq, :HD], pl[:, :Nk, HD:2 * HD], pl[:, :Nk, 2 * HD:]
+    with ops.f32_split(True):
+        ref = ops.attention(q, k, v, heads=heads, scale=0.125)          # the library's choice: the 4-wave kernel
+    got_t = torch.empty_like(ref.t)
+    lib = L.load()
+    L.check(lib.rsvld_attention_split_d64(ops._ptr(q.t), ops._ptr(k.t), ops._ptr(v.t), ops._ptr(got_t), B, heads, Nq, Nk,
+                                          q.t.stride(0), q.t.stride(1), q.t.stride(2), k.t.stride(0), k.t.stride(1), k.t.stride(2),
+                                          v.t.stride(0), v.t.stride(1), v.t.stride(2), got_t.stride(0), got_t.stride(1), got_t.stride(2), 0.125, 4,
+                                          ops._stream()), "ping-pong kernel (developer override)")
+    got = ops.Planes(got_t)
+    assert torch.equal(got_t, ref.t), "the ping-pong form must agree with the 4-wave kernel bit for bit"
+    rows = torch.randint(0, Nq, (64,), generator=torch.Generator().manual_seed(1))
+    want = _attn_ref(qkv[:1, rows, :HD].cpu(), qkv[:1, :Nk, HD:2 * HD].cpu(), qkv[:1, :Nk, 2 * HD:].cpu(), heads, 0.125)
+    _cmp(got.f32()[:1, rows.to(cuda)], want, REL, "  sampled rows vs fp64")
