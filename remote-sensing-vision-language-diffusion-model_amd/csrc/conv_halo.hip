@@ -62,8 +62,9 @@ __device__ __forceinline__ int patch_off(int py, int px, int c) { return (py * P
 
 // logical channel ch0 (start of a 32- or 64-channel chunk) -> source tensor (0: x, 1: x2), channel inside a pixel's row, elements per
 // pixel.  Split: segment 0 = lo planes, segments 1, 2 = hi planes; a pixel's row holds lo | hi.
+template <bool SPLIT>
 __device__ __forceinline__ void halo_src_of(const HaloArgs& p, int ch0, int& which, int& Cs, int& coff) {
-    if (!p.split) {
+    if (!SPLIT) {
         if (ch0 < p.Cin) { which = 0; Cs = p.Cin; coff = ch0; } else { which = 1; Cs = p.Cin2; coff = ch0 - p.Cin; }
         return;
     }
@@ -77,7 +78,7 @@ __device__ __forceinline__ void halo_src_of(const HaloArgs& p, int ch0, int& whi
 // 16-byte NHWC stores, plus the per-channel (sum, sumsq) partials of every 8x32-pixel sub-tile for the next GroupNorm.
 // NW waves own 64*NW pixels (8 rows of 32 per 4 waves); passes of EPI_ROWS pixels; the staging tile aliases the (dead)
 // operand buffers.
-template <typename T, int BN, int TM, int TN, int NW = 4>
+template <typename T, int BN, int TM, int TN, int NW = 4, bool SPLIT = false>
 __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32x16 (&acc)[TN][TM], int tid, int wm, int wn,
                                               int l31, int lh, int x0, int y0, int n0, int img, int tx, int ty) {
     constexpr int NT = 64 * NW, PIX = 64 * NW;
@@ -102,7 +103,7 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
         // The residual pieces of this pass are requested BEFORE the staging writes and their barrier, so that the HBM round trip
         // runs under them (one row at a time every store waited for its own residual load; same change as in gemm.hip).
         u32x4 rres[RPT];
-        if (p.residual != nullptr && n < p.Cout && !p.split) {
+        if (p.residual != nullptr && n < p.Cout && !SPLIT) {
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const int prow = pass * EPI_ROWS + rr + j * RPP;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
                 for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
                 if (p.residual != nullptr) {
                     float rf[8];
-                    if (p.split) {   // fp32 residual
+                    if (SPLIT) {   // fp32 residual
                         const float* r = (const float*)p.residual + m * p.Cout_out + n;
                         const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
 #pragma unroll
@@ -167,7 +168,7 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { st_s[e] += v[e]; st_q[e] += v[e] * v[e]; }
                 }
-                if (p.split && !p.out_f32) {   // planes: lo | hi per pixel row
+                if (SPLIT && !p.out_f32) {   // planes: lo | hi per pixel row
                     float lo[8];
                     typename Mfma<T>::v8 hv;
 #pragma unroll
@@ -210,7 +211,7 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
 
 // TPS = taps of weights staged per pipeline step (per barrier): 1 for BN = 128, 2 for BN = 64, so that every
 // step carries a 16 KiB weight slice and 32 MFMAs per wave
-template <typename T, int BN, int WAVES_M, int TPS>
+template <typename T, int BN, int WAVES_M, int TPS, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int SPC = (9 + TPS - 1) / TPS;       // steps per 64-channel chunk
@@ -252,15 +253,15 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
         // with ush = 1 the conv runs on the nearest-x2 up-sampled map: output-grid pixel (y, x) reads source (y>>1, x>>1)
         poff[i] = (pp < PROWS && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) ? (y >> p.ush) * p.Ws + (x >> p.ush) : -1;
     }
-    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * (p.split ? 2 * p.Cin : p.Cin);
-    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * (p.split ? 2 * p.Cin2 : p.Cin2) : nullptr;
+    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * (SPLIT ? 2 * p.Cin : p.Cin);
+    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * (SPLIT ? 2 * p.Cin2 : p.Cin2) : nullptr;
     const T* __restrict__ Wp = (const T*)p.w;
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
     u32x4 rp[PLOADS];
     auto load_patch = [&](int kc) {
         int which, Cs, coff;
-        halo_src_of(p, kc * 64, which, Cs, coff);
+        halo_src_of<SPLIT>(p, kc * 64, which, Cs, coff);
         const T* src = which ? X2 : X1;
         coff += c * 8;
 #pragma unroll
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
         }
     }
 
-    halo_epilogue<T, BN, TM, TN>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
+    halo_epilogue<T, BN, TM, TN, 4, SPLIT>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -428,7 +429,7 @@ template <int N> __device__ __forceinline__ void halo_wait_barrier() {
 // the halo overhead of the patch drops (612 instead of 680 patch pixels per 512 outputs).  Ablation builds
 // (tools/ablate_halo.sh) put the issue cost of the weight LDS-DMAs at 25 % of the 4-wave kernel's time and the patch
 // pipeline at 22-36 %, the fragment reads at ~1 %: per-wave DMA / staging instructions are what to cut.
-template <typename T, int BN, int NORM, int NW>
+template <typename T, int BN, int NORM, int NW, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     constexpr int NT = 64 * NW;
     constexpr int WAVES_N = 2, WAVES_M = NW / 2;
@@ -483,15 +484,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
         // dead target: the duplicate half of (scale, shift) buffer 0, never read
         pdst[i] = pp < PR ? p32_off(py, px, c4) : (int)(abuf - patch) + 512 + (tid & 31) * 16;
     }
-    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * (p.split ? 2 * p.Cin : p.Cin);
-    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * (p.split ? 2 * p.Cin2 : p.Cin2) : nullptr;
+    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * (SPLIT ? 2 * p.Cin : p.Cin);
+    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * (SPLIT ? 2 * p.Cin2 : p.Cin2) : nullptr;
     const T* __restrict__ Wp = (const T*)p.w;
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
     u32x4 rp[PL];
     auto issue_patch = [&](int k32, u32x4 (&r)[PL]) {
         int which, Cs, coff;
-        halo_src_of(p, k32 * 32, which, Cs, coff);
+        halo_src_of<SPLIT>(p, k32 * 32, which, Cs, coff);
         const T* src = which ? X2 : X1;
         coff += c4 * 8;
 #pragma unroll
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     for (int b = 0; b + 1 < nb; ++b) body(b, std::true_type{});
     body(nb - 1, std::false_type{});
 
-    halo_epilogue<T, BN, TM, TN, NW>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
+    halo_epilogue<T, BN, TM, TN, NW, SPLIT>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
 }
 
 template <typename T, int BN, int NW>
@@ -702,6 +703,9 @@ int launch_halo32(HaloArgs a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), smem, s, a);
         return rsvld_check_launch();
     };
+    if constexpr (__is_same(T, bf16)) {   // RSVLD_SPLIT: planes in, no fused norm (checked by the entry point)
+        if (a.split) return go(conv_halo32_kernel<T, BN, 0, NW, true>);
+    }
     if (norm == 0) return go(conv_halo32_kernel<T, BN, 0, NW>);
     if (norm == 1) return go(conv_halo32_kernel<T, BN, 1, NW>);
     return go(conv_halo32_kernel<T, BN, 2, NW>);
@@ -712,13 +716,18 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
     constexpr int stage = PATCH_BYTES + 2 * TPS * BN * 128;
     constexpr int epi = (256 / (BN > 64 ? 2 : 1)) * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
-    auto kern = conv_halo_kernel<T, BN, WAVES_M, TPS>;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (attr != hipSuccess) return RSVLD_ELAUNCH;
     const int64_t nwg = (int64_t)a.tiles_x * a.tiles_y * a.B * ((a.Cout + BN - 1) / BN);
     if (nwg >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
-    return rsvld_check_launch();
+    auto go = [&](auto kern) -> int {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (attr != hipSuccess) return RSVLD_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
+        return rsvld_check_launch();
+    };
+    if constexpr (__is_same(T, bf16)) {
+        if (a.split) return go(conv_halo_kernel<T, BN, WAVES_M, TPS, true>);
+    }
+    return go(conv_halo_kernel<T, BN, WAVES_M, TPS>);
 }
 
 template <typename T>

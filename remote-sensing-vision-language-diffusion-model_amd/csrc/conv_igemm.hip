@@ -79,7 +79,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // KS = intra-workgroup split of K: KS groups of 4 waves each own every KS-th K-step of the SAME output tile (own
 // LDS ring, shared barriers) and their accumulators are summed through LDS before the epilogue.  For small-M layers
 // whose grid is one workgroup per CU this doubles the waves per SIMD without partial sums in HBM.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES, int KS>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES, int KS, bool SPLIT = false>
 __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
     static_assert(GLDS ? (STAGES >= 2 && STAGES <= 4) : STAGES == 2, "register staging is double-buffered");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per K group");
@@ -159,16 +159,22 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
     u32x4 ra[A_LOADS], rb[B_LOADS];
 
     // logical 8-channel chunk -> (source tensor, chunk inside a pixel's row, elements per pixel).  Split: segment 0 reads the lo
-    // planes, segments 1 and 2 the hi planes; a pixel's row holds lo | hi.
-    auto src_of = [&](int ch, const T*& src, int& cc, int& Cs) {
-        if (!p.split) {
-            if (ch < p.C1_8) { src = X1; cc = ch; Cs = p.Cin; } else { src = X2; cc = ch - p.C1_8; Cs = p.Cin2; }
-            return;
-        }
+    // planes, segments 1 and 2 the hi planes; a pixel's row holds lo | hi.  Written as selects on values (the chunk index is per
+    // LANE): with assignments under nested branches hipcc built a two-entry pointer table on the stack and indexed it with a scratch
+    // load inside the K loop -- whose vmcnt wait drained the LDS-DMA ring (conv_igemm_64x128: 586 -> 437 TFLOP/s until noticed).
+    auto src_of = [&](int ch, const T*& src, int& cc, int& Cs) __attribute__((always_inline)) {
         int hi = 0;
-        if (ch >= p.Cseg8) { ch -= p.Cseg8; hi = 1; }
-        if (ch >= p.Cseg8) ch -= p.Cseg8;
-        if (ch < p.C1_8) { src = X1; cc = ch + hi * p.C1_8; Cs = 2 * p.Cin; } else { src = X2; cc = ch - p.C1_8 + hi * p.C2_8; Cs = 2 * p.Cin2; }
+        if (SPLIT) {                                  // (compile-time)
+            const bool s1 = ch >= p.Cseg8;
+            ch -= s1 ? p.Cseg8 : 0;
+            ch -= ch >= p.Cseg8 ? p.Cseg8 : 0;
+            hi = s1 ? 1 : 0;
+        }
+        const bool first = ch < p.C1_8;
+        src = first ? X1 : X2;
+        const int c1 = first ? p.C1_8 : p.C2_8;         // 8-channel chunks of one plane of the chosen source
+        cc = (first ? ch : ch - p.C1_8) + hi * c1;
+        Cs = (SPLIT ? 16 : 8) * c1;
     };
 
     auto load_tile = [&](int kt) {
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
     // the residual pieces this thread will add on the way out are requested before the staging pass (their HBM round trip
     // runs under it; same change as in gemm.hip / conv_halo.hip)
     u32x4 rres[RPT];
-    if (p.residual != nullptr && n < p.Cout && p.act != RSVLD_ACT_GEGLU && !p.split) {
+    if (p.residual != nullptr && n < p.Cout && p.act != RSVLD_ACT_GEGLU && !SPLIT) {
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const int row = rr + j * RPP;
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];
         }
-        if (p.split) {   // fp32 residual; fp32 or planes (lo | hi per row) out
+        if (SPLIT) {   // fp32 residual; fp32 or planes (lo | hi per row) out
             if (p.act == RSVLD_ACT_GEGLU) {
                 float o[4];
 #pragma unroll
@@ -451,13 +457,20 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int stage = KS * STAGES * (BM + BN) * BK_BYTES;
     constexpr int epi = BM * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
-    auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS>;
-    // one-time, thread-safe (C++11 magic static), per instantiation
-    static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (attr != hipSuccess) return RSVLD_ELAUNCH;
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, a);
-    return rsvld_check_launch();
+    auto go = [&](auto kern) -> int {
+        // one-time, thread-safe (C++11 magic static), per instantiation
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (attr != hipSuccess) return RSVLD_ELAUNCH;
+        hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, a);
+        return rsvld_check_launch();
+    };
+    if constexpr (__is_same(T, bf16) && GLDS) {   // RSVLD_SPLIT: its own instantiation (bf16, LDS-DMA staging), so that the 16-bit kernels stay as they were
+        if (a.split) return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS, true>);
+    } else {
+        if (a.split) return RSVLD_EUNSUPPORTED;
+    }
+    return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS>);
 }
 
 // Tile choice.  Cout <= 32: 256x32.  Cout <= 64: 128x64 (48 KiB LDS -> 3 workgroups per CU: these layers
