@@ -18,3 +18,15 @@ def test_compiler_never_touches_m0_beside_the_asm_lds_dma(unit):
     bad, dma = audit_m0.audit(unit)
     assert dma >= 16, dma            # the pieces are really there
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("unit", ["conv_igemm.hip", "conv_halo.hip", "gemm.hip", "split.hip"])
+def test_lds_dma_kernels_use_no_scratch(unit):
+    """A spill or a compiler-built stack table inside a kernel that streams its operands by LDS-DMA is reloaded with scratch_load,
+    which shares vmcnt with the DMA ring: the wait in front of the reload drains the prefetch (round 4: conv_igemm 586 -> 437 TFLOP/s
+    from a runtime flag in its source selection).  No MFMA kernel of these units may contain a scratch instruction."""
+    import audit_scratch
+    res = audit_scratch.audit(unit)
+    assert len(res) >= 3, res
+    bad = {k: v for k, v in res.items() if v > 0}
+    assert not bad, bad
