@@ -7,7 +7,7 @@ SRC=$ROOT/remote-sensing-vision-language-diffusion-model_amd/csrc
 name=$1; file=$2; shift 2
 stem=$(basename "$file" .hip)
 mkdir -p "$ROOT/tools/ablate"
-extra=""; [ "$stem" = attention ] && extra=-fno-slp-vectorize
+extra=""; { [ "$stem" = attention ] || [ "$stem" = split ]; } && extra=-fno-slp-vectorize
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc $extra "$@" -I"$SRC" -I"$ROOT/include" -c "$SRC/$stem.hip" -o "/tmp/${stem}_$name.o"
 objs=""
 for o in "$SRC"/build/*.o; do [ "$(basename "$o" .o)" = "$stem" ] || objs="$objs $o"; done
