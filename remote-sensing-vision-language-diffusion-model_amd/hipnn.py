@@ -72,13 +72,13 @@ class HipNet(nn.Module):
         key = (tuple(id(m) for m in mods), tag)
         p = self._pk.get(key)
         if p is None:
-            w = torch.cat([m.weight.detach().float() for m in mods], 0)
+            w = torch.cat([m.weight.detach().float() for m in mods], 0)      # (stays on the masters' device: pack_conv re-lays it there)
             if all(m.bias is None for m in mods):
                 b = None
             else:
-                b = torch.cat([torch.zeros(m.weight.shape[0]) if m.bias is None else m.bias.detach().float().cpu()
+                b = torch.cat([torch.zeros(m.weight.shape[0], device=w.device) if m.bias is None else m.bias.detach().float()
                                for m in mods], 0)
-            p = self._pk[key] = ops.pack_conv(w.cpu(), b, self.compute_dtype, self._dev(mods[0].weight), **kw)
+            p = self._pk[key] = ops.pack_conv(w, b, self.compute_dtype, self._dev(mods[0].weight), **kw)
         return p
 
     # ---- stacked emb projections: every ResBlock's emb_layers Linear in ONE launch

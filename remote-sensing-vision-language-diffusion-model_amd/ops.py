@@ -272,14 +272,16 @@ def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
     and gate j (rows j and j + Cout/2 of the reference weight, sgm/modules/attention.py:84-96)
     become adjacent output channels 2j, 2j+1.
     """
-    w = weight.detach().to("cpu", torch.float32)
+    # (the re-layout runs where the master weights live: on the device for a loaded network -- no 15 GB round trip over PCIe and no
+    #  host-side permute of 3.9 B values when a precision is switched -- on the host for weights that are still there)
+    w = weight.detach().to(torch.float32)
     if w.dim() == 2:
         w = w[:, :, None, None]
     cout, cin, kh, kw = w.shape
-    b = None if bias is None else bias.detach().to("cpu", torch.float32)
+    b = None if bias is None else bias.detach().to(device=w.device, dtype=torch.float32)
     if geglu:
         half = cout // 2
-        idx = torch.stack([torch.arange(half), torch.arange(half) + half], 1).reshape(-1)
+        idx = torch.stack([torch.arange(half), torch.arange(half) + half], 1).reshape(-1).to(w.device)
         w = w[idx]
         b = None if b is None else b[idx]
     parts = [cin] if cin_split is None else list(cin_split)
