@@ -405,7 +405,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         if stats and not out_f32:
             ntiles = ((Ho + 7) // 8) * ((Wo + 31) // 32)
             part_out = torch.empty((B, ntiles, pc.cout_p, 2), device=x.device, dtype=torch.float32)
-        _launch(name, flops, nbytes, lambda: L.check(lib.rsvld_conv3x3_halo_nhwc(C.byref(d), _ptr(ab), int(silu), _ptr(part_out),
+        _launch(name + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes, lambda: L.check(lib.rsvld_conv3x3_halo_nhwc(C.byref(d), _ptr(ab), int(silu), _ptr(part_out),
                                                                                  _stream()), "rsvld_conv3x3_halo_nhwc"))
         if part_out is not None:
             out._gn_part = (part_out, ntiles)
@@ -425,7 +425,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         wg128 = ((Mp + 127) // 128) * ((pc.cout_p + 127) // 128)
         wg64 = ((Mp + 63) // 64) * ((pc.cout_p + 127) // 128)
         variant = "conv_igemm_64x64" if wg64 < 256 else ("conv_igemm_64x128" if wg128 < 256 else "conv_igemm_128x128")
-    _launch(variant, flops, nbytes, lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
+    _launch(variant + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes, lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
     return out
 
 

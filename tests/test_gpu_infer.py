@@ -14,10 +14,11 @@ import s2_common as S
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("prec", ["default", "fp32"])
+@pytest.mark.parametrize("prec", ["default", "fp32", "split", "vae_split"])
 def test_pipeline_cli_flow(cuda, tmp_path, prec):
     """``fp32``: PipelineConfig(ae_dtype / diff_dtype / sr3_dtype = "fp32") = the CLI's --fp32: both stages on the fp32-operand
-    kernel family; same files, same sizes."""
+    kernel family; ``split`` = --split (both stages through the split-operand product path), ``vae_split`` = --vae_split (the VAE
+    passes only); same files, same sizes."""
     from PIL import Image
     from rsvld_amd import infer
     cfg = yaml.safe_load(open(S.YAML.replace("juggernautXL.yaml", "juggernautXL_cached.yaml")))
@@ -36,11 +37,14 @@ def test_pipeline_cli_flow(cuda, tmp_path, prec):
     pc = infer.PipelineConfig(input_img=str(tmp_path / "tile.png"), output_dir=str(tmp_path / "out"), model_yaml=str(ypath),
                               allow_random_init=True, no_llava=True,
                               upscale_factor=2, min_size=128, edm_steps=3, sr3_steps=3, seed=1, img_threshold=0.3,
-                              **(dict(ae_dtype="fp32", diff_dtype="fp32", sr3_dtype="fp32") if prec == "fp32" else {}))
+                              **(dict(ae_dtype=prec, diff_dtype=prec, sr3_dtype=prec) if prec in ("fp32", "split") else
+                                 dict(ae_dtype="split") if prec == "vae_split" else {}))
     pipe = infer.SuperResolutionPipeline(pc)
-    want_dt = torch.float32 if prec == "fp32" else torch.float16
+    want_dt = torch.float32 if prec in ("fp32", "split") else torch.float16
     assert pipe.sr3_model.netG.denoise_fn.compute_dtype == want_dt and pipe.refinement_model.model.dtype == want_dt
-    assert pipe.refinement_model.first_stage_model.compute_dtype == (torch.float32 if prec == "fp32" else torch.bfloat16)
+    assert pipe.refinement_model.first_stage_model.compute_dtype == (torch.bfloat16 if prec == "default" else torch.float32)
+    assert pipe.sr3_model.netG.denoise_fn.split == (prec == "split") and pipe.refinement_model.model.split == (prec == "split")
+    assert pipe.refinement_model.first_stage_model.split == (prec in ("split", "vae_split"))
     # zero-initialised output convs would make Stage 2 a no-op: give them small seeded weights
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():

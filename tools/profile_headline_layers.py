@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Per-layer table of the split-operand product path at the headline shapes (one iteration of each stage + the fixed part):
+"""Per-layer table of the headline shapes (one iteration of each stage + the fixed part), split-operand product path by default:
 RSVLD_PROFILE_DETAIL=1 makes rsvld_amd.ops append every matrix layer's shape to its profiler group.  Usage (GPU box):
-    RSVLD_PROFILE_DETAIL=1 python3 tools/profile_split_layers.py [--top 40]"""
+    python3 tools/profile_split_layers.py [--top 40] [--precision default|split|vae-split]"""
 import os
 import sys
 
@@ -16,7 +16,7 @@ import bench
 def main():
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 40
     from rsvld_amd import measure, ops, parallel
-    bench.PRECISION = "split"
+    bench.PRECISION = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "split"
     dev = torch.device("cuda:0")
     net, _ = bench.build_stage1(50)
     net.use_graph = False
