@@ -48,7 +48,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_ABL
-#define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue, 4 three K steps
+#define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue, 4 three K steps,
+                  // 8 the LDS-DMA source cycles over four K tiles (operands L2-resident: the K loop without memory latency)
 #endif
 // G_ONEBAR = 1 (experiment, round 3): ONE barrier per K tile instead of two (see the loop).  Correct (kernel tests green) and within
 // +-1 % of the two-barrier form on all nine headline shapes at 20 repetitions each (profiles/r03_gemm_onebar_ab.txt): the mid-tile
@@ -66,12 +67,26 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_STAGGER
 #define G_STAGGER 0   // experiment: first-round workgroups on every other CU start half a K loop late (s_sleep units per K tile),
 #endif                // so that the CUs' output bursts stop coinciding; 0 = off
+#ifndef G_ORDER2D
+#define G_ORDER2D 1   // tile order inside an XCD's run: 1 = blocks of 8 x 4 tiles (see the index computation), 0 = m fastest (rounds 2-3)
+#endif
+#ifndef G_STAMP
+#define G_STAMP 0     // diagnostic build: thread 0 of every workgroup records s_memrealtime (100 MHz) at its phase boundaries + HW_ID into
+#endif                // g_stamp_buf (read back by rsvld_debug_gemm_stamps; tools/gemm_stamps.py) -- where a tile's time goes, and the gap
+                      // between two workgroups on one CU
 constexpr int G_NST = 4;
 constexpr int G_RING = G_NST * G_STAGE;
 constexpr int G_SMEM = G_RING + 1024;   // + the tile's 256 bias values (fp32), fetched once while the ring fills
 
 // 64-B rows: 16-B slot s of row r sits at s ^ ((r>>2)&3): conflict-free ds_read_b128 (brute-forced, see conv_halo.hip)
 __device__ __forceinline__ int g_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+#if G_STAMP
+__device__ unsigned long long g_stamp_buf[16384 * 8];
+#define G_STAMP_AT(i) do { if (threadIdx.x == 0 && stamp_lid < 16384) g_stamp_buf[stamp_lid * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define G_STAMP_AT(i) do { } while (0)
+#endif
 
 template <int N> __device__ __forceinline__ void g_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -93,10 +108,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int lid = blockIdx.x + blockIdx.y * nmt;
         const int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, slot = lid >> 3;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+#if G_ORDER2D
+        // the 32 workgroups an XCD runs at a time form a block of 8 (m) x up to 4 (n) tiles: an activation tile is fetched into that
+        // L2 once per <= 4 workgroups and a weight tile once per 8, instead of 32 different activation tiles beside ONE weight tile
+        // (1-D order: every activation byte crossed the fabric once per 256 output columns).  Column blocks of balanced width.
+        const int nnt = gridDim.y;
+        const int NB = (nnt + 3) >> 2, wb = nnt / NB, ex = nnt - wb * NB;     // the first `ex` column blocks are wb + 1 tiles wide
+        const int big = nmt * (wb + 1);
+        int nb, rem, w, nfirst;
+        if (t < ex * big) { nb = t / big; rem = t - nb * big; w = wb + 1; nfirst = nb * (wb + 1); }
+        else { const int u = t - ex * big; nb = u / (nmt * wb); rem = u - nb * (nmt * wb); w = wb; nfirst = ex * (wb + 1) + nb * wb; }
+        const int mb = rem / (8 * w), rr = rem - mb * (8 * w);
+        const int h = min(8, nmt - 8 * mb);
+        const int dn = rr / h;
+        tile_n = nfirst + dn;
+        tile_m = 8 * mb + (rr - dn * h);
+#else
         tile_n = t / nmt;
         tile_m = t - tile_n * nmt;
+#endif
     }
     const int m0 = tile_m * 256, n0 = tile_n * 256;
+#if G_STAMP
+    const int stamp_lid = blockIdx.x + blockIdx.y * gridDim.x;
+    G_STAMP_AT(0);
+    if (threadIdx.x == 0 && stamp_lid < 16384) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_stamp_buf[stamp_lid * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int nk0 = p.K >> 5;
     const int nk = (G_ABL & 4) ? 3 : (SPLIT ? 3 * nk0 : nk0);   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
     const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 2 : 1);    // activation row: K values, or the planes lo | hi
@@ -132,8 +174,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #if G_ASMDMA
         const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024);
         // SPLIT: the activation planes are read lo, hi, hi (tiles >= 2 nk0 alias the hi plane); the weight triple is linear
-        const int ktx = (SPLIT && kt >= 2 * nk0) ? kt - nk0 : kt;
-        const char* base = (j & 1) ? Wb + kt * 64 : Xb + ktx * 64;
+        const int ktx = (G_ABL & 8) ? (kt & 3) : (SPLIT && kt >= 2 * nk0) ? kt - nk0 : kt;
+        const char* base = (j & 1) ? Wb + ((G_ABL & 8) ? (kt & 3) : kt) * 64 : Xb + ktx * 64;
         const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[j >> 1];
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
 #else
@@ -232,6 +274,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     else g_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    G_STAMP_AT(1);
+#if G_STAMP
+    const unsigned long long stamp_c0 = __builtin_readcyclecounter();
+#endif
 
     // ---- 2 nk + 1 slots; group 0 reads in even slots and multiplies in odd ones, group 1 runs one slot behind.
     // Tile kt+3 is requested in the multiply slot of tile kt (its stage held tile kt-1, whose last reads returned
@@ -309,6 +355,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 
 #endif
 
+    G_STAMP_AT(2);
+#if G_STAMP
+    if (threadIdx.x == 0 && stamp_lid < 16384) g_stamp_buf[stamp_lid * 8 + 6] = __builtin_readcyclecounter() - stamp_c0;
+#endif
 #if G_ABL & 2
     if (p.M > 0) return;   // diagnostic build: no epilogue at all (the accumulators stay live for the compiler)
 #endif
@@ -517,6 +567,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     }
 #endif
     __syncthreads();
+    G_STAMP_AT(3);
     {
         const int n_tile_out = geglu ? 128 : 256;                         // channels of the stored tile
         const int n_out0 = geglu ? (n0 >> 1) : n0;
@@ -560,9 +611,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         }
         (void)n_tile_out;
     }
+#if G_STAMP
+    G_STAMP_AT(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G_STAMP_AT(5);
+#endif
 }
 
 }  // namespace
+
+#if G_STAMP
+extern "C" int rsvld_debug_gemm_stamps(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamp_buf), bytes < sizeof(g_stamp_buf) ? bytes : sizeof(g_stamp_buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Eligibility + launch, called from rsvld_conv2d_nhwc for 1x1 / stride-1 / single-source layers.
 // Returns RSVLD_EUNSUPPORTED when the shape should stay on the implicit-GEMM kernel.

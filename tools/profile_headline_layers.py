@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer table of the headline shapes (one iteration of each stage + the fixed part), split-operand product path by default:
 RSVLD_PROFILE_DETAIL=1 makes rsvld_amd.ops append every matrix layer's shape to its profiler group.  Usage (GPU box):
-    python3 tools/profile_split_layers.py [--top 40] [--precision default|split|vae-split]"""
+    python3 tools/profile_headline_layers.py [--top 40] [--precision default|split|vae-split]"""
 import os
 import sys
 
