@@ -92,6 +92,7 @@ typedef struct rsvld_conv_desc {
 #define RSVLD_TUNE_HALO_NW4 (1 << 8)    /* halo conv: force the 4-wave 8x32 tile                          */
 #define RSVLD_TUNE_HALO_NW8 (1 << 9)    /* halo conv: force the 8-wave 16x32 tile                         */
 #define RSVLD_TUNE_NO_GEMM256 (1 << 10) /* keep large 1x1 / Linear layers on the implicit-GEMM kernel     */
+#define RSVLD_TUNE_GEMM_ONE_TILE (1 << 12) /* gemm256: one tile per workgroup (rounds 2-3) instead of the persistent form          */
 #define RSVLD_TUNE_F32_SPLIT (1 << 11)  /* rsvld_conv2d_nhwc_f32 only -- a precision MODE, not an A/B switch: every fp32 operand is
                                          * split into hi + lo bf16 and each product runs as three 16-bit MFMAs into the fp32
                                          * accumulator (~1e-5 relative; the "split" precision of SR_backbone.set_precision)        */

@@ -17,6 +17,7 @@ ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 TUNE_TILE = {"256x64": 1, "128x64": 2, "128x128": 3, "64x128": 4}
 TUNE_STAGES_SHIFT, TUNE_NO_KSPLIT, TUNE_REG_STAGING = 3, 1 << 6, 1 << 7
 TUNE_HALO_NW4, TUNE_HALO_NW8, TUNE_NO_GEMM256 = 1 << 8, 1 << 9, 1 << 10
+TUNE_GEMM_ONE_TILE = 1 << 12   # gemm256: one tile per workgroup instead of the persistent form (A/B)
 TUNE_F32_SPLIT = 1 << 11   # rsvld_conv2d_nhwc_f32: split-operand precision mode (three 16-bit MFMAs per fp32 product)
 
 ERRORS = {-1: "RSVLD_EINVAL (bad shape / pointer / combination)",

@@ -77,6 +77,7 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 constexpr int G_NST = 4;
 constexpr int G_RING = G_NST * G_STAGE;
 constexpr int G_SMEM = G_RING + 1024;   // + the tile's 256 bias values (fp32), fetched once while the ring fills
+constexpr int G_SMEM_P = G_RING + 8 * 4096;   // PERSIST: + a private 4 KiB transposition buffer per wave = all 160 KiB of the CU
 
 // 64-B rows: 16-B slot s of row r sits at s ^ ((r>>2)&3): conflict-free ds_read_b128 (brute-forced, see conv_halo.hip)
 __device__ __forceinline__ int g_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
@@ -90,8 +91,13 @@ __device__ unsigned long long g_stamp_buf[16384 * 8];
 
 template <int N> __device__ __forceinline__ void g_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, bool SPLIT = false>
+// PV (PERSIST only): the epilogue variant, chosen on the host: activation (0 none, 1 SiLU, 2 GEGLU) | 4 x (alpha == 1) | 8 x residual.
+// One variant per instantiation: with the seven variants behind a dispatch inside the tile loop hipcc spilled 490-680 dwords around
+// the epilogue (none with one variant), and a scratch reload is a vector-memory load that queues behind the ring's LDS-DMA pieces.
+template <typename T, bool SPLIT = false, bool PERSIST = false, int PV = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
+    static_assert(!(SPLIT && PERSIST), "the persistent form exists for the 16-bit epilogue only");
+    static_assert(PERSIST || PV == 0, "PV is the persistent epilogue's variant");
     typedef typename Mfma<T>::v8 v8;
     typedef typename Mfma<T>::v4 v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,18 +107,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int grp = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // XCD-aware tile order: each XCD walks a contiguous run of tiles, m fastest (the weight tile stays in that L2)
-    int tile_m, tile_n;
+    // ---- tiles.  XCD-aware order: each XCD (= linear workgroup id mod 8) walks a contiguous run of the tile sequence.  One tile per
+    // workgroup (grid = the tile grid), or PERSIST: one workgroup per CU, workgroup c of an XCD takes tiles c, c + step, ... of the run.
+    const int nmt = (p.M + 255) >> 8, nnt = (p.N + 255) >> 8;
+    int t_cur, t_end, t_step;
     {
-        const int nmt = gridDim.x, nwg = gridDim.x * gridDim.y;
-        const int lid = blockIdx.x + blockIdx.y * nmt;
-        const int q = nwg >> 3, r = nwg & 7, xcd = lid & 7, slot = lid >> 3;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        const int ntiles = nmt * nnt;
+        const int lid = PERSIST ? (int)blockIdx.x : (int)(blockIdx.x + blockIdx.y * gridDim.x);
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = lid & 7;
+        const int ts = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        t_cur = ts + (lid >> 3);
+        t_end = PERSIST ? ts + q + (xcd < r ? 1 : 0) : t_cur + 1;
+        t_step = PERSIST ? ((int)gridDim.x - xcd + 7) >> 3 : 1;
+        if (PERSIST && t_cur >= t_end) return;
+    }
+    auto tile_of = [&](int t, int& tile_m, int& tile_n) {
 #if G_ORDER2D
         // the 32 workgroups an XCD runs at a time form a block of 8 (m) x up to 4 (n) tiles: an activation tile is fetched into that
         // L2 once per <= 4 workgroups and a weight tile once per 8, instead of 32 different activation tiles beside ONE weight tile
         // (1-D order: every activation byte crossed the fabric once per 256 output columns).  Column blocks of balanced width.
-        const int nnt = gridDim.y;
         const int NB = (nnt + 3) >> 2, wb = nnt / NB, ex = nnt - wb * NB;     // the first `ex` column blocks are wb + 1 tiles wide
         const int big = nmt * (wb + 1);
         int nb, rem, w, nfirst;
@@ -127,42 +140,83 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         tile_n = t / nmt;
         tile_m = t - tile_n * nmt;
 #endif
-    }
-    const int m0 = tile_m * 256, n0 = tile_n * 256;
-#if G_STAMP
-    const int stamp_lid = blockIdx.x + blockIdx.y * gridDim.x;
-    G_STAMP_AT(0);
-    if (threadIdx.x == 0 && stamp_lid < 16384) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_stamp_buf[stamp_lid * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
-    }
-#endif
+    };
     const int nk0 = p.K >> 5;
     const int nk = (G_ABL & 4) ? 3 : (SPLIT ? 3 * nk0 : nk0);   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
     const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 2 : 1);    // activation row: K values, or the planes lo | hi
     const int64_t rowb_w = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 3 : 1);  // weight row: K values, or the triple hi | lo | hi
-    if (G_STAGGER > 0) {
+    if (G_STAGGER > 0 && !PERSIST) {
         const int lid = blockIdx.x + blockIdx.y * gridDim.x;
         if (lid < 256 && ((lid >> 3) & 1))
             for (int i = 0; i < nk; ++i) __builtin_amdgcn_s_sleep(G_STAGGER);
     }
 
-    // ---- DMA roles: wave w fills rows 32w .. 32w+31 of X and of W: two wave-instructions of 16 rows x 64 B each.
+    // ---- per tile: DMA roles.  Wave w fills rows 32w .. 32w+31 of X and of W: two wave-instructions of 16 rows x 64 B each.
     // lane -> (row = lane>>2, position = lane&3) holds source chunk position ^ ((row>>2)&3); rows past the end of the
     // tensor re-read its last row (their outputs are never stored)
+    int m0 = 0, n0 = 0;
     uint32_t xvo[2], wvo[2];
+    const char *Xb = nullptr, *Wb = nullptr;
+    // PERSIST: the tile's bias enters as the C operand of the first k-step (bC[ni][4 g + e] = bias of channel n0 + 64 wn + 32 ni + 8 g
+    // + 4 lh + e, the accumulator layout): no bias pass in the epilogue and no accumulator clearing.  (The one-tile form keeps the
+    // tile's bias row in LDS and adds it in the epilogue: sum + bias instead of bias + sum, one fp32 rounding apart.)
+    // Its way there touches no register: every wave requests the 64 bias values of its columns by ONE LDS-DMA piece (4 bytes per
+    // lane) into ring stage 3 -- free from the end of a tile's K loop until the first multiply slot of the next tile requests K tile
+    // 3 -- IN FRONT of that tile's K tiles 0..2, so the counted wait before the first fragment read covers it; both groups fetch
+    // their eight quads from there before group 0's first multiply slot opens.  (A register-parked value would be an asynchronous
+    // load the compiler may copy before it has arrived; a load hipcc can see gets a compiler-placed vmcnt(0) inside the epilogue.)
+    f32x16 bC[2];
+    auto dma_bias = [&](int n_first) {
+        if (p.bias != nullptr) {
+            const uint32_t dst = (uint32_t)(uintptr_t)(lptr_t)smem + (uint32_t)(3 * G_STAGE + wave * 256);
+            int tq = tid;
+            asm volatile("" : "+v"(tq));   // (nothing derived from it is hoisted out of the tile loop and spilled)
+            const uint32_t voff = (uint32_t)min(n_first + wn * 64 + (tq & 63), p.N - 1) * 4u;   // channels past N are never stored
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2" : : "v"(voff), "s"(dst), "s"(p.bias) : "memory", "m0");
+        }
+    };
+    auto read_bias = [&]() {
+        const char* const Bw = smem + 3 * G_STAGE + wave * 256;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = 32 * wave + 16 * i + (lane >> 2);
-        const uint32_t ch = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-        // offsets relative to the TILE's first row (the scalar bases below carry the 64-bit part): 256 rows x row bytes < 2^32
-        xvo[i] = (uint32_t)((int64_t)(min(m0 + r, p.M - 1) - m0) * rowb) + ch;
-        wvo[i] = (uint32_t)((int64_t)(min(n0 + r, p.N - 1) - n0) * rowb_w) + ch;
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias != nullptr) bv = *(const f32x4*)(Bw + (ni * 32 + 8 * g + 4 * lh) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bC[ni][4 * g + e] = bv[e];
+            }
+    };
+    auto setup_tile = [&](int t) {
+        int tile_m, tile_n;
+        tile_of(t, tile_m, tile_n);
+        m0 = tile_m * 256;
+        n0 = tile_n * 256;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int tq = tid;
+            if (PERSIST) asm volatile("" : "+v"(tq));   // (nothing derived from it is hoisted out of the tile loop: see load_bias)
+            const int r = 32 * wave + 16 * i + ((tq & 63) >> 2);
+            const uint32_t ch = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+            // offsets relative to the TILE's first row (the scalar bases below carry the 64-bit part): 256 rows x row bytes < 2^32
+            xvo[i] = (uint32_t)((int64_t)(min(m0 + r, p.M - 1) - m0) * rowb) + ch;
+            wvo[i] = (uint32_t)((int64_t)(min(n0 + r, p.N - 1) - n0) * rowb_w) + ch;
+        }
+        Xb = (const char*)p.x + (int64_t)m0 * rowb;
+        Wb = (const char*)p.w + (int64_t)n0 * rowb_w;
+    };
+    setup_tile(t_cur);
+#if G_STAMP
+    int stamp_lid = PERSIST ? t_cur : (int)(blockIdx.x + blockIdx.y * gridDim.x);
+    unsigned long long stamp_hw;
+    {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamp_hw = ((unsigned long long)xcc << 32) | hw;
     }
-    const char* Xb = (const char*)p.x + (int64_t)m0 * rowb;
-    const char* Wb = (const char*)p.w + (int64_t)n0 * rowb_w;
+    G_STAMP_AT(0);
+#endif
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     // j = 0..3: (X, W) x (rows 0..15, 16..31) of this wave's share of tile kt.
     // G_ASMDMA: the builtin made hipcc form a per-lane 64-bit address for every piece -- a v_lshl_add_u64 INTO the fragment
@@ -189,14 +243,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma_piece(kt, j);
     };
+    // the same pieces through the builtin: hipcc SEES them (its vmcnt bookkeeping counts them), for the prefetch in front of an
+    // epilogue that waits for compiler-visible residual loads
+    auto dma_tile_visible = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            char* st = smem + (kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024;
+            const char* src = (j & 1) ? Wb + kt * 64 : Xb + kt * 64;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + ((j & 1) ? wvo[j >> 1] : xvo[j >> 1])), (lptr_t)st, 16, 0, 0);
+        }
+    };
 
     f32x16 acc[2][4];   // [n tile][m tile]
+    if constexpr (!PERSIST) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+    }
 
     int fa_off[2], fb_off[2];
 #pragma unroll
@@ -232,14 +298,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             }
         __builtin_amdgcn_s_setprio(0);
     };
-    auto mma_tile_dma = [&](int next) {   // steady state: the tile to request always exists, no branch around the pieces
+    // FIRST (PERSIST, K tile 0): the first k-step takes the bias registers as its C operand
+    auto mma_tile_dma = [&](int next, auto FIRST) {   // steady state: the tile to request always exists, no branch around the pieces
+        constexpr bool first = decltype(FIRST)::value;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], acc[ni][mi]);
+                for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], (first && ks == 0) ? bC[ni] : acc[ni][mi]);
                 __builtin_amdgcn_sched_barrier(0);   // one piece after every fourth MFMA (hipcc otherwise moves the asm
                 dma_piece(next, 2 * ks + ni);        // statements to the head of the slot, three of them behind the first MFMA)
                 __builtin_amdgcn_sched_barrier(0);
@@ -258,17 +326,229 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue: three tiles in flight, tile 0 landed for everybody; the tile's bias row goes to LDS beside the ring (the
+    // ---- prologue: three tiles in flight; the one-tile form keeps the tile's bias row in LDS beside the ring (the
     // epilogue read it from global memory once per accumulator quad: a dependent L2 round trip at the head of every output burst)
-    if (tid < 64) {
+    if (!PERSIST && tid < 64) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         const int n = n0 + tid * 4;
         if (p.bias != nullptr && n < p.N) bv = *(const f32x4*)(p.bias + n);   // N % 8 == 0: a quad is inside or outside as a whole
         *(f32x4*)(smem + G_RING + tid * 16) = bv;
     }
+    if constexpr (PERSIST) dma_bias(n0);
     dma_tile(0);
     if (nk > 1) dma_tile(1);
     if (nk > 2) dma_tile(2);
+
+    if constexpr (PERSIST) {
+        // ================= PERSIST: one workgroup per CU walks its tiles (host: nk >= 4, 16-bit output) =================
+        // What the one-tile form leaves exposed per tile (tools/gemm_stamps.py, profiles/r04_gemm_stamps.txt: 7-11 us beside a K loop of
+        // 16-33 us at K = 640 / 1 280): the ring fill of the next workgroup (2-3 us), the gap between two workgroups on a CU (1.3 us),
+        // the staging barrier and the store phase (stores issued only after the WHOLE tile is staged, acknowledged before the
+        // workgroup may end).  Here: (1) the next tile's first three K tiles are requested BEFORE the epilogue, into ring stages nobody
+        // reads any more; (2) the epilogue needs no workgroup barrier and no ring space: every wave transposes its own 32 x 64 blocks
+        // through a private 4 KiB LDS buffer (32 rows x 128 B, 16-byte chunks XOR-swizzled by the row) and stores 8 rows x 128 B per
+        // instruction as soon as a block is read back; (3) nobody waits for a store: vmcnt counts in order on gfx9, the next
+        // counted wait of the K loop covers them; (4) the accumulators are never cleared (FIRST above).
+        // Barriers per tile: one in front of the first fragment read + two per K tile; group 1's last multiply slot ends without one
+        // (group 0 is in its epilogue by then), which keeps the two groups' barrier counts equal: 2 nk + 1 each.
+        const int nk_main = nk - 3;
+        char* const P = smem + G_RING + wave * 4096;
+        const int wbase = l31 * 128 + lh * 8, x7 = (l31 & 7) << 4;                          // block write: + ((16-byte chunk << 4) ^ x7)
+        const int rbase = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);            // block read: + i * 1024 (rows lane/8 + 8 i)
+        const int gwbase = l31 * 64 + lh * 4, gx3 = (l31 & 3) << 4;                         // GEGLU: 32 rows x 64 B
+        const int grbase = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 2) & 3)) << 4);      // GEGLU read: + i * 1024 (rows lane/4 + 16 i)
+        for (;;) {
+            g_wait_vm<8>();   // own pieces of K tile 0 (tiles 1, 2 and, from the second tile on, the last stores may stay in flight)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int t_next = t_cur + t_step;
+            const bool has_next = t_next < t_end;
+#if G_STAMP
+            stamp_lid = t_cur;
+            if (threadIdx.x == 0 && stamp_lid < 16384) g_stamp_buf[stamp_lid * 8 + 7] = stamp_hw;
+            G_STAMP_AT(0);
+            G_STAMP_AT(1);
+            const unsigned long long stamp_c0 = __builtin_readcyclecounter();
+#endif
+            if (grp == 0) {
+                read_tile(0);
+                read_bias();
+                slot_end();
+                mma_tile_dma(3, std::true_type{});
+                g_wait_vm<8>();
+                slot_end();
+                for (int kt = 1; kt < nk_main; ++kt) {
+                    read_tile(kt);
+                    slot_end();
+                    mma_tile_dma(kt + 3, std::false_type{});
+                    g_wait_vm<8>();
+                    slot_end();
+                }
+                for (int kt = nk_main; kt < nk; ++kt) {
+                    read_tile(kt);
+                    slot_end();
+                    mma_tile(-1);
+                    wait_ahead(min(nk - 1, kt + 3) - (kt + 1));
+                    slot_end();
+                }
+            } else {
+                read_bias();     // (before group 0's first multiply slot, which requests K tile 3 into the stage that holds the bias rows)
+                slot_end();
+                read_tile(0);
+                g_wait_vm<4>();
+                slot_end();
+                mma_tile_dma(3, std::true_type{});
+                slot_end();
+                for (int kt = 1; kt < nk_main; ++kt) {
+                    read_tile(kt);
+                    g_wait_vm<4>();
+                    slot_end();
+                    mma_tile_dma(kt + 3, std::false_type{});
+                    slot_end();
+                }
+                for (int kt = nk_main; kt < nk; ++kt) {
+                    read_tile(kt);
+                    wait_ahead(min(nk - 1, kt + 2) - (kt + 1));
+                    slot_end();
+                    mma_tile(-1);
+                    if (kt != nk - 1) slot_end();
+                }
+            }
+            G_STAMP_AT(2);
+#if G_STAMP
+            if (threadIdx.x == 0 && stamp_lid < 16384) g_stamp_buf[stamp_lid * 8 + 6] = __builtin_readcyclecounter() - stamp_c0;
+#endif
+            // ---- tile end.  Order of the vector-memory instructions of a wave: residual pieces (16) | next tile's K tiles 0..2 (12) |
+            // [block stores | next tile's bias quads (8) | block stores].  The residual loads are asm statements with ONE counted wait
+            // behind the transposition of all four blocks (vmcnt(12): the ring pieces stay in flight; no store has been issued by
+            // then): hipcc's own wait insertion does not see the LDS-DMA statements and would count them short, i.e. wait for the
+            // ring in front of every residual use.  vmcnt counts in order on gfx9, stores included.
+            const int m0e = m0, n0e = n0;
+            // ---- every wave: its four 32-row blocks through the private buffer.  ONE dispatch on (activation, alpha == 1, residual)
+            // around everything that follows, so that the 64 residual registers exist in the residual variants only.
+            {
+                constexpr int act = PV & 3;
+                constexpr bool alpha1 = (PV & 4) != 0;
+                constexpr bool res = (PV & 8) != 0;
+                // Residual variants: the 16 pieces of a lane in two halves of 8 (the second behind block 1, when 64 accumulator
+                // registers have been released), the next tile's ring pieces behind them: acc + residual + transposed blocks <= 192.
+                u32x4 rv[res ? 16 : 1];
+                auto load_res = [&](int half) {
+                    const int nr = n0e + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+                    for (int c = 8 * half; c < 8 * half + 8; ++c) {
+                        const int m = m0e + grp * 128 + (c >> 2) * 32 + (c & 3) * 8 + (lane >> 3);
+                        // rows / columns past the end re-read a valid address (never stored)
+                        rv[res ? c : 0] = *(const u32x4*)((const T*)p.residual + (int64_t)min(m, p.M - 1) * p.N_out + (nr < p.N_out ? nr : 0));
+                    }
+                };
+                auto prefetch_next = [&]() {
+                    if (has_next) {
+                        setup_tile(t_next);
+                        dma_bias(n0);
+                        dma_tile(0);
+                        dma_tile(1);
+                        dma_tile(2);
+                    }
+                };
+                if constexpr (res) load_res(0);
+                else prefetch_next();
+                constexpr int NCH = act == 2 ? 2 : 4;          // 16-byte chunks per lane and block
+                constexpr int RSTEP = act == 2 ? 16 : 8;       // rows between two chunks of a lane
+                // stores: non-GEGLU lane -> rows lane/8 + 8 i (+ 32 mi), channels 8 (lane % 8) .. + 8 of the wave's 64 (8 rows x 128 B per
+                // instruction); GEGLU lane -> rows lane/4 + 16 i, output channels 8 (lane % 4) .. + 8 of the wave's 32 (16 rows x 64 B)
+                const int nn = act == 2 ? (n0e >> 1) + wn * 32 + (lane & 3) * 8 : n0e + wn * 64 + (lane & 7) * 8;
+                const int r0 = m0e + grp * 128 + (act == 2 ? (lane >> 2) : (lane >> 3));
+                T* const op = (T*)p.out + (int64_t)r0 * p.N_out + nn;
+                const int64_t rstep = (int64_t)RSTEP * p.N_out;
+                u32x4 o[res ? 16 : NCH];
+                auto store_block = [&](int mi, const u32x4* ob) {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        const int m = r0 + mi * 32 + i * RSTEP;
+                        if (nn < p.N_out && m < p.M && !((G_ABL & 1) && p.M > 0)) {
+                            u32x4 val = ob[i];
+                            if constexpr (res) {
+                                float f[8], rf[8];
+                                unpack8<T>(val, f);
+                                unpack8<T>(rv[mi * 4 + i], rf);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
+                                val = pack8<T>(f);
+                            }
+                            *(u32x4*)(op + (mi * (32 / RSTEP) + i) * rstep) = val;
+                        }
+                    }
+                };
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e];
+                            if constexpr (act == 2) {   // channels are (value, gate) interleaved: 2 outputs per quad
+                                T o2[2] = {(T)(p.alpha * v[0] * gelu_erf_f(v[1])), (T)(p.alpha * v[2] * gelu_erf_f(v[3]))};
+                                uint32_t packed;
+                                __builtin_memcpy(&packed, o2, 4);
+                                *(uint32_t*)(P + gwbase + (((ni * 2 + (g >> 1)) << 4) ^ gx3) + (g & 1) * 8) = packed;
+                            } else {
+                                if constexpr (act == 1) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                                }
+                                v4 ov;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) ov[e] = alpha1 ? (T)v[e] : (T)(v[e] * p.alpha);
+                                *(v4*)(P + wbase + (((ni * 4 + g) << 4) ^ x7)) = ov;
+                            }
+                        }
+                    u32x4* const ob = res ? o + mi * 4 : o;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) ob[i] = *(const u32x4*)(P + (act == 2 ? grbase : rbase) + i * 1024);
+                    if constexpr (!res) {
+                        store_block(mi, ob);
+                    } else if (mi == 1) {
+                        load_res(1);
+                    }
+                }
+                if constexpr (res) {
+                    // Residual variants: the 16 pieces are loads hipcc sees (an asm load is a register the compiler may copy before the
+                    // data has arrived: it did, in front of a tied wait statement), so its own wait sits in front of their first use
+                    // and counts only what it sees.  The next tile's pieces are therefore requested BEHIND an explicit wait for
+                    // the residual (nothing else is in flight at that point) and before the add-and-store pass, whose length
+                    // they have to land in; the compiler's later waits then only ask for ring pieces the K loop is about to need.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    prefetch_next();
+                    G_STAMP_AT(3);
+                    // a full tile takes a branch-free path: in straight-line code hipcc's vmcnt bookkeeping is exact (the residual piece
+                    // a store needs, with the younger residual pieces, the 12 ring pieces and the stores issued so far left in flight);
+                    // behind the per-row guards of the edge path it falls back to vmcnt(0), i.e. waits for the ring pieces
+                    if (m0e + 256 <= p.M && n0e + 256 <= p.N_out && !(G_ABL & 1)) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            float f[8], rf[8];
+                            unpack8<T>(o[c], f);
+                            unpack8<T>(rv[c], rf);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
+                            *(u32x4*)(op + ((c >> 2) * 4 + (c & 3)) * rstep) = pack8<T>(f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) store_block(mi, o + mi * 4);
+                    }
+                }
+            }
+            G_STAMP_AT(4);
+            G_STAMP_AT(5);
+            if (!has_next) return;
+            t_cur = t_next;
+        }
+    }
+
     if (nk > 2) g_wait_vm<8>();
     else if (nk > 1) g_wait_vm<4>();
     else g_wait_vm<0>();
@@ -276,6 +556,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     G_STAMP_AT(1);
 #if G_STAMP
+    if (threadIdx.x == 0 && stamp_lid < 16384) g_stamp_buf[stamp_lid * 8 + 7] = stamp_hw;
     const unsigned long long stamp_c0 = __builtin_readcyclecounter();
 #endif
 
@@ -300,7 +581,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             g_wait_vm<4>();
             slot_end();
         }
-        mma_tile_dma(kt + 3);
+        mma_tile_dma(kt + 3, std::false_type{});
         if (grp == 1) {
             g_wait_vm<8>();
             slot_end();
@@ -323,7 +604,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         for (int kt = 0; kt < nk_main; ++kt) {              // steady state: two tiles stay in flight behind tile kt + 1
             read_tile(kt);
             slot_end();
-            mma_tile_dma(kt + 3);
+            mma_tile_dma(kt + 3, std::false_type{});
             g_wait_vm<8>();
             slot_end();
         }
@@ -341,7 +622,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             read_tile(kt);
             g_wait_vm<4>();
             slot_end();
-            mma_tile_dma(kt + 3);
+            mma_tile_dma(kt + 3, std::false_type{});
             slot_end();
         }
         for (int kt = nk_main; kt < nk; ++kt) {
@@ -652,13 +933,35 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
     a.out_planes = (split && !d->out_f32) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((M + 255) / 256), (unsigned)((d->Cout + 255) / 256));
-    auto go = [&](auto kern) -> int {
-        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM);
+    const unsigned nmt = (unsigned)((M + 255) / 256), nnt = (unsigned)((d->Cout + 255) / 256);
+    auto go = [&](auto kern, dim3 grid, int smem) -> int {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (attr != hipSuccess) return RSVLD_ELAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(512), G_SMEM, s, a);
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, s, a);
         return rsvld_check_launch();
     };
-    if (split) return go(gemm256_kernel<bf16, true>);
-    return d->dtype == RSVLD_F16 ? go(gemm256_kernel<f16, false>) : go(gemm256_kernel<bf16, false>);
+    if (split) return go(gemm256_kernel<bf16, true, false>, dim3(nmt, nnt), G_SMEM);
+    // the persistent form: 16-bit output, at least four K tiles (its K loop peels tile 0 and requests three tiles ahead)
+    if (!(d->tune & RSVLD_TUNE_GEMM_ONE_TILE) && d->Cin >= 128) {
+        static const int n_cu = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+            return n;
+        }();
+        if (n_cu > 0) {
+            const dim3 pgrid((unsigned)min((int64_t)nmt * nnt, (int64_t)n_cu));
+            const int pv = (a.act == RSVLD_ACT_GEGLU ? 2 : a.act == RSVLD_ACT_SILU ? 1 : 0) | (a.alpha == 1.0f ? 4 : 0) | (a.residual != nullptr ? 8 : 0);
+            const bool h = d->dtype == RSVLD_F16;
+#define G_PV_CASE(V) case V: return h ? go(gemm256_kernel<f16, false, true, V>, pgrid, G_SMEM_P) : go(gemm256_kernel<bf16, false, true, V>, pgrid, G_SMEM_P);
+            switch (pv) {
+                G_PV_CASE(0) G_PV_CASE(4) G_PV_CASE(8) G_PV_CASE(12)      // no activation: alpha, alpha == 1, + residual
+                G_PV_CASE(1) G_PV_CASE(5) G_PV_CASE(9) G_PV_CASE(13)      // SiLU
+                G_PV_CASE(2) G_PV_CASE(6)                                 // GEGLU (never with a residual: checked above)
+                default: break;
+            }
+#undef G_PV_CASE
+        }
+    }
+    return d->dtype == RSVLD_F16 ? go(gemm256_kernel<f16, false, false>, dim3(nmt, nnt), G_SMEM)
+                                 : go(gemm256_kernel<bf16, false, false>, dim3(nmt, nnt), G_SMEM);
 }

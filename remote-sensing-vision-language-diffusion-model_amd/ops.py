@@ -202,6 +202,8 @@ def _tune_from_env():
         t |= L.TUNE_HALO_NW8 if e["RSVLD_HALO_NW"][:1] == "8" else L.TUNE_HALO_NW4
     if e.get("RSVLD_GEMM256_OFF") is not None:
         t |= L.TUNE_NO_GEMM256
+    if e.get("RSVLD_GEMM256_ONE_TILE") is not None:
+        t |= L.TUNE_GEMM_ONE_TILE
     return t
 
 
