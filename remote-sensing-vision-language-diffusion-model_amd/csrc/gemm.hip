@@ -70,6 +70,9 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_ORDER2D
 #define G_ORDER2D 1   // tile order inside an XCD's run: 1 = blocks of 8 x 4 tiles (see the index computation), 0 = m fastest (rounds 2-3)
 #endif
+#ifndef G_GELU_PACKED
+#define G_GELU_PACKED 1   // persistent GEGLU epilogue: the pairwise GELU in packed fp32 arithmetic (gelu_erf2_f); 0 = the scalar form
+#endif
 #ifndef G_STAMP
 #define G_STAMP 0     // diagnostic build: thread 0 of every workgroup records s_memrealtime (100 MHz) at its phase boundaries + HW_ID into
 #endif                // g_stamp_buf (read back by rsvld_debug_gemm_stamps; tools/gemm_stamps.py) -- where a tile's time goes, and the gap
@@ -490,7 +493,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e];
                             if constexpr (act == 2) {   // channels are (value, gate) interleaved: 2 outputs per quad
+#if G_GELU_PACKED
+                                const f32x2_t gl = gelu_erf2_f((f32x2_t){v[1], v[3]});
+                                const f32x2_t pr = ((f32x2_t){v[0], v[2]} * p.alpha) * gl;
+                                T o2[2] = {(T)pr[0], (T)pr[1]};
+#else
                                 T o2[2] = {(T)(p.alpha * v[0] * gelu_erf_f(v[1])), (T)(p.alpha * v[2] * gelu_erf_f(v[3]))};
+#endif
                                 uint32_t packed;
                                 __builtin_memcpy(&packed, o2, 4);
                                 *(uint32_t*)(P + gwbase + (((ni * 2 + (g >> 1)) << 4) ^ gx3) + (g & 1) * 8) = packed;

@@ -80,6 +80,27 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
+// The same GELU (same erf approximation, same coefficients) on a PAIR of values, written so that hipcc emits packed fp32 arithmetic
+// (6 v_pk_fma_f32 + 4 v_pk_mul_f32 per pair beside the 2 v_rcp + 2 v_exp): gelu(x) = max(x, 0) - |x| * (0.5 P(t) t) exp(-x^2 / 2),
+// t = 1 / (1 + 0.3275911 |x| / sqrt 2).  The GEGLU epilogue of the persistent gemm256 is pure vector work (64 GELUs per lane and
+// tile, two waves per SIMD: 8-10 us beside a 20-40 us K loop); this form needs 10 packed + 6 plain + 4 transcendental instructions
+// per pair where the scalar form needs 2 x (14 + 2).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2_f(f32x2_t x) {
+    const f32x2_t ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+    const f32x2_t u = ax * 0.2316418882f + 1.0f;                  // 0.3275911 / sqrt 2
+    const f32x2_t t = {__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
+    const f32x2_t w = (x * -0.7213475204f) * x;                   // -x^2 / 2 * log2 e
+    const f32x2_t e = {__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
+    f32x2_t poly = t * 0.5307027145f - 0.7265760135f;             // the Abramowitz-Stegun 7.1.26 coefficients, halved
+    poly = poly * t + 0.7107068705f;
+    poly = poly * t - 0.142248368f;
+    poly = poly * t + 0.127414796f;
+    const f32x2_t q = (poly * t) * e;
+    const f32x2_t r = {__builtin_fmaxf(x[0], 0.f), __builtin_fmaxf(x[1], 0.f)};
+    return r - ax * q;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
