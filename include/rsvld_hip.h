@@ -360,6 +360,13 @@ int rsvld_gemv(const void* w, const void* x, const void* bias, void* y, int N, i
 /* fp32 [rows][C] -> planes [rows][2C], and back (x = float(hi) + float(lo)) */
 int rsvld_split_planes(const float* x, void* planes, int64_t rows, int C, void* stream);
 int rsvld_merge_planes(const void* planes, float* x, int64_t rows, int C, void* stream);
+/* The "split, attention in fp16" composition (rsvld_amd.ops.SPLIT_ATTN = "f16"): the operands of an attention leave the planes as fp16
+ * (x = fp16(float(hi) + float(lo)); `ld` = row stride and `plane_stride` = distance lo -> hi of the source, in elements: a channel
+ * slice of a fused qkv planes tensor is read in place) for rsvld_attention, and its fp16 output returns as planes (exact).
+ * Replaces xformers.ops.memory_efficient_attention at sgm/modules/attention.py:357-359 and the einsum + softmax of
+ * models/sr3_model/sr3_modules/unet.py:133-141 when every other product of the network runs in the split precision. */
+int rsvld_planes_to_f16(const void* planes, int64_t ld, int64_t plane_stride, void* out_f16, int64_t out_ld, int64_t rows, int C, void* stream);
+int rsvld_f16_to_planes(const void* x_f16, int64_t ld, void* planes, int64_t rows, int C, void* stream);
 /* fp32 K-major weights [Cout][taps][Ctot] -> bf16 triples [Cout][taps][W_hi(Ctot) | W_lo(Ctot) | W_hi(Ctot)] */
 int rsvld_split_pack_weights(const float* w, void* w3, int64_t Cout, int taps, int Ctot, void* stream);
 /* planes [rows][lo(C) | hi(C)] (row stride ld elements, ld >= 2C) -> the TRANSPOSED triple [C][V_hi^T(rows_p) | V_lo^T(rows_p) | V_hi^T(rows_p)]

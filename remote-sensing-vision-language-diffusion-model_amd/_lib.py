@@ -98,6 +98,8 @@ SIGNATURES = {
     "rsvld_nchw_f32_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "rsvld_split_planes": (_i, [_vp, _vp, _i64, _i, _vp]),
     "rsvld_merge_planes": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "rsvld_planes_to_f16": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _vp]),
+    "rsvld_f16_to_planes": (_i, [_vp, _i64, _vp, _i64, _i, _vp]),
     "rsvld_split_pack_weights": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "rsvld_planes_transpose_triple": (_i, [_vp, _vp, _i64, _i64, _i, _i64, _vp]),
     "rsvld_planes_to_triple": (_i, [_vp, _vp, _i64, _i64, _i, _i64, _vp]),

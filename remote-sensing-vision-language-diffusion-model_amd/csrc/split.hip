@@ -59,6 +59,37 @@ __global__ __launch_bounds__(256) void merge_planes_kernel(const bf16* __restric
     }
 }
 
+// planes (rows of lo | hi, the two planes `ps` elements apart, rows `ld` elements apart: a channel slice of a wider planes tensor
+// is fine) -> fp16 [rows][C] (row stride old): the operands of the 16-bit attention kernels in the "split, attention in fp16" mode
+__global__ __launch_bounds__(256) void planes_to_f16_kernel(const bf16* __restrict__ y, f16* __restrict__ o, int64_t items, int C8, int64_t ld,
+                                                            int64_t ps, int64_t old) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        float l[8], h[8];
+        unpack8<bf16>(*(const u32x4*)(y + row * ld + c), l);
+        unpack8<bf16>(*(const u32x4*)(y + row * ld + ps + c), h);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] += l[e];
+        *(u32x4*)(o + row * old + c) = pack8<f16>(h);
+    }
+}
+
+// fp16 [rows][C] (row stride ld) -> planes [rows][lo(C) | hi(C)]: exact (11 significant bits fit hi + lo)
+__global__ __launch_bounds__(256) void f16_to_planes_kernel(const f16* __restrict__ x, bf16* __restrict__ y, int64_t items, int C8, int64_t ld) {
+    const int C = C8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        float f[8];
+        unpack8<f16>(*(const u32x4*)(x + row * ld + c), f);
+        u32x4 lo, hi;
+        split8v(f, lo, hi);
+        *(u32x4*)(y + row * (2 * (int64_t)C) + c) = lo;
+        *(u32x4*)(y + row * (2 * (int64_t)C) + C + c) = hi;
+    }
+}
+
 // w [R][Ctot] fp32 (R = Cout * taps) -> [R][hi | lo | hi]
 __global__ __launch_bounds__(256) void split_pack_weights_kernel(const float* __restrict__ w, bf16* __restrict__ o, int64_t items, int C8) {
     const int C = C8 * 8;
@@ -1082,6 +1113,21 @@ extern "C" int rsvld_merge_planes(const void* planes, float* x, int64_t rows, in
     if (!x || !planes || rows < 1 || C < 8 || C % 8) return RSVLD_EINVAL;
     const int64_t items = rows * (C / 8);
     hipLaunchKernelGGL(merge_planes_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, (const bf16*)planes, x, items, C / 8);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_planes_to_f16(const void* planes, int64_t ld, int64_t plane_stride, void* out, int64_t out_ld, int64_t rows, int C, void* stream) {
+    if (!planes || !out || rows < 1 || C < 8 || C % 8 || ld % 8 || plane_stride % 8 || out_ld % 8 || out_ld < C) return RSVLD_EINVAL;
+    const int64_t items = rows * (C / 8);
+    hipLaunchKernelGGL(planes_to_f16_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, (const bf16*)planes, (f16*)out, items, C / 8,
+                       ld, plane_stride, out_ld);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_f16_to_planes(const void* x, int64_t ld, void* planes, int64_t rows, int C, void* stream) {
+    if (!x || !planes || rows < 1 || C < 8 || C % 8 || ld % 8 || ld < C) return RSVLD_EINVAL;
+    const int64_t items = rows * (C / 8);
+    hipLaunchKernelGGL(f16_to_planes_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (bf16*)planes, items, C / 8, ld);
     return rsvld_check_launch();
 }
 

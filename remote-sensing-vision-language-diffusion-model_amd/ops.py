@@ -266,6 +266,9 @@ class PackedConv:
         self.kh, self.kw, self.geglu = kh, kw, geglu
 
 
+_EXP_W16 = {"f16": torch.float16, "bf16": torch.bfloat16}.get(os.environ.get("RSVLD_EXP_W16", ""))   # measurement only
+
+
 def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
     """fp32 ``[Cout, Cin, KH, KW]`` (or Linear ``[Cout, Cin]``) -> PackedConv on ``device``.
 
@@ -277,6 +280,8 @@ def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
     # (the re-layout runs where the master weights live: on the device for a loaded network -- no 15 GB round trip over PCIe and no
     #  host-side permute of 3.9 B values when a precision is switched -- on the host for weights that are still there)
     w = weight.detach().to(torch.float32)
+    if dtype == torch.float32 and _EXP_W16 is not None:   # precision experiment (tools/tolerance_check.py --w16): weights rounded to 16 bits
+        w = w.to(_EXP_W16).to(torch.float32)
     if w.dim() == 2:
         w = w[:, :, None, None]
     cout, cin, kh, kw = w.shape
@@ -812,7 +817,47 @@ def _split_gemm(xt, w3, out, M, K, N, out_f32, name):
             lambda: L.check(L.load().rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
 
 
+# How the split mode runs its attentions.  "f16" (default): the operands leave the planes as fp16 and the 16-BIT attention kernels run
+# (attn_d64c / attn_d512b at 1 100-1 240 TFLOP/s instead of the three-MFMA kernels at 400-440 effective) -- every other product of the
+# network stays in the split precision.  Measured against the reference's CPU runs after 50 + 50 steps: see DESIGN.md (the attention
+# operands are the one place where 11 significant bits are enough: rounding ONLY them costs 4e-5 in Stage 1 and 2.5e-4 in Stage 2 on the
+# CPU restatement, where rounding the weights costs 2e-3 and every activation 3e-3).  "split": the fused split attention kernels.
+SPLIT_ATTN = os.environ.get("RSVLD_SPLIT_ATTN", "f16")
+
+
+def _planes_to_f16(x):
+    """Planes / fp32 ``[B, N, C]`` (channel slices of a fused planes tensor are read in place) -> contiguous fp16 ``[B, N, C]``."""
+    if not isinstance(x, Planes):
+        return x.to(torch.float16)
+    t = x.t                                             # [B, N, 2, C]
+    B, N, _, C = t.shape
+    if t.stride(3) != 1 or t.stride(0) != N * t.stride(1):
+        t = t.contiguous()
+    out = torch.empty((B, N, C), device=t.device, dtype=torch.float16)
+    _launch("planes_to_f16", 0.0, 6.0 * B * N * C, lambda: L.check(L.load().rsvld_planes_to_f16(
+        _ptr(t), t.stride(1), t.stride(2), _ptr(out), C, B * N, C, _stream()), "rsvld_planes_to_f16"))
+    return out
+
+
+def _f16_to_planes(x):
+    """contiguous fp16 ``[..., C]`` -> Planes (exact)."""
+    C = x.shape[-1]
+    t = torch.empty(tuple(x.shape[:-1]) + (2, C), device=x.device, dtype=torch.bfloat16)
+    _launch("f16_to_planes", 0.0, 6.0 * x.numel(), lambda: L.check(L.load().rsvld_f16_to_planes(
+        _ptr(x), C, _ptr(t), x.numel() // C, C, _stream()), "rsvld_f16_to_planes"))
+    return Planes(t)
+
+
 def _attention_split(q, k, v, heads, scale):
+    if SPLIT_ATTN == "f16" and q.shape[-1] % 8 == 0:
+        shared = k is v
+        q16, k16 = _planes_to_f16(q), _planes_to_f16(k)
+        v16 = k16 if shared else _planes_to_f16(v)
+        return _f16_to_planes(attention(q16, k16, v16, heads, scale))
+    return _attention_split_kernels(q, k, v, heads, scale)
+
+
+def _attention_split_kernels(q, k, v, heads, scale):
     """Attention in the split precision -> ``Planes [B, Nq, heads*D]`` (its consumer is always a projection).
     D = 64: the fused flash kernel on planes (rsvld_attention_split_d64).  Other head sizes (single-head d = 512 of SR3 and the
     VAE): two split GEMMs around a row softmax per block of query rows -- S = Q K^T (fp32) -> P = softmax(scale S) (planes) ->

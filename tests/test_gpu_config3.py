@@ -141,15 +141,23 @@ def test_config3_stage2_latent512_one_guided_call(cuda, full_model):
         inp = guider.prepare_inputs(xt, sigma, c, uc)
         return guider(m.denoiser(m.model, *inp, control_scale=1.0, fbcache_mode="none", partial_info=None), sigma).float().cpu()
 
+    from rsvld_amd import ops
     x16 = call()
     try:
         m.set_precision("bf16", "fp32")
         x32 = call()
         m.set_precision("bf16", "split")
-        xsp = call()
+        xsp = call()                                  # the mode as shipped: attention operands in fp16
+        keep, ops.SPLIT_ATTN = ops.SPLIT_ATTN, "split"
+        try:
+            xsf = call()                              # its attentions in the split kernels too
+        finally:
+            ops.SPLIT_ATTN = keep
     finally:
         m.set_precision("bf16", "fp16")
     mx, mn = _rel(x16, x32, "configs[3] Stage 2 at latent 512: guided x0, fp16 vs fp32 family")
     assert mx < 7e-3 and mn < 1e-3          # measured 3.4e-3 / 4.7e-4 (latent 64: 3.8e-3 / 6.5e-4, test_gpu_configs.py)
-    mx, mn = _rel(xsp, x32, "configs[3] Stage 2 at latent 512: guided x0, split operands vs fp32 family")
+    mx, mn = _rel(xsf, x32, "configs[3] Stage 2 at latent 512: guided x0, split operands (attention too) vs fp32 family")
     assert mx < 1e-4 and mn < 1e-5
+    mx, mn = _rel(xsp, x32, "configs[3] Stage 2 at latent 512: guided x0, split operands + fp16 attention vs fp32 family")
+    assert mx < 4e-4 and mn < 6e-5          # measured 1.4e-4 / 2.2e-5

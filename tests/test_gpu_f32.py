@@ -24,6 +24,17 @@ REL_SPLIT = 1e-4
 MODES = ["fp32", "split"]
 
 
+@pytest.fixture(autouse=True)
+def _split_attention_kernels():
+    """Kernel-level bounds: the split mode's attentions run the split kernels here (ops.SPLIT_ATTN = "split"), not the mode's default
+    composition with the 16-bit attention kernels (tests/test_gpu_split.py::test_attention_split_mode_f16_composition)."""
+    from rsvld_amd import ops
+    keep, ops.SPLIT_ATTN = ops.SPLIT_ATTN, "split"
+    yield
+    ops.SPLIT_ATTN = keep
+
+
+
 def _cmp(got, want, rel, what):
     want = want.float() if torch.is_tensor(want) else torch.tensor(want).float()
     got = got.float().cpu()

@@ -14,6 +14,16 @@ pytestmark = pytest.mark.gpu
 REL = 1e-4
 
 
+@pytest.fixture(autouse=True)
+def _split_attention_kernels():
+    """The kernel-level bounds of this file are those of the split attention KERNELS: run them (ops.SPLIT_ATTN = "split"); the default
+    composition of the mode -- attention operands to fp16, the 16-bit attention kernels -- has its own test at the bottom."""
+    from rsvld_amd import ops
+    keep, ops.SPLIT_ATTN = ops.SPLIT_ATTN, "split"
+    yield
+    ops.SPLIT_ATTN = keep
+
+
 def _cmp(got, want, rel, what):
     got = got.double().cpu()
     want = want.double()
@@ -342,3 +352,38 @@ def test_attention_split_d64_pingpong_vs_four_wave(cuda, B, heads, Nq, Nk):
     rows = torch.randint(0, Nq, (64,), generator=torch.Generator().manual_seed(1))
     want = _attn_ref(qkv[:1, rows, :HD].cpu(), qkv[:1, :Nk, HD:2 * HD].cpu(), qkv[:1, :Nk, 2 * HD:].cpu(), heads, 0.125)
     _cmp(got.f32()[:1, rows.to(cuda)], want, REL, "  sampled rows vs fp64")
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,D,shared", [(2, 5, 1024, 1024, 64, False), (1, 20, 300, 77, 64, False), (1, 1, 2304, 2304, 512, True),
+                                                    (1, 1, 1000, 1000, 512, False)])
+def test_attention_split_mode_f16_composition(cuda, B, heads, Nq, Nk, D, shared):
+    """ops.SPLIT_ATTN = "f16" (the mode's default): q | k | v leave the planes as fp16 (rsvld_planes_to_f16, channel slices of a fused
+    planes tensor read in place), the 16-bit attention kernels run, the fp16 result returns as planes (rsvld_f16_to_planes, exact).
+    Against fp64 on the host at the 16-bit kernels' tolerance, and against the same kernels called on fp16(fp32) operands."""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(Nq + D)
+    HD = heads * D
+    q = torch.randn(B, Nq, HD, generator=g)
+    k = torch.randn(B, Nk, HD, generator=g)
+    v = k if shared else torch.randn(B, Nk, HD, generator=g)
+    want = _attn_ref(q, k, v, heads, D ** -0.5)
+    if Nq == Nk and not shared:
+        qkv = ops.to_planes(torch.cat([q, k, v], -1).to(cuda))
+        qp, kp, vp = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
+    else:
+        qp, kp = ops.to_planes(q.to(cuda)), ops.to_planes(k.to(cuda))
+        vp = kp if shared else ops.to_planes(v.to(cuda))
+    ops.SPLIT_ATTN = "f16"
+    with ops.f32_split(True):
+        got = ops.attention(qp, kp, vp, heads=heads, scale=D ** -0.5)
+    assert isinstance(got, ops.Planes) and got.shape == (B, Nq, HD)
+    _cmp(got.f32(), want, 4e-3, f"split mode, attention in fp16: B{B} h{heads} {Nq}x{Nk} d{D}")
+    q16, k16 = q.to(cuda).half(), k.to(cuda).half()
+    ref16 = ops.attention(q16, k16, k16 if shared else v.to(cuda).half(), heads=heads, scale=D ** -0.5)
+    # (not bit-identical: fp16(bf16 hi + bf16 lo) rounds the 16 kept bits of an fp32 value, fp16(fp32) all 24 -- a different fp16
+    #  neighbour where the kept bits sit on a tie)
+    _cmp(got.f32(), ref16.float().cpu(), 2e-3, "  against the same kernels on fp16(fp32) operands")
+    # the conversions alone: planes -> fp16 -> planes is the identity on fp16-representable values
+    x16 = torch.randn(3, 70, 136, generator=g).half()
+    back = ops._f16_to_planes(ops._planes_to_f16(ops.to_planes(x16.float().to(cuda))))
+    assert torch.equal(back.f32().cpu(), x16.float())

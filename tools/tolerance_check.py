@@ -76,6 +76,8 @@ def errors_after_50_steps(dev, sr3_prec, ae, diff):
 if __name__ == "__main__":
     import json
     dev = torch.device("cuda:0")
-    for name, (s1, ae, df) in {"shipped": ("fp16", "bf16", "fp16"), "vae_split": ("fp16", "split", "fp16"),
-                               "split": ("split", "split", "split")}.items():
+    modes = {"shipped": ("fp16", "bf16", "fp16"), "vae_split": ("fp16", "split", "fp16"), "split": ("split", "split", "split")}
+    if "--only" in sys.argv:
+        modes = {k: v for k, v in modes.items() if k in sys.argv[sys.argv.index("--only") + 1].split(",")}
+    for name, (s1, ae, df) in modes.items():
         print(name, json.dumps(errors_after_50_steps(dev, s1, ae, df)))
