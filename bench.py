@@ -512,7 +512,8 @@ def bench_headline(args, dev, rank, world):
         del lq
 
     # ---- the precision that meets north_star's 1e-3: both stages in the split-operand mode (bf16 hi + lo planes, three MFMAs per
-    # product, fp32 everywhere else), timed at the same shapes in the same run, with its measured distance from the reference's CPU
+    # convolution / Linear product, fp32 tensors; the attention operands in fp16 through the 16-bit attention kernels unless
+    # RSVLD_SPLIT_ATTN=split), timed at the same shapes in the same run, with its measured distance from the reference's CPU
     # path after 50 + 50 steps (tools/tolerance_check.py against the committed reference-generated goldens)
     tol = None
     if rank == 0 and world == 1 and not full and PRECISION == "default" and not args.no_extras:
@@ -526,7 +527,9 @@ def bench_headline(args, dev, rank, world):
             ta = pht.acc
             tfx = sum(v for k, v in ta.items() if k not in ("s1_loop", "edm_sampler_loop"))
             t1, t2 = ta["s1_loop"] / 2, ta["edm_sampler_loop"] / 2
-            tol = {"dtype": "f32 tensors; matrix operands bf16 hi + lo planes, three MFMAs per product, fp32 accumulation",
+            tol = {"dtype": "f32 tensors; convolution / Linear operands bf16 hi + lo planes, three MFMAs per product, fp32 accumulation; "
+                            + ("attention operands fp16 (the 16-bit attention kernels)" if ops.SPLIT_ATTN == "f16" else "attention in the split kernels too"),
+                   "attention": ops.SPLIT_ATTN,
                    "t_s1_iter_ms": round(t1 * 1e3, 1), "t_s2_iter_ms": round(t2 * 1e3, 1), "t_fixed_ms": round(tfx * 1e3, 1),
                    "seconds_per_image": round(T * t1 + T * t2 + tfx, 2), "iterations_timed_per_stage": 2,
                    "x_shipped_time": round((T * t1 + T * t2 + tfx) / (T * it1 + T * it2 + fx), 2),
@@ -553,7 +556,8 @@ def bench_headline(args, dev, rank, world):
             "metric": METRIC if is_metric_cfg else f"two-stage SR images/sec @{T} steps, {args.lr_side}px x{args.scale} (secondary workload)",
             "value": round(value, 6), "unit": "img/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "split": "f32 tensors, bf16 hi+lo split operands (3 MFMAs per product)",
+            "dtype": {"fp32": "f32", "split": "f32 tensors, bf16 hi+lo split operands (3 MFMAs per product)" +
+                                              (", attention operands f16" if ops.SPLIT_ATTN == "f16" else ""),
                       "vae-split": "f16 (UNets, fp32 accumulate); VAE: f32 tensors, bf16 hi+lo split operands"}.get(
                 PRECISION, "f16 (UNets, fp32 accumulate), bf16 (VAE)"), "data": "synthetic",
             "config": {

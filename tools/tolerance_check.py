@@ -76,8 +76,17 @@ def errors_after_50_steps(dev, sr3_prec, ae, diff):
 if __name__ == "__main__":
     import json
     dev = torch.device("cuda:0")
-    modes = {"shipped": ("fp16", "bf16", "fp16"), "vae_split": ("fp16", "split", "fp16"), "split": ("split", "split", "split")}
+    from rsvld_amd import ops
+    # split = the mode as shipped (ops.SPLIT_ATTN = "f16": attention operands in fp16); split_full = its attentions in the split kernels too
+    modes = {"shipped": ("fp16", "bf16", "fp16"), "vae_split": ("fp16", "split", "fp16"), "split": ("split", "split", "split"),
+             "split_full": ("split", "split", "split")}
     if "--only" in sys.argv:
         modes = {k: v for k, v in modes.items() if k in sys.argv[sys.argv.index("--only") + 1].split(",")}
     for name, (s1, ae, df) in modes.items():
-        print(name, json.dumps(errors_after_50_steps(dev, s1, ae, df)))
+        keep = ops.SPLIT_ATTN
+        if name == "split_full":
+            ops.SPLIT_ATTN = "split"
+        try:
+            print(name, json.dumps(errors_after_50_steps(dev, s1, ae, df)))
+        finally:
+            ops.SPLIT_ATTN = keep
