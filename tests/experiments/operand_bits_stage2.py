@@ -37,6 +37,23 @@ if mode in ("in16", "in16_lin", "in16_conv"):
         O.conv = lambda sd, p, x, **k: _conv(sd, p, r16(x), **k)
     if mode in ("in16", "in16_lin"):
         O.lin = lambda sd, p, x: _lin(sd, p, r16(x))
+if mode.startswith("lin:"):
+    # attention in fp16 + the input of the Linear layers whose parameter path contains one of the given substrings (comma-separated)
+    def attention_core(q, k, v, heads):
+        B, N, Cq = q.shape; d = Cq // heads
+        q, k, v = (r16(t).view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+        a = r16(torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1))
+        return r16((a @ v).transpose(1, 2).reshape(B, N, Cq))
+    O.attention_core = attention_core
+    keys = mode[4:].split(",")
+    _lin = O.lin
+    hits = set()
+    def lin(sd, p, x):
+        if any(k in p for k in keys):
+            hits.add(p.split(".")[-2] + "." + p.split(".")[-1] if p.split(".")[-1].isdigit() else p.split(".")[-1])
+            return _lin(sd, p, r16(x))
+        return _lin(sd, p, x)
+    O.lin = lin
 if mode == "all":
     for name in ("gn", "conv", "lin", "layer_norm"):
         f = getattr(O, name)
