@@ -37,3 +37,23 @@ def test_conv_desc_matches_header_layout():
         for nm in decl.split(","):
             fields.append(nm.strip().split()[-1].lstrip("*"))
     assert fields == [f[0] for f in _lib.ConvDesc._fields_]
+
+
+def test_constants_match_header():
+    """The dtype / activation / tune constants of the ctypes layer are the header's #defines (a flag added on one side only would
+    silently select another kernel)."""
+    from rsvld_amd import _lib
+    src = open(os.path.join(ROOT, "include", "rsvld_hip.h")).read()
+    defs = {}
+    for name, expr in re.findall(r"^#define\s+(RSVLD_[A-Z0-9_]+)\s+(\(?-?[0-9]+(?:\s*<<\s*[0-9]+)?\)?)", src, flags=re.M):
+        defs[name] = eval(expr)                      # integer literals and shifts only (the regular expression admits nothing else)
+    want = {"RSVLD_F16": _lib.F16, "RSVLD_BF16": _lib.BF16, "RSVLD_F32": _lib.F32, "RSVLD_SPLIT": _lib.SPLIT,
+            "RSVLD_ACT_NONE": _lib.ACT_NONE, "RSVLD_ACT_SILU": _lib.ACT_SILU, "RSVLD_ACT_GEGLU": _lib.ACT_GEGLU,
+            "RSVLD_TUNE_STAGES_SHIFT": _lib.TUNE_STAGES_SHIFT, "RSVLD_TUNE_NO_KSPLIT": _lib.TUNE_NO_KSPLIT,
+            "RSVLD_TUNE_REG_STAGING": _lib.TUNE_REG_STAGING, "RSVLD_TUNE_HALO_NW4": _lib.TUNE_HALO_NW4,
+            "RSVLD_TUNE_HALO_NW8": _lib.TUNE_HALO_NW8, "RSVLD_TUNE_NO_GEMM256": _lib.TUNE_NO_GEMM256,
+            "RSVLD_TUNE_GEMM_ONE_TILE": _lib.TUNE_GEMM_ONE_TILE, "RSVLD_TUNE_F32_SPLIT": _lib.TUNE_F32_SPLIT}
+    for k, v in want.items():
+        assert defs.get(k) == v, (k, defs.get(k), v)
+    flags = [v for k, v in defs.items() if k.startswith("RSVLD_TUNE_") and k not in ("RSVLD_TUNE_TILE_MASK", "RSVLD_TUNE_STAGES_SHIFT")]
+    assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 and f > 63 for f in flags), "tune flags must be distinct single bits above the tile / stage fields"
