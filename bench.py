@@ -528,7 +528,7 @@ def bench_headline(args, dev, rank, world):
             tfx = sum(v for k, v in ta.items() if k not in ("s1_loop", "edm_sampler_loop"))
             t1, t2 = ta["s1_loop"] / 2, ta["edm_sampler_loop"] / 2
             tol = {"dtype": "f32 tensors; convolution / Linear operands bf16 hi + lo planes, three MFMAs per product, fp32 accumulation; "
-                            + ("attention operands fp16 (the 16-bit attention kernels)" if ops.SPLIT_ATTN == "f16" else "attention in the split kernels too"),
+                            + ("attention operands of the UNets / SR3 fp16 (the 16-bit attention kernels)" if ops.SPLIT_ATTN == "f16" else "attention in the split kernels too"),
                    "attention": ops.SPLIT_ATTN,
                    "t_s1_iter_ms": round(t1 * 1e3, 1), "t_s2_iter_ms": round(t2 * 1e3, 1), "t_fixed_ms": round(tfx * 1e3, 1),
                    "seconds_per_image": round(T * t1 + T * t2 + tfx, 2), "iterations_timed_per_stage": 2,
