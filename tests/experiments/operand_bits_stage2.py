@@ -54,6 +54,19 @@ if mode.startswith("lin:"):
             return _lin(sd, p, r16(x))
         return _lin(sd, p, x)
     O.lin = lin
+if mode in ("attn_self", "attn_cross"):
+    # fp16 operands only for the self-attentions (keys = the tokens themselves) or only for the attentions over another sequence
+    # (the 77 text tokens; ZeroCrossAttn's control tokens)
+    _core = O.attention_core
+    def attention_core(q, k, v, heads):
+        is_self = q.shape[1] == k.shape[1]
+        if is_self != (mode == "attn_self"):
+            return _core(q, k, v, heads)
+        B, N, Cq = q.shape; d = Cq // heads
+        q, k, v = (r16(t).view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+        a = r16(torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1))
+        return r16((a @ v).transpose(1, 2).reshape(B, N, Cq))
+    O.attention_core = attention_core
 if mode == "all":
     for name in ("gn", "conv", "lin", "layer_norm"):
         f = getattr(O, name)
