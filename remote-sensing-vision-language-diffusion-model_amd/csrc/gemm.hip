@@ -17,6 +17,12 @@
 // The MFMA A operand is the weight tile, the B operand the activation tile: a lane owns one output row (token) and,
 // per accumulator quad, four consecutive output channels (8-byte stores; GEGLU pairs are adjacent channels).
 //
+// PERSIST instantiations (round 4; the 16-bit layers with K >= 128, the library's choice unless RSVLD_TUNE_GEMM_ONE_TILE): one workgroup
+// per CU walks its tiles (2-D tile order per XCD); the next tile's first K tiles and bias row are requested before the epilogue, the
+// epilogue transposes per wave through a private 4 KiB LDS buffer without a workgroup barrier, the bias is the C operand of the
+// tile's first MFMAs; one instantiation per epilogue variant.  Where a tile's time went before and after: tools/gemm_stamps.py
+// (-DG_STAMP=1), profiles/r04_gemm_stamps*.txt; the comment at the head of the PERSIST block below.
+//
 // SPLIT instantiation (round 4; dtype RSVLD_SPLIT): the split-operand precision on THIS tiling.  An fp32 activation x is stored as two
 // bf16 planes per row, [lo(K) | hi(K)] with hi = bf16(x), lo = bf16(x - hi); a weight row as the triple [W_hi(K) | W_lo(K) | W_hi(K)].
 // The product x W^T = x_lo W_hi + x_hi W_lo + x_hi W_hi (+ the dropped 2^-16 term) is then ONE bf16 GEMM over the concatenated
