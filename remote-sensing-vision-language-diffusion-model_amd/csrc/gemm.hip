@@ -252,16 +252,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma_piece(kt, j);
     };
-    // the same pieces through the builtin: hipcc SEES them (its vmcnt bookkeeping counts them), for the prefetch in front of an
-    // epilogue that waits for compiler-visible residual loads
-    auto dma_tile_visible = [&](int kt) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            char* st = smem + (kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024;
-            const char* src = (j & 1) ? Wb + kt * 64 : Xb + kt * 64;
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + ((j & 1) ? wvo[j >> 1] : xvo[j >> 1])), (lptr_t)st, 16, 0, 0);
-        }
-    };
 
     f32x16 acc[2][4];   // [n tile][m tile]
     if constexpr (!PERSIST) {
