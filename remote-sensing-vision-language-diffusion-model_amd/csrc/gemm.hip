@@ -55,7 +55,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_ABL
 #define G_ABL 0   // diagnostic builds (results WRONG, timing only): 1 no global stores / residual loads, 2 no epilogue, 4 three K steps,
-                  // 8 the LDS-DMA source cycles over four K tiles (operands L2-resident: the K loop without memory latency)
+                  // 8 the LDS-DMA source cycles over four K tiles (operands L2-resident: the K loop without memory latency),
+                  // 16 no LDS-DMA pieces in the steady-state multiply slots beyond K tile 5 (the K loop without their issue cost; waits pass at once)
 #endif
 // G_ONEBAR = 1 (experiment, round 3): ONE barrier per K tile instead of two (see the loop).  Correct (kernel tests green) and within
 // +-1 % of the two-barrier form on all nine headline shapes at 20 repetitions each (profiles/r03_gemm_onebar_ab.txt): the mid-tile
@@ -75,6 +76,16 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #endif                // so that the CUs' output bursts stop coinciding; 0 = off
 #ifndef G_ORDER2D
 #define G_ORDER2D 1   // tile order inside an XCD's run: 1 = blocks of 8 x 4 tiles (see the index computation), 0 = m fastest (rounds 2-3)
+#endif
+#ifndef G_DMA_IN_READ
+#define G_DMA_IN_READ 0   // experiment (round 4), persistent form: the LDS-DMA pieces of tile kt + 3 in the READ slot of tile kt (1) instead of between the
+                          // MFMAs of its multiply slot (0).  Correct (kernel tests green) and level with 0 on all nine headline shapes: the pieces' issue
+                          // (~130 cycles each, 4 per wave and K tile) is what a slot takes in EITHER place -- without them the K loop runs at the matrix
+                          // pipe's rate (-DG_ABL=16: 31.3 -> 26.6 us per tile at K = 1 280 = 1 026 cycles per K tile), a half tile's slots with 8 MFMAs
+                          // and 3 pieces take as long as a whole tile's with 16 and 4.  profiles/r04_gemm_dma_issue.txt.  Off.
+#endif
+#ifndef G_HALF_TILES
+#define G_HALF_TILES 1    // persistent form: the last partial round of an XCD's run as 128-row half tiles (see the tile enumeration); 0 = whole tiles
 #endif
 #ifndef G_GELU_PACKED
 #define G_GELU_PACKED 1   // persistent GEGLU epilogue: the pairwise GELU in packed fp32 arithmetic (gelu_erf2_f); 0 = the scalar form
@@ -119,7 +130,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // ---- tiles.  XCD-aware order: each XCD (= linear workgroup id mod 8) walks a contiguous run of the tile sequence.  One tile per
     // workgroup (grid = the tile grid), or PERSIST: one workgroup per CU, workgroup c of an XCD takes tiles c, c + step, ... of the run.
     const int nmt = (p.M + 255) >> 8, nnt = (p.N + 255) >> 8;
+    // PERSIST, the last round of an XCD's run: when it holds rem <= half as many tiles as the XCD has workgroups, each of them is cut
+    // into two 128-row HALF tiles for two workgroups (640 tiles on 256 CUs: 2.5 rounds instead of 3; 1 920 tiles: 7.5 instead of 8).
     int t_cur, t_end, t_step;
+    int n_full = 1, t_half = -1, h_half = -1;   // this workgroup: n_full whole tiles t_cur, t_cur + t_step, ..., then half h_half of tile t_half
     {
         const int ntiles = nmt * nnt;
         const int lid = PERSIST ? (int)blockIdx.x : (int)(blockIdx.x + blockIdx.y * gridDim.x);
@@ -128,7 +142,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         t_cur = ts + (lid >> 3);
         t_end = PERSIST ? ts + q + (xcd < r ? 1 : 0) : t_cur + 1;
         t_step = PERSIST ? ((int)gridDim.x - xcd + 7) >> 3 : 1;
-        if (PERSIST && t_cur >= t_end) return;
+        if constexpr (PERSIST) {
+            const int c = lid >> 3, qx = t_end - ts;
+            const int fr = qx / t_step, rem = qx - fr * t_step;
+            const bool halves = G_HALF_TILES && rem > 0 && 2 * rem <= t_step;
+            n_full = fr + ((!halves && c < rem) ? 1 : 0);
+            if (halves && c < 2 * rem) {
+                t_half = ts + fr * t_step + (c >> 1);
+                h_half = c & 1;
+            }
+            if (n_full == 0 && t_half < 0) return;
+        }
     }
     auto tile_of = [&](int t, int& tile_m, int& tile_n) {
 #if G_ORDER2D
@@ -150,6 +174,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         tile_m = t - tile_n * nmt;
 #endif
     };
+    if (PERSIST && t_half >= 0) {   // a lower half that starts beyond M (the last row of tiles holds <= 128 rows) does not exist: its row offsets
+        int tm, tn;                 // relative to the tile's first row would be negative, i.e. huge as the 32-bit unsigned offsets of the LDS-DMA pieces
+        tile_of(t_half, tm, tn);
+        if (tm * 256 + 128 * h_half >= p.M) {
+            t_half = -1;
+            if (n_full == 0) return;
+        }
+    }
     const int nk0 = p.K >> 5;
     const int nk = (G_ABL & 4) ? 3 : (SPLIT ? 3 * nk0 : nk0);   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
     const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 2 : 1);    // activation row: K values, or the planes lo | hi
@@ -196,25 +228,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 for (int e = 0; e < 4; ++e) bC[ni][4 * g + e] = bv[e];
             }
     };
-    auto setup_tile = [&](int t) {
+    // hsel < 0: a whole tile; 0 / 1: its upper / lower 128 rows (a HALF tile: wave w fills X rows 16w .. 16w+15 with ONE piece, xvo[0])
+    auto setup_tile = [&](int t, int hsel = -1) {
         int tile_m, tile_n;
         tile_of(t, tile_m, tile_n);
-        m0 = tile_m * 256;
+        m0 = tile_m * 256 + (hsel > 0 ? 128 : 0);
         n0 = tile_n * 256;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int tq = tid;
             if (PERSIST) asm volatile("" : "+v"(tq));   // (nothing derived from it is hoisted out of the tile loop: see load_bias)
-            const int r = 32 * wave + 16 * i + ((tq & 63) >> 2);
+            const int rw = 32 * wave + 16 * i + ((tq & 63) >> 2);
+            const int rx = hsel < 0 ? rw : 16 * wave + ((tq & 63) >> 2);
             const uint32_t ch = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
             // offsets relative to the TILE's first row (the scalar bases below carry the 64-bit part): 256 rows x row bytes < 2^32
-            xvo[i] = (uint32_t)((int64_t)(min(m0 + r, p.M - 1) - m0) * rowb) + ch;
-            wvo[i] = (uint32_t)((int64_t)(min(n0 + r, p.N - 1) - n0) * rowb_w) + ch;
+            xvo[i] = (uint32_t)((int64_t)(min(m0 + rx, p.M - 1) - m0) * rowb) + ch;
+            wvo[i] = (uint32_t)((int64_t)(min(n0 + rw, p.N - 1) - n0) * rowb_w) + ch;
         }
         Xb = (const char*)p.x + (int64_t)m0 * rowb;
         Wb = (const char*)p.w + (int64_t)n0 * rowb_w;
     };
-    setup_tile(t_cur);
+    if (PERSIST && n_full == 0) setup_tile(t_half, h_half);
+    else setup_tile(t_cur);
 #if G_STAMP
     int stamp_lid = PERSIST ? t_cur : (int)(blockIdx.x + blockIdx.y * gridDim.x);
     unsigned long long stamp_hw;
@@ -308,7 +343,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], (first && ks == 0) ? bC[ni] : acc[ni][mi]);
                 __builtin_amdgcn_sched_barrier(0);   // one piece after every fourth MFMA (hipcc otherwise moves the asm
-                dma_piece(next, 2 * ks + ni);        // statements to the head of the slot, three of them behind the first MFMA)
+                if (!(G_ABL & 16) || next < 6) dma_piece(next, 2 * ks + ni);   // statements to the head of the slot, three of them behind the first MFMA)
                 __builtin_amdgcn_sched_barrier(0);
             }
         __builtin_amdgcn_s_setprio(0);
@@ -325,6 +360,65 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // ---- HALF tiles (PERSIST): 128 rows x 256 columns on the same eight waves: group g owns rows 64 g .. + 64 (two 32-row accumulators
+    // per column block: acc[ni][0..1]), 8 MFMAs per slot and wave, three LDS-DMA pieces per K tile and wave (X: 16 rows, W: 2 x 16)
+    int fbh_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fbh_off[ks] = g_off(grp * 64 + l31, 2 * ks + lh);
+    auto dma_piece_h = [&](int kt, int j) {   // j = 0: the wave's X rows; 1, 3: its W rows as in a whole tile
+        const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + ((j & 1) ? wave * 2048 + 16384 + (j >> 1) * 1024 : wave * 1024));
+        const char* base = (j & 1) ? Wb + kt * 64 : Xb + kt * 64;
+        const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[0];
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
+    };
+    auto dma_tile_h = [&](int kt) {
+        dma_piece_h(kt, 0);
+        dma_piece_h(kt, 1);
+        dma_piece_h(kt, 3);
+    };
+    auto read_tile_h = [&](int kt) {
+        const char* st = smem + (kt & (G_NST - 1)) * G_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) fa[ks][ni] = *(const v8*)(st + fa_off[ks] + ni * 2048);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) fb[ks][mi] = *(const v8*)(st + fbh_off[ks] + mi * 2048);
+        }
+    };
+    auto mma_tile_h = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], acc[ni][mi]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto mma_tile_dma_h = [&](int next, auto FIRST) {
+        constexpr bool first = decltype(FIRST)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], (first && ks == 0) ? bC[ni] : acc[ni][mi]);
+                if (2 * ks + ni != 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_piece_h(next, 2 * ks + ni);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto wait_ahead_h = [&](int ahead) {   // three instructions per K tile
+        if (ahead >= 2) g_wait_vm<6>();
+        else if (ahead == 1) g_wait_vm<3>();
+        else g_wait_vm<0>();
+    };
+
     // ---- prologue: three tiles in flight; the one-tile form keeps the tile's bias row in LDS beside the ring (the
     // epilogue read it from global memory once per accumulator quad: a dependent L2 round trip at the head of every output burst)
     if (!PERSIST && tid < 64) {
@@ -334,9 +428,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         *(f32x4*)(smem + G_RING + tid * 16) = bv;
     }
     if constexpr (PERSIST) dma_bias(n0);
-    dma_tile(0);
-    if (nk > 1) dma_tile(1);
-    if (nk > 2) dma_tile(2);
+    if (PERSIST && n_full == 0) {
+        dma_tile_h(0);
+        dma_tile_h(1);
+        dma_tile_h(2);
+    } else {
+        dma_tile(0);
+        if (nk > 1) dma_tile(1);
+        if (nk > 2) dma_tile(2);
+    }
 
     if constexpr (PERSIST) {
         // ================= PERSIST: one workgroup per CU walks its tiles (host: nk >= 4, 16-bit output) =================
@@ -356,12 +456,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         const int rbase = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);            // block read: + i * 1024 (rows lane/8 + 8 i)
         const int gwbase = l31 * 64 + lh * 4, gx3 = (l31 & 3) << 4;                         // GEGLU: 32 rows x 64 B
         const int grbase = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 2) & 3)) << 4);      // GEGLU read: + i * 1024 (rows lane/4 + 16 i)
-        for (;;) {
-            g_wait_vm<8>();   // own pieces of K tile 0 (tiles 1, 2 and, from the second tile on, the last stores may stay in flight)
+        // One tile: HALF = false: a whole tile; true: a half tile (the helpers with the _h suffix, MI = 2 row blocks per group).
+        // t_next / h_next (< 0: whole) = the tile whose first pieces this tile's epilogue requests; has_next false: none.
+        auto run_tile = [&](auto HALF, const bool has_next, const int t_next, const int h_next) {
+            constexpr bool half = decltype(HALF)::value;
+            constexpr int MI = half ? 2 : 4;
+            // own pieces of K tile 0 (tiles 1, 2 and, from the second tile on, the last stores may stay in flight)
+            if constexpr (half) g_wait_vm<6>();
+            else g_wait_vm<8>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            const int t_next = t_cur + t_step;
-            const bool has_next = t_next < t_end;
 #if G_STAMP
             stamp_lid = t_cur;
             if (threadIdx.x == 0 && stamp_lid < 16384) g_stamp_buf[stamp_lid * 8 + 7] = stamp_hw;
@@ -369,50 +473,122 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             G_STAMP_AT(1);
             const unsigned long long stamp_c0 = __builtin_readcyclecounter();
 #endif
+            auto rd = [&](int kt) { if constexpr (half) read_tile_h(kt); else read_tile(kt); };
+            auto mm = [&]() { if constexpr (half) mma_tile_h(); else mma_tile(-1); };
+            auto mmd = [&](int next, auto FIRST) { if constexpr (half) mma_tile_dma_h(next, FIRST); else mma_tile_dma(next, FIRST); };
+            auto wa = [&](int ahead) { if constexpr (half) wait_ahead_h(ahead); else wait_ahead(ahead); };
+#if G_DMA_IN_READ
+            // The LDS-DMA pieces of K tile kt + 3 are issued in the READ slot of tile kt, behind the fragment reads (their issue -- 60-180
+            // cycles each -- then runs under the LDS latency the reading wave waits for anyway, and the multiply slot is 16 bare MFMAs):
+            // with the pieces between the MFMAs the K loop ran at 83 % of the matrix pipe's rate and at 100 % without them
+            // (-DG_ABL=16, tools/gemm_stamps.py).  The stage of tile kt + 3 held tile kt - 1, whose last fragment reads (group 1's,
+            // in the slot before) returned before the barrier that opened this slot.  Exception: group 0 requests K tile 3 at the head
+            // of its first MULTIPLY slot -- in its first read slot group 1 still fetches its bias rows from that stage.
+            auto dm = [&](int kt) { if constexpr (half) dma_tile_h(kt); else dma_tile(kt); };
+            auto mmf = [&]() {   // K tile 0: the bias rows as C operand of the first k-step
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], ks == 0 ? bC[ni] : acc[ni][mi]);
+                __builtin_amdgcn_s_setprio(0);
+            };
             if (grp == 0) {
-                read_tile(0);
+                rd(0);
                 read_bias();
                 slot_end();
-                mma_tile_dma(3, std::true_type{});
-                g_wait_vm<8>();
+                dm(3);
+                mmf();
+                wa(2);
                 slot_end();
                 for (int kt = 1; kt < nk_main; ++kt) {
-                    read_tile(kt);
+                    rd(kt);
+                    dm(kt + 3);
                     slot_end();
-                    mma_tile_dma(kt + 3, std::false_type{});
-                    g_wait_vm<8>();
+                    mm();
+                    wa(2);
                     slot_end();
                 }
                 for (int kt = nk_main; kt < nk; ++kt) {
-                    read_tile(kt);
+                    rd(kt);
                     slot_end();
-                    mma_tile(-1);
-                    wait_ahead(min(nk - 1, kt + 3) - (kt + 1));
+                    mm();
+                    wa(max(nk - 2 - kt, 0));
+                    slot_end();
+                }
+            } else {
+                read_bias();
+                slot_end();
+                rd(0);
+                dm(3);
+                wa(2);
+                slot_end();
+                mmf();
+                slot_end();
+                for (int kt = 1; kt < nk_main; ++kt) {
+                    rd(kt);
+                    dm(kt + 3);
+                    wa(2);
+                    slot_end();
+                    mm();
+                    slot_end();
+                }
+                for (int kt = nk_main; kt < nk; ++kt) {
+                    rd(kt);
+                    wa(max(nk - 2 - kt, 0));
+                    slot_end();
+                    mm();
+                    if (kt != nk - 1) slot_end();
+                }
+            }
+#else
+            if (grp == 0) {
+                rd(0);
+                read_bias();
+                slot_end();
+                mmd(3, std::true_type{});
+                wa(2);
+                slot_end();
+                for (int kt = 1; kt < nk_main; ++kt) {
+                    rd(kt);
+                    slot_end();
+                    mmd(kt + 3, std::false_type{});
+                    wa(2);
+                    slot_end();
+                }
+                for (int kt = nk_main; kt < nk; ++kt) {
+                    rd(kt);
+                    slot_end();
+                    mm();
+                    wa(min(nk - 1, kt + 3) - (kt + 1));
                     slot_end();
                 }
             } else {
                 read_bias();     // (before group 0's first multiply slot, which requests K tile 3 into the stage that holds the bias rows)
                 slot_end();
-                read_tile(0);
-                g_wait_vm<4>();
+                rd(0);
+                wa(1);
                 slot_end();
-                mma_tile_dma(3, std::true_type{});
+                mmd(3, std::true_type{});
                 slot_end();
                 for (int kt = 1; kt < nk_main; ++kt) {
-                    read_tile(kt);
-                    g_wait_vm<4>();
+                    rd(kt);
+                    wa(1);
                     slot_end();
-                    mma_tile_dma(kt + 3, std::false_type{});
+                    mmd(kt + 3, std::false_type{});
                     slot_end();
                 }
                 for (int kt = nk_main; kt < nk; ++kt) {
-                    read_tile(kt);
-                    wait_ahead(min(nk - 1, kt + 2) - (kt + 1));
+                    rd(kt);
+                    wa(min(nk - 1, kt + 2) - (kt + 1));
                     slot_end();
-                    mma_tile(-1);
+                    mm();
                     if (kt != nk - 1) slot_end();
                 }
             }
+#endif
             G_STAMP_AT(2);
 #if G_STAMP
             if (threadIdx.x == 0 && stamp_lid < 16384) g_stamp_buf[stamp_lid * 8 + 6] = __builtin_readcyclecounter() - stamp_c0;
@@ -431,23 +607,29 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 constexpr bool res = (PV & 8) != 0;
                 // Residual variants: the 16 pieces of a lane in two halves of 8 (the second behind block 1, when 64 accumulator
                 // registers have been released), the next tile's ring pieces behind them: acc + residual + transposed blocks <= 192.
-                u32x4 rv[res ? 16 : 1];
-                auto load_res = [&](int half) {
+                u32x4 rv[res ? 4 * MI : 1];
+                auto load_res = [&](int part) {
                     const int nr = n0e + wn * 64 + (lane & 7) * 8;
 #pragma unroll
-                    for (int c = 8 * half; c < 8 * half + 8; ++c) {
-                        const int m = m0e + grp * 128 + (c >> 2) * 32 + (c & 3) * 8 + (lane >> 3);
+                    for (int c = 2 * MI * part; c < 2 * MI * part + 2 * MI; ++c) {
+                        const int m = m0e + grp * (32 * MI) + (c >> 2) * 32 + (c & 3) * 8 + (lane >> 3);
                         // rows / columns past the end re-read a valid address (never stored)
                         rv[res ? c : 0] = *(const u32x4*)((const T*)p.residual + (int64_t)min(m, p.M - 1) * p.N_out + (nr < p.N_out ? nr : 0));
                     }
                 };
                 auto prefetch_next = [&]() {
                     if (has_next) {
-                        setup_tile(t_next);
+                        setup_tile(t_next, h_next);
                         dma_bias(n0);
-                        dma_tile(0);
-                        dma_tile(1);
-                        dma_tile(2);
+                        if (h_next < 0) {
+                            dma_tile(0);
+                            dma_tile(1);
+                            dma_tile(2);
+                        } else {
+                            dma_tile_h(0);
+                            dma_tile_h(1);
+                            dma_tile_h(2);
+                        }
                     }
                 };
                 if constexpr (res) load_res(0);
@@ -457,10 +639,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 // stores: non-GEGLU lane -> rows lane/8 + 8 i (+ 32 mi), channels 8 (lane % 8) .. + 8 of the wave's 64 (8 rows x 128 B per
                 // instruction); GEGLU lane -> rows lane/4 + 16 i, output channels 8 (lane % 4) .. + 8 of the wave's 32 (16 rows x 64 B)
                 const int nn = act == 2 ? (n0e >> 1) + wn * 32 + (lane & 3) * 8 : n0e + wn * 64 + (lane & 7) * 8;
-                const int r0 = m0e + grp * 128 + (act == 2 ? (lane >> 2) : (lane >> 3));
+                const int r0 = m0e + grp * (32 * MI) + (act == 2 ? (lane >> 2) : (lane >> 3));
                 T* const op = (T*)p.out + (int64_t)r0 * p.N_out + nn;
                 const int64_t rstep = (int64_t)RSTEP * p.N_out;
-                u32x4 o[res ? 16 : NCH];
+                u32x4 o[res ? 4 * MI : NCH];
                 auto store_block = [&](int mi, const u32x4* ob) {
 #pragma unroll
                     for (int i = 0; i < NCH; ++i) {
@@ -480,7 +662,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     }
                 };
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
+                for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -515,7 +697,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     for (int i = 0; i < NCH; ++i) ob[i] = *(const u32x4*)(P + (act == 2 ? grbase : rbase) + i * 1024);
                     if constexpr (!res) {
                         store_block(mi, ob);
-                    } else if (mi == 1) {
+                    } else if (mi == MI / 2 - 1) {
                         load_res(1);
                     }
                 }
@@ -531,9 +713,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     // a full tile takes a branch-free path: in straight-line code hipcc's vmcnt bookkeeping is exact (the residual piece
                     // a store needs, with the younger residual pieces, the 12 ring pieces and the stores issued so far left in flight);
                     // behind the per-row guards of the edge path it falls back to vmcnt(0), i.e. waits for the ring pieces
-                    if (m0e + 256 <= p.M && n0e + 256 <= p.N_out && !(G_ABL & 1)) {
+                    if (m0e + 64 * MI <= p.M && n0e + 256 <= p.N_out && !(G_ABL & 1)) {
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) {
+                        for (int c = 0; c < 4 * MI; ++c) {
                             float f[8], rf[8];
                             unpack8<T>(o[c], f);
                             unpack8<T>(rv[c], rf);
@@ -543,15 +725,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                         }
                     } else {
 #pragma unroll
-                        for (int mi = 0; mi < 4; ++mi) store_block(mi, o + mi * 4);
+                        for (int mi = 0; mi < MI; ++mi) store_block(mi, o + mi * 4);
                     }
                 }
             }
             G_STAMP_AT(4);
             G_STAMP_AT(5);
-            if (!has_next) return;
-            t_cur = t_next;
+        };
+        // this workgroup's list: n_full whole tiles, then (last round of the XCD's run) possibly one half tile
+        for (int i = 0; i < n_full; ++i) {
+            const bool more = i + 1 < n_full;
+            run_tile(std::false_type{}, more || t_half >= 0, more ? t_cur + t_step : t_half, more ? -1 : h_half);
+            t_cur += t_step;
         }
+        if (t_half >= 0) {
+            t_cur = t_half;
+            run_tile(std::true_type{}, false, 0, -1);
+        }
+        return;
     }
 
     if (nk > 2) g_wait_vm<8>();

@@ -212,6 +212,11 @@ GEMM_CASES = [
     (65536, 640, 640, 0, True),     # 768 tiles = three per workgroup, N % 256 = 128, residual (Stage 2, level 2 to_out)
     (16640, 640, 1280, 2, False),   # GEGLU, 65 x 5 tiles, ragged M tile (Stage 2, level 2 feed-forward shape)
     (33024, 320, 768, 1, False),    # 129 x 3 = 387 tiles: runs of 48 / 49 tiles per XCD, SiLU without a residual
+    # ... and its half tiles (the last round of an XCD's run cut into 128-row halves when it holds <= half as many tiles as the XCD has workgroups)
+    (32768, 256, 1280, 0, True),    # 640 tiles = 2.5 rounds: every workgroup ends on a half tile; residual (Stage 2, level 3 to_out shape)
+    (32896, 160, 1280, 2, False),   # 129 x 5 = 645 tiles: 80 / 81 per XCD = two rounds + 16 (halved) / + 17 (whole): both kinds in one launch; GEGLU;
+                                    # the last row of tiles has 128 rows: its lower halves lie beyond M
+    (9216, 192, 2560, 1, True),     # 360 tiles = 45 per XCD: one round + 13 halved tiles (26 of 32 workgroups get a half); SiLU + residual
 ]
 
 
