@@ -77,12 +77,18 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
 #ifndef G_ORDER2D
 #define G_ORDER2D 1   // tile order inside an XCD's run: 1 = blocks of 8 x 4 tiles (see the index computation), 0 = m fastest (rounds 2-3)
 #endif
+#ifndef G_DMA_SPLIT
+#define G_DMA_SPLIT 0     // experiment (round 4), persistent form: activation pieces of tile kt + 3 in the read slot of tile kt, weight pieces between
+                          // the MFMAs of its multiply slot (two and two instead of four in one slot).  Correct, and level with 0: see G_DMA_IN_READ.
+#endif
 #ifndef G_DMA_IN_READ
 #define G_DMA_IN_READ 0   // experiment (round 4), persistent form: the LDS-DMA pieces of tile kt + 3 in the READ slot of tile kt (1) instead of between the
-                          // MFMAs of its multiply slot (0).  Correct (kernel tests green) and level with 0 on all nine headline shapes: the pieces' issue
-                          // (~130 cycles each, 4 per wave and K tile) is what a slot takes in EITHER place -- without them the K loop runs at the matrix
-                          // pipe's rate (-DG_ABL=16: 31.3 -> 26.6 us per tile at K = 1 280 = 1 026 cycles per K tile), a half tile's slots with 8 MFMAs
-                          // and 3 pieces take as long as a whole tile's with 16 and 4.  profiles/r04_gemm_dma_issue.txt.  Off.
+                          // MFMAs of its multiply slot (0).  Correct (kernel tests green) and level with 0 on all nine headline shapes, and so is
+                          // G_DMA_SPLIT (two and two): WHERE the pieces are issued does not matter.  Without them the K loop runs at the matrix pipe's
+                          // rate (-DG_ABL=16: 31.3 -> 26.6 us per tile at K = 1 280 = 1 026 cycles per K tile); a half tile's slots with 8 MFMAs and 3
+                          // pieces take as long as a whole tile's with 16 and 4.  What the pieces cost is LDS time: per K tile the CU reads 96 KiB of
+                          // fragments (<= 256 B/clk) and the pieces write 32 KiB (~64 B/clk): ~900 of the 1 024 cycles its 128 MFMAs take.
+                          // profiles/r04_gemm_dma_issue.txt.  Off.
 #endif
 #ifndef G_HALF_TILES
 #define G_HALF_TILES 1    // persistent form: the last partial round of an XCD's run as 128-row half tiles (see the tile enumeration); 0 = whole tiles
@@ -477,7 +483,83 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             auto mm = [&]() { if constexpr (half) mma_tile_h(); else mma_tile(-1); };
             auto mmd = [&](int next, auto FIRST) { if constexpr (half) mma_tile_dma_h(next, FIRST); else mma_tile_dma(next, FIRST); };
             auto wa = [&](int ahead) { if constexpr (half) wait_ahead_h(ahead); else wait_ahead(ahead); };
-#if G_DMA_IN_READ
+#if G_DMA_SPLIT
+            // The pieces of K tile kt + 3 in BOTH slots of tile kt: the activation pieces behind the fragment reads of the read slot, the
+            // weight pieces between the MFMAs of the multiply slot.  A piece costs its wave ~130 issue cycles: four of them beside 16 MFMAs
+            // (128 issue cycles) or beside 12 fragment reads overrun the 512 cycles the partner's MFMAs take; two and two stay inside.
+            // Exception: group 0's first read slot of a tile issues nothing (group 1 still fetches its bias rows from stage 3): all four
+            // pieces of K tile 3 in its first multiply slot.
+            auto dmx = [&](int kt) {
+                if constexpr (half) dma_piece_h(kt, 0);
+                else { dma_piece(kt, 0); dma_piece(kt, 2); }
+            };
+            auto mmw = [&](int next, auto FIRST, auto ALL) {   // the MFMAs of a tile with the weight pieces (ALL: every piece) of tile `next` between them
+                constexpr bool first = decltype(FIRST)::value, all = decltype(ALL)::value;
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], (first && ks == 0) ? bC[ni] : acc[ni][mi]);
+                        const int j = 2 * ks + ni;
+                        if ((j & 1) || (all && !(half && j == 2))) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (half) dma_piece_h(next, j); else dma_piece(next, j);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                __builtin_amdgcn_s_setprio(0);
+            };
+            constexpr int PX = half ? 1 : 2, PT = half ? 3 : 4;   // activation pieces / all pieces per wave and K tile
+            if (grp == 0) {
+                rd(0);
+                read_bias();
+                slot_end();
+                mmw(3, std::true_type{}, std::true_type{});
+                wa(2);
+                slot_end();
+                for (int kt = 1; kt < nk_main; ++kt) {
+                    rd(kt);
+                    dmx(kt + 3);
+                    slot_end();
+                    mmw(kt + 3, std::false_type{}, std::false_type{});
+                    wa(2);
+                    slot_end();
+                }
+                for (int kt = nk_main; kt < nk; ++kt) {
+                    rd(kt);
+                    slot_end();
+                    mm();
+                    wa(max(nk - 2 - kt, 0));
+                    slot_end();
+                }
+            } else {
+                read_bias();
+                slot_end();
+                rd(0);
+                dmx(3);
+                g_wait_vm<PT + PX>();      // K tile 1 has landed; tile 2 and the activation pieces of tile 3 may stay in flight
+                slot_end();
+                mmw(3, std::true_type{}, std::false_type{});
+                slot_end();
+                for (int kt = 1; kt < nk_main; ++kt) {
+                    rd(kt);
+                    dmx(kt + 3);
+                    g_wait_vm<PT + PX>();
+                    slot_end();
+                    mmw(kt + 3, std::false_type{}, std::false_type{});
+                    slot_end();
+                }
+                for (int kt = nk_main; kt < nk; ++kt) {
+                    rd(kt);
+                    wa(max(nk - 2 - kt, 0));
+                    slot_end();
+                    mm();
+                    if (kt != nk - 1) slot_end();
+                }
+            }
+#elif G_DMA_IN_READ
             // The LDS-DMA pieces of K tile kt + 3 are issued in the READ slot of tile kt, behind the fragment reads (their issue -- 60-180
             // cycles each -- then runs under the LDS latency the reading wave waits for anyway, and the multiply slot is 16 bare MFMAs):
             // with the pieces between the MFMAs the K loop ran at 83 % of the matrix pipe's rate and at 100 % without them
