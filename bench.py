@@ -528,8 +528,8 @@ def bench_headline(args, dev, rank, world):
             tfx = sum(v for k, v in ta.items() if k not in ("s1_loop", "edm_sampler_loop"))
             t1, t2 = ta["s1_loop"] / 2, ta["edm_sampler_loop"] / 2
             tol = {"dtype": "f32 tensors; convolution / Linear operands bf16 hi + lo planes, three MFMAs per product, fp32 accumulation; "
-                            + ("attention operands of the UNets / SR3 fp16 (the 16-bit attention kernels)" if ops.SPLIT_ATTN == "f16" else "attention in the split kernels too"),
-                   "attention": ops.SPLIT_ATTN,
+                            + "fp16 hand-overs per policy",
+                   "policy": ops.UNET_POLICY.describe(),
                    "t_s1_iter_ms": round(t1 * 1e3, 1), "t_s2_iter_ms": round(t2 * 1e3, 1), "t_fixed_ms": round(tfx * 1e3, 1),
                    "seconds_per_image": round(T * t1 + T * t2 + tfx, 2), "iterations_timed_per_stage": 2,
                    "x_shipped_time": round((T * t1 + T * t2 + tfx) / (T * it1 + T * it2 + fx), 2),
@@ -557,7 +557,7 @@ def bench_headline(args, dev, rank, world):
             "value": round(value, 6), "unit": "img/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "split": "f32 tensors, bf16 hi+lo split operands (3 MFMAs per product)" +
-                                              (", attention operands f16" if ops.SPLIT_ATTN == "f16" else ""),
+                                              ", fp16 layer inputs per ops.UNET_POLICY",
                       "vae-split": "f16 (UNets, fp32 accumulate); VAE: f32 tensors, bf16 hi+lo split operands"}.get(
                 PRECISION, "f16 (UNets, fp32 accumulate), bf16 (VAE)"), "data": "synthetic",
             "config": {
@@ -790,6 +790,8 @@ def main():
                          "with every matrix product as three 16-bit MFMAs on hi + lo bf16 operands; secondary measurements only -- the "
                          "metric is quoted on the reference's GPU policy (fp16 UNets, bf16 VAE)")
     ap.add_argument("--no-graph", action="store_true", help="c2: launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--profile-detail", action="store_true", help="append every matrix layer's shape to its group in roofline.by_kernel")
+    ap.add_argument("--dev-env", action="store_true", help="apply the developer A/B switches of the environment (rsvld_amd.devtools.apply_env)")
     ap.add_argument("--pmc-pass", action="store_true", help="c4: one iteration of each stage + the fixed part and nothing "
                                                              "else (the process rocprofv3 --pmc counts)")
     args = ap.parse_args()
@@ -814,7 +816,11 @@ def main():
     if args.workload == "c4" and max(args.steps, args.warmup) > args.ddpm_steps:
         raise SystemExit("--steps / --warmup must not exceed --ddpm-steps on the per-iteration workload")
 
-    from rsvld_amd import parallel
+    from rsvld_amd import devtools, ops, parallel
+    if args.dev_env:
+        devtools.apply_env()
+    if args.profile_detail:
+        ops.PROFILE_DETAIL = True
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

@@ -40,6 +40,7 @@ extern "C" {
 #define RSVLD_BF16 1
 #define RSVLD_F32 2   /* accepted ONLY by the *_f32 entry points at the end of this header */
 #define RSVLD_SPLIT 3 /* split-operand precision on the 16-bit tilings (rsvld_conv_desc.dtype; the *_split entry points below) */
+#define RSVLD_F16W2 4 /* fp16 activations x fp16 weight PAIRS [W_lo | W_hi] (rsvld_conv_desc.dtype; see below): two MFMAs per product */
 
 /* epilogue activations for rsvld_conv2d_nhwc */
 #define RSVLD_ACT_NONE 0
@@ -75,7 +76,7 @@ typedef struct rsvld_conv_desc {
     int32_t KH, KW, stride, pad_t, pad_l, Ho, Wo;
     int32_t upsample;      /* 0 / 1                                                 */
     int32_t dtype;         /* RSVLD_F16 / RSVLD_BF16                                */
-    int32_t out_f32;       /* 1: out is fp32 (Cout <= 32 only)                      */
+    int32_t out_f32;       /* 1: out is fp32 (16-bit dtypes: Cout <= 32 only); 2: RSVLD_SPLIT only, out is fp16 */
     int32_t act;           /* RSVLD_ACT_*                                           */
     float alpha, beta;
     int32_t rowvec_stride; /* elements between rows of rowvec; 0 = Cout                     */
@@ -106,6 +107,13 @@ typedef struct rsvld_conv_desc {
  * per fp32 product, fp32 accumulation.  residual: fp32 [.., Cout_out].  out: fp32 [.., Cout_out] when out_f32 = 1 (the residual
  * stream), bf16 planes [.., lo(Cout_out) | hi(Cout_out)] when out_f32 = 0 (a tensor that only feeds another matrix product; no
  * residual then).  The fused GroupNorm prologue of the halo kernel is not available (rsvld_groupnorm_apply_split writes planes). */
+/* dtype = RSVLD_F16W2 (round 5; accepted by rsvld_conv2d_nhwc and rsvld_conv3x3_halo_nhwc): the layers of the tolerance-compliant
+ * mode whose INPUT may be rounded to fp16 (measured: DESIGN.md section 4) but whose WEIGHTS may not.  x, x2 : fp16 [B,H,W,C];
+ *     w : fp16 [Cout][KH*KW][ W_lo(Cin+Cin2) | W_hi(Cin+Cin2) ]   W_hi = fp16(W), W_lo = fp16(W - W_hi)   (rsvld_pack_weight_pairs)
+ * so that x W = x W_lo + x W_hi is ONE fp16 contraction over 2 (Cin+Cin2) logical channels per tap whose second segment re-reads
+ * the activation: two MFMAs per product instead of RSVLD_SPLIT's three, half the activation bytes, and the fused GroupNorm prologue
+ * of the halo kernel stays available.  residual: fp32.  out: fp32 when out_f32 = 1, fp16 when out_f32 = 0 (no residual then).
+ * RSVLD_SPLIT with out_f32 = 2 writes fp16 as well (q | k | v on their way to the 16-bit attention kernels). */
 int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
 
 /* 3x3 / stride-1 / pad-1 convolution with an LDS-resident input halo patch (each activation byte crosses
@@ -369,6 +377,9 @@ int rsvld_planes_to_f16(const void* planes, int64_t ld, int64_t plane_stride, vo
 int rsvld_f16_to_planes(const void* x_f16, int64_t ld, void* planes, int64_t rows, int C, void* stream);
 /* fp32 K-major weights [Cout][taps][Ctot] -> bf16 triples [Cout][taps][W_hi(Ctot) | W_lo(Ctot) | W_hi(Ctot)] */
 int rsvld_split_pack_weights(const float* w, void* w3, int64_t Cout, int taps, int Ctot, void* stream);
+/* fp32 K-major weights [Cout][taps][Ctot] -> fp16 pairs [Cout][taps][W_lo(Ctot) | W_hi(Ctot)], W_hi = fp16(W), W_lo = fp16(W - W_hi): the
+ * weights of dtype RSVLD_F16W2 (same nn.Conv2d / nn.Linear call sites as rsvld_conv2d_nhwc) */
+int rsvld_pack_weight_pairs(const float* w, void* w2, int64_t Cout, int taps, int Ctot, void* stream);
 /* planes [rows][lo(C) | hi(C)] (row stride ld elements, ld >= 2C) -> the TRANSPOSED triple [C][V_hi^T(rows_p) | V_lo^T(rows_p) | V_hi^T(rows_p)]
  * (rows_p = rows padded with zeros to a multiple of 8): the "weights" of the P V product of an attention run as two split GEMMs */
 int rsvld_planes_transpose_triple(const void* planes, void* w3, int64_t rows, int64_t rows_p, int C, int64_t ld, void* stream);
@@ -388,11 +399,12 @@ int rsvld_groupnorm_stats_f32_fast(const float* x, const float* x2, float* mean_
 int rsvld_groupnorm_scale_shift_from_stats(const float* mean_var, const float* gamma, const float* beta, float* scale_shift,
                                            int B, int C, int groups, float eps, void* stream);
 /* y = act(scale * [x | x2] + shift) [* (1 + mod_scale1p) + mod_shift] from fp32 NHWC inputs; out: planes [B,HW, 2(C1+C2)]
- * (out_f32 = 0) or fp32 [B,HW,C1+C2] (out_f32 = 1).  mod_* fp32 with row stride mod_stride (ZeroSFT, SR_modules.py:100-106). */
+ * (out_f32 = 0), fp32 [B,HW,C1+C2] (out_f32 = 1) or fp16 [B,HW,C1+C2] (out_f32 = 2: the input of an RSVLD_F16W2 layer).
+ * mod_* fp32 with row stride mod_stride (ZeroSFT, SR_modules.py:100-106). */
 int rsvld_groupnorm_apply_split(const float* x, const float* x2, void* out, const float* scale_shift,
                                 const float* mod_scale1p, const float* mod_shift, int mod_stride,
                                 int B, int HW, int C1, int C2, int silu, int out_f32, void* stream);
-/* LayerNorm of fp32 rows -> planes [rows][2C] (out_f32 = 0) or fp32 (out_f32 = 1); C % 8 == 0, C <= 4096 */
+/* LayerNorm of fp32 rows -> planes [rows][2C] (out_f32 = 0), fp32 (out_f32 = 1) or fp16 (out_f32 = 2); C % 8 == 0, C <= 4096 */
 int rsvld_layernorm_split(const float* x, void* out, const float* gamma, const float* beta, int64_t rows, int C, float eps,
                           int out_f32, void* stream);
 /* Flash attention on planes, D = 64 (sgm CrossAttention at sgm/modules/attention.py:357-359 under diffusion_dtype "split"):

@@ -42,7 +42,10 @@ struct HaloArgs {
     int B_plan, tune;       // batch rows the launch plan is made for (B / plan_div); RSVLD_TUNE_*
     // dtype RSVLD_SPLIT (round 4; see gemm.hip): x / x2 are bf16 planes [.., lo(C) | hi(C)], the weights the per-tap triple
     // [W_hi | W_lo | W_hi]; Ctot = 3 Cseg logical channels whose third segment re-reads the hi planes; fp32 residual, fp32 / planes out
-    int split, Cseg;
+    // dtype RSVLD_F16W2 (round 5): x / x2 fp16, the weights the per-tap pair [W_lo | W_hi]; Ctot = 2 Cseg logical channels whose second
+    // segment re-reads the activation (and re-applies the fused GroupNorm: `ab` holds Cseg rows per image); residual and output fp32
+    // (out_f32) or fp16
+    int seg, Cseg;
 };
 
 constexpr int TH = 8, TW = 32, PW = TW + 2, PROWS = (TH + 2) * PW;   // 340 patch pixels
@@ -62,9 +65,10 @@ __device__ __forceinline__ int patch_off(int py, int px, int c) { return (py * P
 
 // logical channel ch0 (start of a 32- or 64-channel chunk) -> source tensor (0: x, 1: x2), channel inside a pixel's row, elements per
 // pixel.  Split: segment 0 = lo planes, segments 1, 2 = hi planes; a pixel's row holds lo | hi.
-template <bool SPLIT>
+template <int SEG>
 __device__ __forceinline__ void halo_src_of(const HaloArgs& p, int ch0, int& which, int& Cs, int& coff) {
-    if (!SPLIT) {
+    if (SEG != 3) {
+        if (SEG == 2 && ch0 >= p.Cseg) ch0 -= p.Cseg;   // the pair form reads the one activation twice
         if (ch0 < p.Cin) { which = 0; Cs = p.Cin; coff = ch0; } else { which = 1; Cs = p.Cin2; coff = ch0 - p.Cin; }
         return;
     }
@@ -78,9 +82,12 @@ __device__ __forceinline__ void halo_src_of(const HaloArgs& p, int ch0, int& whi
 // 16-byte NHWC stores, plus the per-channel (sum, sumsq) partials of every 8x32-pixel sub-tile for the next GroupNorm.
 // NW waves own 64*NW pixels (8 rows of 32 per 4 waves); passes of EPI_ROWS pixels; the staging tile aliases the (dead)
 // operand buffers.
-template <typename T, int BN, int TM, int TN, int NW = 4, bool SPLIT = false>
+template <typename T, int BN, int TM, int TN, int NW = 4, int SEG = 1>
 __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32x16 (&acc)[TN][TM], int tid, int wm, int wn,
                                               int l31, int lh, int x0, int y0, int n0, int img, int tx, int ty) {
+    constexpr bool SPLIT = SEG == 3;
+    // the residual has the output's type: fp32 beside an fp32 / planes output of the multi-segment forms, 16-bit otherwise
+    const bool res32 = SEG > 1 && (SPLIT || p.out_f32);
     constexpr int NT = 64 * NW, PIX = 64 * NW;
     constexpr int EPI_ROWS = BN > 64 ? 128 : 256;
     constexpr int EPI_PASSES = PIX / EPI_ROWS;
@@ -103,7 +110,7 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
         // The residual pieces of this pass are requested BEFORE the staging writes and their barrier, so that the HBM round trip
         // runs under them (one row at a time every store waited for its own residual load; same change as in gemm.hip).
         u32x4 rres[RPT];
-        if (p.residual != nullptr && n < p.Cout && !SPLIT) {
+        if (p.residual != nullptr && n < p.Cout && !res32) {
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const int prow = pass * EPI_ROWS + rr + j * RPP;
@@ -153,7 +160,7 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
                 for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
                 if (p.residual != nullptr) {
                     float rf[8];
-                    if (SPLIT) {   // fp32 residual
+                    if (res32) {   // fp32 residual
                         const float* r = (const float*)p.residual + m * p.Cout_out + n;
                         const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
 #pragma unroll
@@ -211,8 +218,9 @@ __device__ __forceinline__ void halo_epilogue(const HaloArgs& p, char* smem, f32
 
 // TPS = taps of weights staged per pipeline step (per barrier): 1 for BN = 128, 2 for BN = 64, so that every
 // step carries a 16 KiB weight slice and 32 MFMAs per wave
-template <typename T, int BN, int WAVES_M, int TPS, bool SPLIT = false>
+template <typename T, int BN, int WAVES_M, int TPS, int SEG = 1>
 __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
+    constexpr bool SPLIT = SEG == 3;
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int SPC = (9 + TPS - 1) / TPS;       // steps per 64-channel chunk
     constexpr int TM = TH / WAVES_M;               // 32-pixel rows per wave
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     u32x4 rp[PLOADS];
     auto load_patch = [&](int kc) {
         int which, Cs, coff;
-        halo_src_of<SPLIT>(p, kc * 64, which, Cs, coff);
+        halo_src_of<SEG>(p, kc * 64, which, Cs, coff);
         const T* src = which ? X2 : X1;
         coff += c * 8;
 #pragma unroll
@@ -274,7 +282,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     auto store_patch = [&](int kc) {
         float sa[8], sb[8];
         if (p.ab != nullptr) {
-            const float* ab = p.ab + ((int64_t)img * p.Ctot + kc * 64 + c * 8) * 2;
+            const int kch = kc * 64 - ((SEG == 2 && kc * 64 >= p.Cseg) ? p.Cseg : 0);   // the channels this logical chunk holds
+            const float* ab = p.ab + ((int64_t)img * p.Cseg + kch + c * 8) * 2;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sa[e] = ab[2 * e]; sb[e] = ab[2 * e + 1]; }
         }
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
         }
     }
 
-    halo_epilogue<T, BN, TM, TN, 4, SPLIT>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
+    halo_epilogue<T, BN, TM, TN, 4, SEG>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -429,8 +438,9 @@ template <int N> __device__ __forceinline__ void halo_wait_barrier() {
 // the halo overhead of the patch drops (612 instead of 680 patch pixels per 512 outputs).  Ablation builds
 // (tools/ablate_halo.sh) put the issue cost of the weight LDS-DMAs at 25 % of the 4-wave kernel's time and the patch
 // pipeline at 22-36 %, the fragment reads at ~1 %: per-wave DMA / staging instructions are what to cut.
-template <typename T, int BN, int NORM, int NW, bool SPLIT = false>
+template <typename T, int BN, int NORM, int NW, int SEG = 1>
 __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
+    constexpr bool SPLIT = SEG == 3;
     constexpr int NT = 64 * NW;
     constexpr int WAVES_N = 2, WAVES_M = NW / 2;
     constexpr int TM = 4;                            // 32-pixel rows per wave
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     u32x4 rp[PL];
     auto issue_patch = [&](int k32, u32x4 (&r)[PL]) {
         int which, Cs, coff;
-        halo_src_of<SPLIT>(p, k32 * 32, which, Cs, coff);
+        halo_src_of<SEG>(p, k32 * 32, which, Cs, coff);
         const T* src = which ? X2 : X1;
         coff += c4 * 8;
 #pragma unroll
@@ -559,7 +569,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     };
     auto dma_ab = [&](int b, int buf) {   // (scale, shift) of the 64 channels of body b: 512 B, lanes 32..63 duplicate it
         if (NORM != 0) {   // every wave issues the same piece (identical bytes): no branch in the step, uniform vmcnt
-            const float* src = p.ab + ((int64_t)img * p.Ctot + b * 64) * 2 + (lane & 31) * 4;
+            const int bch = b * 64 - ((SEG == 2 && b * 64 >= p.Cseg) ? p.Cseg : 0);   // the channels body b holds (wave-uniform)
+            const float* src = p.ab + ((int64_t)img * p.Cseg + bch) * 2 + (lane & 31) * 4;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abuf + buf * AB32_BYTES), 16, 0, 0);
         }
     };
@@ -591,7 +602,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
         issue_patch(1, rp);
         float ab16[16];
         if (NORM != 0) {
-            const float* ab = p.ab + ((int64_t)img * p.Ctot + c4 * 8) * 2;
+            const float* ab = p.ab + ((int64_t)img * p.Cseg + c4 * 8) * 2;
 #pragma unroll
             for (int e = 0; e < 16; ++e) ab16[e] = ab[e];
         }
@@ -682,7 +693,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     for (int b = 0; b + 1 < nb; ++b) body(b, std::true_type{});
     body(nb - 1, std::false_type{});
 
-    halo_epilogue<T, BN, TM, TN, NW, SPLIT>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
+    halo_epilogue<T, BN, TM, TN, NW, SEG>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
 }
 
 template <typename T, int BN, int NW>
@@ -704,8 +715,15 @@ int launch_halo32(HaloArgs a, hipStream_t s) {
         return rsvld_check_launch();
     };
     if constexpr (__is_same(T, bf16)) {   // RSVLD_SPLIT: planes in, no fused norm (checked by the entry point)
-        if (a.split) return go(conv_halo32_kernel<T, BN, 0, NW, true>);
+        if (a.seg == 3) return go(conv_halo32_kernel<T, BN, 0, NW, 3>);
+    } else {                              // RSVLD_F16W2: fp16 in, weight pairs, the fused norm available
+        if (a.seg == 2) {
+            if (norm == 0) return go(conv_halo32_kernel<T, BN, 0, NW, 2>);
+            if (norm == 1) return go(conv_halo32_kernel<T, BN, 1, NW, 2>);
+            return go(conv_halo32_kernel<T, BN, 2, NW, 2>);
+        }
     }
+    if (a.seg != 1) return RSVLD_EUNSUPPORTED;
     if (norm == 0) return go(conv_halo32_kernel<T, BN, 0, NW>);
     if (norm == 1) return go(conv_halo32_kernel<T, BN, 1, NW>);
     return go(conv_halo32_kernel<T, BN, 2, NW>);
@@ -725,8 +743,11 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
         return rsvld_check_launch();
     };
     if constexpr (__is_same(T, bf16)) {
-        if (a.split) return go(conv_halo_kernel<T, BN, WAVES_M, TPS, true>);
+        if (a.seg == 3) return go(conv_halo_kernel<T, BN, WAVES_M, TPS, 3>);
+    } else {
+        if (a.seg == 2) return go(conv_halo_kernel<T, BN, WAVES_M, TPS, 2>);
     }
+    if (a.seg != 1) return RSVLD_EUNSUPPORTED;
     return go(conv_halo_kernel<T, BN, WAVES_M, TPS>);
 }
 
@@ -752,7 +773,7 @@ extern "C" int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d) {
     if (d->Ho != up * d->H || d->Wo != up * d->W) return 0;
     if (d->Cin % 64 != 0 || d->Cin2 % 64 != 0) return 0;
     if (d->act == RSVLD_ACT_GEGLU) return 0;
-    if (d->out_f32 && d->Cout > 32 && d->dtype != RSVLD_SPLIT) return 0;
+    if (d->out_f32 && d->Cout > 32 && d->dtype != RSVLD_SPLIT && d->dtype != RSVLD_F16W2) return 0;
     if (d->Wo < 16 || d->Ho < 4) return 0;   // tiny maps: the 8x32 tile would be mostly padding
     return 1;
 }
@@ -763,8 +784,10 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     if (d->x == nullptr || d->w == nullptr || d->out == nullptr) return RSVLD_EINVAL;
     if (d->B <= 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
     if ((d->Cin2 > 0) != (d->x2 != nullptr)) return RSVLD_EINVAL;
-    const bool split = d->dtype == RSVLD_SPLIT;
-    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16 && !split) return RSVLD_EINVAL;
+    const bool split = d->dtype == RSVLD_SPLIT, w2 = d->dtype == RSVLD_F16W2;
+    const int seg = split ? 3 : w2 ? 2 : 1;
+    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16 && seg == 1) return RSVLD_EINVAL;
+    if (d->out_f32 < 0 || d->out_f32 > 1) return RSVLD_EINVAL;   // (an fp16 output of RSVLD_SPLIT exists for the Linear layers only)
     if (split && norm_scale_shift != nullptr) return RSVLD_EUNSUPPORTED;   // the normalised tensor is split by its own kernel (rsvld_groupnorm_apply_split)
     if (split && !d->out_f32 && d->residual != nullptr) return RSVLD_EINVAL;
     if ((int64_t)d->Ho * d->Wo >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
@@ -772,8 +795,8 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     HaloArgs a;
     a.x = d->x; a.x2 = d->x2; a.w = d->w; a.bias = d->bias; a.rowvec = d->rowvec; a.residual = d->residual; a.out = d->out;
     a.ab = norm_scale_shift;
-    a.stats = (d->out_f32 && !split) ? nullptr : out_stats_partials;
-    a.split = split ? 1 : 0;
+    a.stats = (d->out_f32 && seg == 1) ? nullptr : out_stats_partials;
+    a.seg = seg;
     a.Cseg = d->Cin + d->Cin2;
     a.B = d->B; a.H = d->Ho; a.W = d->Wo; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
     a.B_plan = d->plan_div > 1 ? (d->B + d->plan_div - 1) / d->plan_div : d->B;
@@ -781,7 +804,7 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     a.Hs = d->H; a.Ws = d->W; a.ush = d->upsample ? 1 : 0;
     a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.norm_silu = norm_silu ? 1 : 0;
     a.alpha = d->alpha; a.beta = d->beta;
-    a.Ctot = (split ? 3 : 1) * (d->Cin + d->Cin2);
+    a.Ctot = seg * (d->Cin + d->Cin2);
     a.nchunks = a.Ctot / 64;
     a.tiles_x = (d->Wo + TW - 1) / TW;
     a.tiles_y = (d->Ho + TH - 1) / TH;
@@ -789,5 +812,5 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
     a.Cout_out = d->Cout;
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == RSVLD_F16 ? dispatch_halo<f16>(a, s) : dispatch_halo<bf16>(a, s);   // RSVLD_SPLIT runs the bf16 kernels
+    return (d->dtype == RSVLD_F16 || w2) ? dispatch_halo<f16>(a, s) : dispatch_halo<bf16>(a, s);   // RSVLD_SPLIT runs the bf16 kernels, RSVLD_F16W2 the fp16 ones
 }

@@ -25,7 +25,9 @@
 // dtype RSVLD_SPLIT (round 4, the split-operand precision on this tiling; see gemm.hip): x / x2 are bf16 PLANES [.., lo(C) | hi(C)]
 // of fp32 activations, the weights are packed per tap as the triple [W_hi | W_lo | W_hi] over the concatenated channels, and the
 // kernel runs as a bf16 convolution over 3 (Cin + Cin2) logical channels per tap whose third segment re-reads the hi planes:
-// x_lo W_hi + x_hi W_lo + x_hi W_hi.  Residual fp32; output fp32 (out_f32) or planes.
+// x_lo W_hi + x_hi W_lo + x_hi W_hi.  Residual fp32; output fp32 (out_f32 = 1), planes (0) or fp16 (2).
+// dtype RSVLD_F16W2 (round 5): fp16 activations, weights per tap as the fp16 pair [W_lo | W_hi]: an fp16 convolution over 2 (Cin + Cin2)
+// logical channels per tap whose second segment re-reads the activation.  Residual fp32; output fp32 (out_f32 = 1) or fp16 (0).
 #include <stdlib.h>
 #include <string.h>
 
@@ -56,8 +58,10 @@ struct ConvArgs {
     int rv_stride; // row stride of rowvec
     int M_plan;    // rows the launch plan is made for (M / plan_div)
     int tune;      // RSVLD_TUNE_*
-    int split;     // RSVLD_SPLIT: planes in, triple weights; Ctot8 / KC then count the 3 (Cin + Cin2) LOGICAL channels
-    int Cseg8;     // split: (Cin + Cin2) / 8, the chunks of one segment
+    int seg;       // K segments per tap: 1 plain; 3 RSVLD_SPLIT (planes in, triple weights); 2 RSVLD_F16W2 (fp16 in, pair weights).
+                   // Ctot8 / KC count the seg x (Cin + Cin2) LOGICAL channels
+    int out_kind;  // seg > 1: 0 = fp16 out, 1 = fp32 out, 2 = bf16 planes out (seg == 1: out_f32 decides)
+    int Cseg8;     // (Cin + Cin2) / 8, the chunks of one segment
     int C2_8;      // Cin2 / 8
 };
 
@@ -79,8 +83,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // KS = intra-workgroup split of K: KS groups of 4 waves each own every KS-th K-step of the SAME output tile (own
 // LDS ring, shared barriers) and their accumulators are summed through LDS before the epilogue.  For small-M layers
 // whose grid is one workgroup per CU this doubles the waves per SIMD without partial sums in HBM.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES, int KS, bool SPLIT = false>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES, int KS, int SEG = 1>
 __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
+    constexpr bool SPLIT = SEG == 3;
     static_assert(GLDS ? (STAGES >= 2 && STAGES <= 4) : STAGES == 2, "register staging is double-buffered");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per K group");
     static_assert(KS == 1 || (GLDS && STAGES > 2), "split K runs on the LDS-DMA ring");
@@ -169,6 +174,8 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
             ch -= s1 ? p.Cseg8 : 0;
             ch -= ch >= p.Cseg8 ? p.Cseg8 : 0;
             hi = s1 ? 1 : 0;
+        } else if (SEG == 2) {                        // the pair form reads the one activation twice
+            ch -= ch >= p.Cseg8 ? p.Cseg8 : 0;
         }
         const bool first = ch < p.C1_8;
         src = first ? X1 : X2;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
     // the residual pieces this thread will add on the way out are requested before the staging pass (their HBM round trip
     // runs under it; same change as in gemm.hip / conv_halo.hip)
     u32x4 rres[RPT];
-    if (p.residual != nullptr && n < p.Cout && p.act != RSVLD_ACT_GEGLU && !SPLIT) {
+    if (p.residual != nullptr && n < p.Cout && p.act != RSVLD_ACT_GEGLU && SEG == 1) {
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const int row = rr + j * RPP;
@@ -375,13 +382,18 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];
         }
-        if (SPLIT) {   // fp32 residual; fp32 or planes (lo | hi per row) out
+        if (SEG > 1) {   // fp32 residual; fp32, planes (lo | hi per row) or fp16 out
             if (p.act == RSVLD_ACT_GEGLU) {
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = p.alpha * v[2 * e] * gelu_erf_f(v[2 * e + 1]);
-                if (p.out_f32) {
+                if (p.out_kind == 1) {
                     *(f32x4*)((float*)p.out + (int64_t)m * p.Cout_out + (n >> 1)) = (f32x4){o[0], o[1], o[2], o[3]};
+                } else if (p.out_kind == 0) {
+                    f16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (f16)o[e];
+                    *(f16x4*)((f16*)p.out + (int64_t)m * p.Cout_out + (n >> 1)) = ov;
                 } else {
                     typename Mfma<T>::v4 oh, ol;
 #pragma unroll
@@ -398,16 +410,25 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-            if (p.residual != nullptr) {
-                const float* r = (const float*)p.residual + (int64_t)m * p.Cout_out + n;
-                const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
+            if (p.residual != nullptr) {   // the residual has the output's type: fp32, or fp16 beside the pair form's fp16 output
+                if (SEG == 2 && p.out_kind == 0) {
+                    float rf[8];
+                    unpack8<f16>(*(const u32x4*)((const f16*)p.residual + (int64_t)m * p.Cout_out + n), rf);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += p.beta * r0[e]; v[4 + e] += p.beta * r1[e]; }
+                    for (int e = 0; e < 8; ++e) v[e] += p.beta * rf[e];
+                } else {
+                    const float* r = (const float*)p.residual + (int64_t)m * p.Cout_out + n;
+                    const f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += p.beta * r0[e]; v[4 + e] += p.beta * r1[e]; }
+                }
             }
-            if (p.out_f32) {
+            if (p.out_kind == 1) {
                 float* o = (float*)p.out + (int64_t)m * p.Cout_out + n;
                 *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
                 *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            } else if (p.out_kind == 0) {
+                *(u32x4*)((f16*)p.out + (int64_t)m * p.Cout_out + n) = pack8<f16>(v);
             } else {
                 float lo[8];
                 typename Mfma<T>::v8 hv;
@@ -466,9 +487,13 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         return rsvld_check_launch();
     };
     if constexpr (__is_same(T, bf16) && GLDS) {   // RSVLD_SPLIT: its own instantiation (bf16, LDS-DMA staging), so that the 16-bit kernels stay as they were
-        if (a.split) return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS, true>);
+        if (a.seg == 3) return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS, 3>);
+        if (a.seg != 1) return RSVLD_EUNSUPPORTED;
+    } else if constexpr (__is_same(T, f16) && GLDS) {   // RSVLD_F16W2 likewise (fp16, LDS-DMA staging)
+        if (a.seg == 2) return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS, 2>);
+        if (a.seg != 1) return RSVLD_EUNSUPPORTED;
     } else {
-        if (a.split) return RSVLD_EUNSUPPORTED;
+        if (a.seg != 1) return RSVLD_EUNSUPPORTED;
     }
     return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS>);
 }
@@ -535,10 +560,12 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     if (d->Cin <= 0 || d->Cin % 8 != 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
     if (d->Cin2 < 0 || d->Cin2 % 8 != 0 || ((d->Cin2 > 0) != (d->x2 != nullptr))) return RSVLD_EINVAL;
     if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return RSVLD_EINVAL;
-    const bool split = d->dtype == RSVLD_SPLIT;
-    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16 && !split) return RSVLD_EINVAL;
-    if (!split && d->out_f32 && (d->Cout > 32 || d->act == RSVLD_ACT_GEGLU || d->residual != nullptr)) return RSVLD_EUNSUPPORTED;
-    if (split && !d->out_f32 && d->residual != nullptr) return RSVLD_EINVAL;   // planes out: no residual (the stream stays fp32)
+    const bool split = d->dtype == RSVLD_SPLIT, w2 = d->dtype == RSVLD_F16W2;
+    const int seg = split ? 3 : w2 ? 2 : 1;
+    if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16 && seg == 1) return RSVLD_EINVAL;
+    if (d->out_f32 < 0 || d->out_f32 > 2 || (d->out_f32 == 2 && !split)) return RSVLD_EINVAL;
+    if (seg == 1 && d->out_f32 && (d->Cout > 32 || d->act == RSVLD_ACT_GEGLU || d->residual != nullptr)) return RSVLD_EUNSUPPORTED;
+    if (split && d->out_f32 != 1 && d->residual != nullptr) return RSVLD_EINVAL;   // planes / fp16 out of RSVLD_SPLIT: no residual (the stream stays fp32)
     if (d->act == RSVLD_ACT_GEGLU && (d->Cout % 16 != 0 || d->residual != nullptr)) return RSVLD_EINVAL;
     if ((int64_t)d->B * d->Ho * d->Wo >= (int64_t)1 << 31) return RSVLD_EUNSUPPORTED;
     if ((int64_t)d->B * d->H * d->W >= (int64_t)1 << 31) return RSVLD_EUNSUPPORTED;
@@ -566,20 +593,21 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cin2 = d->Cin2; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
     a.Ho = d->Ho; a.Wo = d->Wo; a.upsample = d->upsample ? 1 : 0;
-    a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
+    a.out_f32 = d->out_f32 == 1 ? 1 : 0; a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
     a.M = d->B * d->Ho * d->Wo;
     a.M_plan = d->plan_div > 1 ? (a.M + d->plan_div - 1) / d->plan_div : a.M;
     a.tune = d->tune;
     a.HoWo = d->Ho * d->Wo;
     a.C1_8 = d->Cin / 8;
     a.C2_8 = d->Cin2 / 8;
-    a.split = split ? 1 : 0;
+    a.seg = seg;
+    a.out_kind = d->out_f32 == 1 ? 1 : (split && d->out_f32 == 0) ? 2 : 0;
     a.Cseg8 = (d->Cin + d->Cin2) / 8;
-    a.Ctot8 = (split ? 3 : 1) * a.Cseg8;
+    a.Ctot8 = seg * a.Cseg8;
     a.KC = d->KH * d->KW * a.Ctot8;
     a.nk = (a.KC + 7) / 8;
     a.Cout_out = d->act == RSVLD_ACT_GEGLU ? d->Cout / 2 : d->Cout;
     a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
     hipStream_t s = (hipStream_t)stream;
-    return d->dtype == RSVLD_F16 ? dispatch_conv<f16>(a, s) : dispatch_conv<bf16>(a, s);   // RSVLD_SPLIT runs the bf16 kernels
+    return (d->dtype == RSVLD_F16 || w2) ? dispatch_conv<f16>(a, s) : dispatch_conv<bf16>(a, s);   // RSVLD_SPLIT runs the bf16 kernels, RSVLD_F16W2 the fp16 ones
 }

@@ -46,7 +46,7 @@ struct GemmArgs {
     int M, N, K, N_out;
     int act;
     float alpha, beta;
-    int out_planes;        // SPLIT only: 1 = bf16 planes out, 0 = fp32 out
+    int out_kind;          // SEG > 1 only: 0 = 16-bit out (fp16), 1 = fp32 out (+ fp32 residual), 2 = bf16 planes out
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -120,12 +120,23 @@ template <int N> __device__ __forceinline__ void g_wait_vm() { asm volatile("s_w
 // PV (PERSIST only): the epilogue variant, chosen on the host: activation (0 none, 1 SiLU, 2 GEGLU) | 4 x (alpha == 1) | 8 x residual.
 // One variant per instantiation: with the seven variants behind a dispatch inside the tile loop hipcc spilled 490-680 dwords around
 // the epilogue (none with one variant), and a scratch reload is a vector-memory load that queues behind the ring's LDS-DMA pieces.
-template <typename T, bool SPLIT = false, bool PERSIST = false, int PV = 0>
+// SEG = K segments of one logical product: 1 = a plain 16-bit GEMM; 3 = RSVLD_SPLIT (bf16 planes lo | hi x triples W_hi | W_lo | W_hi);
+// 2 = RSVLD_F16W2 (round 5): fp16 activations x fp16 weight PAIRS [W_lo | W_hi] -- the weights keep ~22 significant bits, the
+// activation its 11: x W = x W_lo + x W_hi is ONE fp16 GEMM over K' = 2 K whose second segment re-reads the activation row.
+// TO = the 16-bit OUTPUT type: T for a plain GEMM, fp16 for both multi-segment forms (a tensor that goes on to an fp16-operand
+// consumer: the 16-bit attention kernels, another F16W2 layer); their fp32 / planes outputs leave through the one-tile SEG epilogue.
+// WIDE (one-tile form of the multi-segment GEMMs): true = the fp32 / planes epilogue, false = the 16-bit one -- a template parameter,
+// because a kernel that holds BOTH epilogues spills (220 scratch instructions; a scratch reload shares vmcnt with the LDS-DMA ring).
+template <typename T, int SEG = 1, bool PERSIST = false, int PV = 0, bool WIDE = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
-    static_assert(!(SPLIT && PERSIST), "the persistent form exists for the 16-bit epilogue only");
+    static_assert(!WIDE || (SEG > 1 && !PERSIST), "the fp32 / planes epilogue belongs to the one-tile multi-segment kernels");
+    static_assert(SEG >= 1 && SEG <= 3, "1 plain, 2 fp16 x weight pairs, 3 bf16 planes x weight triples");
+    static_assert(SEG == 1 || !(PV & 8), "the persistent residual variants are 16-bit residuals (plain GEMM only)");
     static_assert(PERSIST || PV == 0, "PV is the persistent epilogue's variant");
+    constexpr bool SPLIT = SEG == 3;
     typedef typename Mfma<T>::v8 v8;
-    typedef typename Mfma<T>::v4 v4;
+    typedef typename std::conditional<SEG == 1, T, f16>::type TO;
+    typedef typename Mfma<TO>::v4 v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -189,9 +200,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         }
     }
     const int nk0 = p.K >> 5;
-    const int nk = (G_ABL & 4) ? 3 : (SPLIT ? 3 * nk0 : nk0);   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
+    const int nk = (G_ABL & 4) ? 3 : SEG * nk0;   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
     const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 2 : 1);    // activation row: K values, or the planes lo | hi
-    const int64_t rowb_w = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 3 : 1);  // weight row: K values, or the triple hi | lo | hi
+    const int64_t rowb_w = (int64_t)p.K * (int64_t)sizeof(T) * SEG;              // weight row: K values, the pair lo | hi, or the triple hi | lo | hi
+    // K tile kt of the concatenated K' -> the activation's K tile: SPLIT reads the planes lo, hi, hi (tiles >= 2 nk0 alias the hi
+    // plane), the pair form reads the one row twice; the weight row is linear
+    auto xk = [&](int kt) { return SEG == 3 ? (kt >= 2 * nk0 ? kt - nk0 : kt) : SEG == 2 ? (kt >= nk0 ? kt - nk0 : kt) : kt; };
     if (G_STAGGER > 0 && !PERSIST) {
         const int lid = blockIdx.x + blockIdx.y * gridDim.x;
         if (lid < 256 && ((lid >> 3) & 1))
@@ -277,14 +291,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     auto dma_piece = [&](int kt, int j) {
 #if G_ASMDMA
         const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024);
-        // SPLIT: the activation planes are read lo, hi, hi (tiles >= 2 nk0 alias the hi plane); the weight triple is linear
-        const int ktx = (G_ABL & 8) ? (kt & 3) : (SPLIT && kt >= 2 * nk0) ? kt - nk0 : kt;
+        const int ktx = (G_ABL & 8) ? (kt & 3) : xk(kt);
         const char* base = (j & 1) ? Wb + ((G_ABL & 8) ? (kt & 3) : kt) * 64 : Xb + ktx * 64;
         const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[j >> 1];
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
 #else
         char* st = smem + (kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024;
-        const int ktx = (SPLIT && kt >= 2 * nk0) ? kt - nk0 : kt;
+        const int ktx = xk(kt);
         const char* src = (j & 1) ? Wb + kt * 64 : Xb + ktx * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)(src + ((j & 1) ? wvo[j >> 1] : xvo[j >> 1])), (lptr_t)st, 16, 0, 0);
 #endif
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     for (int ks = 0; ks < 2; ++ks) fbh_off[ks] = g_off(grp * 64 + l31, 2 * ks + lh);
     auto dma_piece_h = [&](int kt, int j) {   // j = 0: the wave's X rows; 1, 3: its W rows as in a whole tile
         const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + ((j & 1) ? wave * 2048 + 16384 + (j >> 1) * 1024 : wave * 1024));
-        const char* base = (j & 1) ? Wb + kt * 64 : Xb + kt * 64;
+        const char* base = (j & 1) ? Wb + kt * 64 : Xb + xk(kt) * 64;
         const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[0];
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
     };
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     for (int c = 2 * MI * part; c < 2 * MI * part + 2 * MI; ++c) {
                         const int m = m0e + grp * (32 * MI) + (c >> 2) * 32 + (c & 3) * 8 + (lane >> 3);
                         // rows / columns past the end re-read a valid address (never stored)
-                        rv[res ? c : 0] = *(const u32x4*)((const T*)p.residual + (int64_t)min(m, p.M - 1) * p.N_out + (nr < p.N_out ? nr : 0));
+                        rv[res ? c : 0] = *(const u32x4*)((const TO*)p.residual + (int64_t)min(m, p.M - 1) * p.N_out + (nr < p.N_out ? nr : 0));
                     }
                 };
                 auto prefetch_next = [&]() {
@@ -722,7 +735,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 // instruction); GEGLU lane -> rows lane/4 + 16 i, output channels 8 (lane % 4) .. + 8 of the wave's 32 (16 rows x 64 B)
                 const int nn = act == 2 ? (n0e >> 1) + wn * 32 + (lane & 3) * 8 : n0e + wn * 64 + (lane & 7) * 8;
                 const int r0 = m0e + grp * (32 * MI) + (act == 2 ? (lane >> 2) : (lane >> 3));
-                T* const op = (T*)p.out + (int64_t)r0 * p.N_out + nn;
+                TO* const op = (TO*)p.out + (int64_t)r0 * p.N_out + nn;
                 const int64_t rstep = (int64_t)RSTEP * p.N_out;
                 u32x4 o[res ? 4 * MI : NCH];
                 auto store_block = [&](int mi, const u32x4* ob) {
@@ -733,11 +746,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                             u32x4 val = ob[i];
                             if constexpr (res) {
                                 float f[8], rf[8];
-                                unpack8<T>(val, f);
-                                unpack8<T>(rv[mi * 4 + i], rf);
+                                unpack8<TO>(val, f);
+                                unpack8<TO>(rv[mi * 4 + i], rf);
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
-                                val = pack8<T>(f);
+                                val = pack8<TO>(f);
                             }
                             *(u32x4*)(op + (mi * (32 / RSTEP) + i) * rstep) = val;
                         }
@@ -756,9 +769,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #if G_GELU_PACKED
                                 const f32x2_t gl = gelu_erf2_f((f32x2_t){v[1], v[3]});
                                 const f32x2_t pr = ((f32x2_t){v[0], v[2]} * p.alpha) * gl;
-                                T o2[2] = {(T)pr[0], (T)pr[1]};
+                                TO o2[2] = {(TO)pr[0], (TO)pr[1]};
 #else
-                                T o2[2] = {(T)(p.alpha * v[0] * gelu_erf_f(v[1])), (T)(p.alpha * v[2] * gelu_erf_f(v[3]))};
+                                TO o2[2] = {(TO)(p.alpha * v[0] * gelu_erf_f(v[1])), (TO)(p.alpha * v[2] * gelu_erf_f(v[3]))};
 #endif
                                 uint32_t packed;
                                 __builtin_memcpy(&packed, o2, 4);
@@ -770,7 +783,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                                 }
                                 v4 ov;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) ov[e] = alpha1 ? (T)v[e] : (T)(v[e] * p.alpha);
+                                for (int e = 0; e < 4; ++e) ov[e] = alpha1 ? (TO)v[e] : (TO)(v[e] * p.alpha);
                                 *(v4*)(P + wbase + (((ni * 4 + g) << 4) ^ x7)) = ov;
                             }
                         }
@@ -799,11 +812,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                         for (int c = 0; c < 4 * MI; ++c) {
                             float f[8], rf[8];
-                            unpack8<T>(o[c], f);
-                            unpack8<T>(rv[c], rf);
+                            unpack8<TO>(o[c], f);
+                            unpack8<TO>(rv[c], rf);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
-                            *(u32x4*)(op + ((c >> 2) * 4 + (c & 3)) * rstep) = pack8<T>(f);
+                            *(u32x4*)(op + ((c >> 2) * 4 + (c & 3)) * rstep) = pack8<TO>(f);
                         }
                     } else {
 #pragma unroll
@@ -922,15 +935,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     if (p.M > 0) return;   // diagnostic build: no epilogue at all (the accumulators stay live for the compiler)
 #endif
 
-    if constexpr (SPLIT) {
-        // ---- SPLIT epilogue: the 256 x 256 fp32 tile (256 KiB; as planes lo | hi the same bytes) does not fit the 128 KiB ring, so it
+    if constexpr (WIDE) {
+        // ---- SEG epilogue (fp32 / planes out; a 16-bit output takes the plain epilogue below): the 256 x 256 fp32 tile (256 KiB; as planes lo | hi the same bytes) does not fit the 128 KiB ring, so it
         // leaves in two halves of 128 rows = the rows of group 0, then of group 1: the owning group stages bias / activation / alpha
         // in registers -> LDS (16-byte chunks XOR-swizzled by the row), all 512 threads move whole 16-byte chunks out as contiguous
         // runs and add the fp32 residual on that side.  Twice the bytes of the 16-bit epilogue behind three times its K loop.
         const bool geglu = p.act == RSVLD_ACT_GEGLU;
         const int ncol = geglu ? 128 : 256;                       // columns of the stored tile
         const int n_out0 = geglu ? (n0 >> 1) : n0;
-        const bool planes = p.out_planes != 0;
+        const bool planes = p.out_kind == 2;
         // fp32: row = ncol * 4 bytes = ncol / 4 chunks; planes: row = lo (ncol * 2 bytes) | hi (ncol * 2 bytes) = ncol / 4 chunks as well
         const int rchunks = ncol >> 2;                            // 64 or 32 16-byte chunks per staged row
         const int rbytes = rchunks << 4;
@@ -1037,7 +1050,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + (tid >> 5) + 16 * i;
-            rv[i] = (m < p.M && nn < p.N_out && !(G_ABL & 1)) ? *(const u32x4*)((const T*)p.residual + (int64_t)m * p.N_out + nn)
+            rv[i] = (m < p.M && nn < p.N_out && !(G_ABL & 1)) ? *(const u32x4*)((const TO*)p.residual + (int64_t)m * p.N_out + nn)
                                                               : u32x4{0u, 0u, 0u, 0u};
         }
     }
@@ -1066,7 +1079,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e] + bq[e];
                         if constexpr (act == 2) {   // channels are (value, gate) interleaved: 2 outputs per quad
-                            T o2[2] = {(T)(p.alpha * v[0] * gelu_erf_f(v[1])), (T)(p.alpha * v[2] * gelu_erf_f(v[3]))};
+                            TO o2[2] = {(TO)(p.alpha * v[0] * gelu_erf_f(v[1])), (TO)(p.alpha * v[2] * gelu_erf_f(v[3]))};
                             uint32_t packed;
                             __builtin_memcpy(&packed, o2, 4);
                             *(uint32_t*)(smem + so + mi * (32 * 256)) = packed;
@@ -1077,7 +1090,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                             }
                             v4 o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = alpha1 ? (T)v[e] : (T)(v[e] * p.alpha);
+                            for (int e = 0; e < 4; ++e) o[e] = alpha1 ? (TO)v[e] : (TO)(v[e] * p.alpha);
                             *(v4*)(smem + so + mi * (32 * 512)) = o;
                         }
                     }
@@ -1107,7 +1120,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     for (int e = 0; e < 4; ++e) v[e] += bv[e];
                 }
                 if (geglu) {   // channels are (value, gate) interleaved: 2 outputs per quad
-                    T o2[2] = {(T)(p.alpha * v[0] * gelu_erf_f(v[1])), (T)(p.alpha * v[2] * gelu_erf_f(v[3]))};
+                    TO o2[2] = {(TO)(p.alpha * v[0] * gelu_erf_f(v[1])), (TO)(p.alpha * v[2] * gelu_erf_f(v[3]))};
                     uint32_t packed;
                     __builtin_memcpy(&packed, o2, 4);
                     const int oc = col >> 1;   // output column inside the 128-wide tile
@@ -1119,7 +1132,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     }
                     v4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (T)(v[e] * p.alpha);
+                    for (int e = 0; e < 4; ++e) o[e] = (TO)(v[e] * p.alpha);
                     *(v4*)(smem + c_off(row, col >> 3) + (col & 7) * 2) = o;
                 }
             }
@@ -1140,11 +1153,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     const int row = (tid >> 5) + 16 * i;
                     if (m0 + row >= p.M || ((G_ABL & 1) && p.M > 0)) continue;
                     float f[8], rf[8];
-                    unpack8<T>(*(const u32x4*)(smem + c_off(row, chunk)), f);
-                    unpack8<T>(rv[i], rf);
+                    unpack8<TO>(*(const u32x4*)(smem + c_off(row, chunk)), f);
+                    unpack8<TO>(rv[i], rf);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] += p.beta * rf[e];
-                    *(u32x4*)((T*)p.out + (int64_t)(m0 + row) * p.N_out + nn) = pack8<T>(f);
+                    *(u32x4*)((TO*)p.out + (int64_t)(m0 + row) * p.N_out + nn) = pack8<TO>(f);
                 }
             }
         } else if (nn < p.N_out) {
@@ -1153,8 +1166,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 // staging offset alternates between two precomputed values (row & 31 = (r0 & 15) | 16 (i & 1)): 16 x (read, store,
                 // pointer add) instead of 16 x (bounds test, 64-bit multiply-add, swizzle)
                 const int r0 = tid >> 5;
-                char* o = (char*)((T*)p.out + (int64_t)(m0 + r0) * p.N_out + nn);
-                const int64_t ostep = (int64_t)16 * p.N_out * (int64_t)sizeof(T);
+                char* o = (char*)((TO*)p.out + (int64_t)(m0 + r0) * p.N_out + nn);
+                const int64_t ostep = (int64_t)16 * p.N_out * (int64_t)sizeof(TO);
                 const int so0 = r0 * 512 + ((chunk ^ r0) << 4), so1 = (r0 + 16) * 512 + ((chunk ^ (r0 + 16)) << 4);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -1164,7 +1177,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             } else {
                 for (int row = tid / row_chunks; row < 256; row += rows_per_pass) {
                     if (m0 + row >= p.M || ((G_ABL & 1) && p.M > 0)) break;
-                    *(u32x4*)((T*)p.out + (int64_t)(m0 + row) * p.N_out + nn) = *(const u32x4*)(smem + c_off(row, chunk));
+                    *(u32x4*)((TO*)p.out + (int64_t)(m0 + row) * p.N_out + nn) = *(const u32x4*)(smem + c_off(row, chunk));
                 }
             }
         }
@@ -1187,11 +1200,24 @@ extern "C" int rsvld_debug_gemm_stamps(void* dst, size_t bytes) {
 
 // Eligibility + launch, called from rsvld_conv2d_nhwc for 1x1 / stride-1 / single-source layers.
 // Returns RSVLD_EUNSUPPORTED when the shape should stay on the implicit-GEMM kernel.
+namespace {
+// one launch helper per KERNEL (a non-type template parameter): the one-time registration of the dynamic LDS size is a
+// function-local static of THIS instantiation (a generic lambda's static would be shared by every kernel of one function type)
+template <auto KERN, int SMEM>
+int gemm_go(dim3 grid, hipStream_t s, const GemmArgs& a) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    hipLaunchKernelGGL(KERN, grid, dim3(512), SMEM, s, a);
+    return rsvld_check_launch();
+}
+}  // namespace
+
 int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
-    const bool split = d->dtype == RSVLD_SPLIT;
+    const bool split = d->dtype == RSVLD_SPLIT, w2 = d->dtype == RSVLD_F16W2;
+    const int seg = split ? 3 : w2 ? 2 : 1;
     if (d->tune & RSVLD_TUNE_NO_GEMM256) return RSVLD_EUNSUPPORTED;   // A/B switch
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad_t != 0 || d->pad_l != 0 || d->upsample) return RSVLD_EUNSUPPORTED;
-    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || (d->out_f32 && !split)) return RSVLD_EUNSUPPORTED;
+    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || (d->out_f32 && seg == 1)) return RSVLD_EUNSUPPORTED;
     if (d->Cin % 32 != 0 || d->Cout % 8 != 0) return RSVLD_EUNSUPPORTED;
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     if (d->H != d->Ho || d->W != d->Wo) return RSVLD_EUNSUPPORTED;
@@ -1200,27 +1226,24 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     if (d->Cout < 256 || Mp < 4096) return RSVLD_EUNSUPPORTED;
     const int64_t tiles = ((Mp + 255) / 256) * ((d->Cout + 255) / 256);
     if (tiles < 128) return RSVLD_EUNSUPPORTED;   // one workgroup per CU; measured: from half the chip up it beats the 128x128 kernel
-    // 32-bit lane offsets inside a tile: 256 rows of the activation tensor (planes: 2 K per row) / of the weights (triple: 3 K)
-    if ((int64_t)256 * d->Cin * (split ? 6 : 2) >= ((int64_t)1 << 32) || M >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
+    // 32-bit lane offsets inside a tile: 256 rows of the activation tensor (planes: 2 K per row) / of the weights (pair 2 K, triple 3 K)
+    if ((int64_t)256 * d->Cin * 2 * seg >= ((int64_t)1 << 32) || M >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
     if (d->act == RSVLD_ACT_GEGLU && (d->Cout % 16 != 0 || d->residual != nullptr)) return RSVLD_EINVAL;
-    if (split && !d->out_f32 && d->residual != nullptr) return RSVLD_EINVAL;   // planes out: no residual (the stream stays fp32)
+    // RSVLD_SPLIT: the residual is the fp32 stream and goes with the fp32 output only (RSVLD_F16W2: the residual has the output's type)
+    if (split && d->out_f32 != 1 && d->residual != nullptr) return RSVLD_EINVAL;
+    if ((d->out_f32 == 2 && !split) || d->out_f32 < 0 || d->out_f32 > 2) return RSVLD_EINVAL;
     GemmArgs a;
     a.x = d->x; a.w = d->w; a.bias = d->bias; a.residual = d->residual; a.out = d->out;
     a.M = (int)M; a.N = d->Cout; a.K = d->Cin;
     a.N_out = d->act == RSVLD_ACT_GEGLU ? d->Cout / 2 : d->Cout;
     a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
-    a.out_planes = (split && !d->out_f32) ? 1 : 0;
+    // out_kind: 0 = 16-bit (T, or fp16 from the multi-segment forms), 1 = fp32, 2 = bf16 planes (RSVLD_SPLIT's native output)
+    a.out_kind = seg == 1 ? 0 : d->out_f32 == 1 ? 1 : (split && d->out_f32 == 0) ? 2 : 0;
     hipStream_t s = (hipStream_t)stream;
     const unsigned nmt = (unsigned)((M + 255) / 256), nnt = (unsigned)((d->Cout + 255) / 256);
-    auto go = [&](auto kern, dim3 grid, int smem) -> int {
-        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (attr != hipSuccess) return RSVLD_ELAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, s, a);
-        return rsvld_check_launch();
-    };
-    if (split) return go(gemm256_kernel<bf16, true, false>, dim3(nmt, nnt), G_SMEM);
+    const dim3 grid1(nmt, nnt);
     // the persistent form: 16-bit output, at least four K tiles (its K loop peels tile 0 and requests three tiles ahead)
-    if (!(d->tune & RSVLD_TUNE_GEMM_ONE_TILE) && d->Cin >= 128) {
+    if (!(d->tune & RSVLD_TUNE_GEMM_ONE_TILE) && a.out_kind == 0 && seg * d->Cin >= 128) {
         static const int n_cu = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -1230,16 +1253,29 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
             const dim3 pgrid((unsigned)min((int64_t)nmt * nnt, (int64_t)n_cu));
             const int pv = (a.act == RSVLD_ACT_GEGLU ? 2 : a.act == RSVLD_ACT_SILU ? 1 : 0) | (a.alpha == 1.0f ? 4 : 0) | (a.residual != nullptr ? 8 : 0);
             const bool h = d->dtype == RSVLD_F16;
-#define G_PV_CASE(V) case V: return h ? go(gemm256_kernel<f16, false, true, V>, pgrid, G_SMEM_P) : go(gemm256_kernel<bf16, false, true, V>, pgrid, G_SMEM_P);
-            switch (pv) {
-                G_PV_CASE(0) G_PV_CASE(4) G_PV_CASE(8) G_PV_CASE(12)      // no activation: alpha, alpha == 1, + residual
-                G_PV_CASE(1) G_PV_CASE(5) G_PV_CASE(9) G_PV_CASE(13)      // SiLU
-                G_PV_CASE(2) G_PV_CASE(6)                                 // GEGLU (never with a residual: checked above)
-                default: break;
-            }
+            if (seg == 1) {
+#define G_PV_CASE(V) case V: return h ? gemm_go<gemm256_kernel<f16, 1, true, V>, G_SMEM_P>(pgrid, s, a) : gemm_go<gemm256_kernel<bf16, 1, true, V>, G_SMEM_P>(pgrid, s, a);
+                switch (pv) {
+                    G_PV_CASE(0) G_PV_CASE(4) G_PV_CASE(8) G_PV_CASE(12)      // no activation: alpha, alpha == 1, + residual
+                    G_PV_CASE(1) G_PV_CASE(5) G_PV_CASE(9) G_PV_CASE(13)      // SiLU
+                    G_PV_CASE(2) G_PV_CASE(6)                                 // GEGLU (never with a residual: checked above)
+                    default: break;
+                }
 #undef G_PV_CASE
+            } else {   // fp16 out of the multi-segment forms (the transformer blocks' q | k | v and GEGLU layers): no SiLU variants
+#define G_PV_CASE(V) case V: return split ? gemm_go<gemm256_kernel<bf16, 3, true, V>, G_SMEM_P>(pgrid, s, a) : gemm_go<gemm256_kernel<f16, 2, true, V>, G_SMEM_P>(pgrid, s, a);
+                switch (pv) {
+                    G_PV_CASE(0) G_PV_CASE(4) G_PV_CASE(2) G_PV_CASE(6)
+                    default: break;
+                }
+#undef G_PV_CASE
+            }
         }
     }
-    return d->dtype == RSVLD_F16 ? go(gemm256_kernel<f16, false, false>, dim3(nmt, nnt), G_SMEM)
-                                 : go(gemm256_kernel<bf16, false, false>, dim3(nmt, nnt), G_SMEM);
+    if (split) return a.out_kind != 0 ? gemm_go<gemm256_kernel<bf16, 3, false, 0, true>, G_SMEM>(grid1, s, a)
+                                      : gemm_go<gemm256_kernel<bf16, 3, false, 0, false>, G_SMEM>(grid1, s, a);
+    if (w2) return a.out_kind != 0 ? gemm_go<gemm256_kernel<f16, 2, false, 0, true>, G_SMEM>(grid1, s, a)
+                                   : gemm_go<gemm256_kernel<f16, 2, false, 0, false>, G_SMEM>(grid1, s, a);
+    return d->dtype == RSVLD_F16 ? gemm_go<gemm256_kernel<f16, 1, false>, G_SMEM>(grid1, s, a)
+                                 : gemm_go<gemm256_kernel<bf16, 1, false>, G_SMEM>(grid1, s, a);
 }

@@ -468,8 +468,8 @@ __global__ __launch_bounds__(256) void gn_partial_f32_kernel(const float* __rest
     }
 }
 
-// y = act(a[b,c] * v + s[b,c]) [* (1 + mod_scale) + mod_shift]; fp32 in (one or two sources), planes or fp32 out
-template <bool OUT_F32>
+// y = act(a[b,c] * v + s[b,c]) [* (1 + mod_scale) + mod_shift]; fp32 in (one or two sources); OUT: 0 planes, 1 fp32, 2 fp16 out
+template <int OUT>
 __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __restrict__ x1, const float* __restrict__ x2, void* __restrict__ y,
                                                              const float* __restrict__ ab, const float* __restrict__ mod_scale,
                                                              const float* __restrict__ mod_shift, int HW, int C1, int C2, int silu,
@@ -507,10 +507,12 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __rest
                 for (int e = 0; e < 8; ++e) f[e] = f[e] * (1.f + ms[e]) + mh[e];
             }
             const int64_t pix = (int64_t)b * HW + r;
-            if (OUT_F32) {
+            if (OUT == 1) {
                 float* o = (float*)y + pix * C + cc * 8;
                 *(f32x4*)o = (f32x4){f[0], f[1], f[2], f[3]};
                 *(f32x4*)(o + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+            } else if (OUT == 2) {
+                *(u32x4*)((f16*)y + pix * C + cc * 8) = pack8<f16>(f);
             } else {
                 st_planes8((bf16*)y + pix * (2 * C), C, cc * 8, f);
             }
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __rest
 
 // LayerNorm of fp32 rows -> planes (or fp32): the 16-bit kernel's structure (one wave per row group, rows and the lane's
 // gamma / beta in registers, exact two-pass variance) with 32-byte pieces
-template <int MAXC, int ROWS, bool OUT_F32>
+template <int MAXC, int ROWS, int OUT>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, void* __restrict__ y,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               int64_t rows, int C, float eps) {
@@ -590,10 +592,12 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
                     float o[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (f[r][j][e] - mean) * rstd * ga[j][e] + be[j][e];
-                    if (OUT_F32) {
+                    if (OUT == 1) {
                         float* d = (float*)y + (row0 + r) * C + cc * 8;
                         *(f32x4*)d = (f32x4){o[0], o[1], o[2], o[3]};
                         *(f32x4*)(d + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+                    } else if (OUT == 2) {
+                        *(u32x4*)((f16*)y + (row0 + r) * C + cc * 8) = pack8<f16>(o);
                     } else {
                         st_planes8((bf16*)y + (row0 + r) * (2 * (int64_t)C), C, cc * 8, o);
                     }
@@ -845,16 +849,20 @@ extern "C" int rsvld_groupnorm_apply_split(const float* x, const float* x2, void
     if (rpb < 2 * rif) rpb = 2 * rif;
     const int nblk = (HW + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
-    if (out_f32)
-        hipLaunchKernelGGL(gn_apply_split_kernel<true>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
+    if (out_f32 < 0 || out_f32 > 2) return RSVLD_EINVAL;
+    if (out_f32 == 1)
+        hipLaunchKernelGGL(gn_apply_split_kernel<1>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
+                           mod_shift, HW, C1, C2, silu, rpb, mod_stride > 0 ? mod_stride : C);
+    else if (out_f32 == 2)
+        hipLaunchKernelGGL(gn_apply_split_kernel<2>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
                            mod_shift, HW, C1, C2, silu, rpb, mod_stride > 0 ? mod_stride : C);
     else
-        hipLaunchKernelGGL(gn_apply_split_kernel<false>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
+        hipLaunchKernelGGL(gn_apply_split_kernel<0>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
                            mod_shift, HW, C1, C2, silu, rpb, mod_stride > 0 ? mod_stride : C);
     return rsvld_check_launch();
 }
 
-template <bool OUT_F32>
+template <int OUT_F32>
 static void launch_layernorm_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
                                    hipStream_t s) {
     const int chunks_per_lane = (C / 8 + 63) / 64;
@@ -872,8 +880,10 @@ extern "C" int rsvld_layernorm_split(const float* x, void* out, const float* gam
                                      int out_f32, void* stream) {
     if (!x || !out || rows <= 0 || C <= 0 || C % 8 || C > 4096) return RSVLD_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (out_f32) launch_layernorm_split<true>(x, out, gamma, beta, rows, C, eps, s);
-    else launch_layernorm_split<false>(x, out, gamma, beta, rows, C, eps, s);
+    if (out_f32 < 0 || out_f32 > 2) return RSVLD_EINVAL;
+    if (out_f32 == 1) launch_layernorm_split<1>(x, out, gamma, beta, rows, C, eps, s);
+    else if (out_f32 == 2) launch_layernorm_split<2>(x, out, gamma, beta, rows, C, eps, s);
+    else launch_layernorm_split<0>(x, out, gamma, beta, rows, C, eps, s);
     return rsvld_check_launch();
 }
 

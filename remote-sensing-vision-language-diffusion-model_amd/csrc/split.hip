@@ -1095,6 +1095,27 @@ __global__ __launch_bounds__(256) void attn_split_d512_kernel(AttnSplit512Args p
     }
 }
 
+// w [R][Ctot] fp32 (R = Cout * taps) -> fp16 pairs [R][lo | hi]: hi = fp16(w), lo = fp16(w - hi) (RSVLD_F16W2; a weight beyond the fp16
+// range saturates hi and leaves the rest to lo: not a case a trained network has)
+__global__ __launch_bounds__(256) void pack_weight_pairs_kernel(const float* __restrict__ w, f16* __restrict__ o, int64_t items, int C8) {
+    const int C = C8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        float f[8], l[8];
+        ld8f(w + row * C + c, f);
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[e] = (f16)fminf(fmaxf(f[e], -65504.f), 65504.f);
+            l[e] = f[e] - (float)h[e];
+        }
+        f16* d = o + row * (2 * (int64_t)C) + c;
+        *(u32x4*)d = pack8<f16>(l);
+        *(u32x4*)(d + C) = __builtin_bit_cast(u32x4, h);
+    }
+}
+
 static unsigned ew_blocks(int64_t items) {
     int64_t b = cdiv64(items, 256);
     return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -1135,6 +1156,13 @@ extern "C" int rsvld_split_pack_weights(const float* w, void* w3, int64_t Cout, 
     if (!w || !w3 || Cout < 1 || taps < 1 || Ctot < 8 || Ctot % 8) return RSVLD_EINVAL;
     const int64_t items = Cout * taps * (Ctot / 8);
     hipLaunchKernelGGL(split_pack_weights_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, w, (bf16*)w3, items, Ctot / 8);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_pack_weight_pairs(const float* w, void* w2, int64_t Cout, int taps, int Ctot, void* stream) {
+    if (!w || !w2 || Cout < 1 || taps < 1 || Ctot < 8 || Ctot % 8) return RSVLD_EINVAL;
+    const int64_t items = Cout * taps * (Ctot / 8);
+    hipLaunchKernelGGL(pack_weight_pairs_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, w, (f16*)w2, items, Ctot / 8);
     return rsvld_check_launch();
 }
 

@@ -1,0 +1,48 @@
+"""Developer A/B switches of the tools layer (benchmark scripts under tools/, ``bench.py --dev-env``).
+
+The product reads no environment variable for anything that changes what is computed or how it is planned: precision
+compositions are ``ops.SplitPolicy`` arguments of the owning network, launch-plan constants are module attributes of
+``rsvld_amd.ops``.  A tool that wants the old ``RSVLD_*`` switches calls ``apply_env()`` explicitly; nothing calls it on import.
+
+    RSVLD_CONV_TILE / RSVLD_CONV_STAGES / RSVLD_CONV_KSPLIT / RSVLD_CONV_STAGING / RSVLD_HALO_NW /
+    RSVLD_GEMM256_OFF / RSVLD_GEMM256_ONE_TILE   -> ops.TUNE   (rsvld_conv_desc.tune: every combination computes the same function)
+    RSVLD_D64_KERNEL=b|c|p                        -> ops.D64_KERNEL_TUNE (the three bit-identical forms of the d = 64 attention)
+    RSVLD_PROFILE_DETAIL=1                        -> ops.PROFILE_DETAIL (layer shapes in the profiler group names)
+    RSVLD_HALO_MIN_WGS=n                          -> ops.HALO_MIN_WGS
+"""
+import os
+
+from . import _lib as L
+from . import ops
+
+
+def tune_from_env(e=None):
+    e = os.environ if e is None else e
+    t = L.TUNE_TILE.get(e.get("RSVLD_CONV_TILE", ""), 0)
+    if e.get("RSVLD_CONV_STAGES"):
+        t |= (int(e["RSVLD_CONV_STAGES"]) & 7) << L.TUNE_STAGES_SHIFT
+    if e.get("RSVLD_CONV_KSPLIT", "1")[:1] == "0":
+        t |= L.TUNE_NO_KSPLIT
+    if e.get("RSVLD_CONV_STAGING", "")[:1] == "r":
+        t |= L.TUNE_REG_STAGING
+    if e.get("RSVLD_HALO_NW"):
+        t |= L.TUNE_HALO_NW8 if e["RSVLD_HALO_NW"][:1] == "8" else L.TUNE_HALO_NW4
+    if e.get("RSVLD_GEMM256_OFF") is not None:
+        t |= L.TUNE_NO_GEMM256
+    if e.get("RSVLD_GEMM256_ONE_TILE") is not None:
+        t |= L.TUNE_GEMM_ONE_TILE
+    return t
+
+
+def d64_kernel(name):
+    """"b" (four-wave), "c" (ping-pong), "p" (pipelined), "" = the library's choice -> ops.D64_KERNEL_TUNE."""
+    ops.D64_KERNEL_TUNE = {"b": 1, "c": 2, "p": 3}.get(name or "", 0)
+
+
+def apply_env(e=None):
+    e = os.environ if e is None else e
+    ops.TUNE = tune_from_env(e)
+    d64_kernel(e.get("RSVLD_D64_KERNEL", ""))
+    ops.PROFILE_DETAIL = bool(e.get("RSVLD_PROFILE_DETAIL"))
+    if e.get("RSVLD_HALO_MIN_WGS"):
+        ops.HALO_MIN_WGS = int(e["RSVLD_HALO_MIN_WGS"])

@@ -33,8 +33,11 @@ class SR_backbone(DiffusionEngine):
         self.upscale, self.min_size = 1, 256
         self._measure = None   # (stamp, max_steps) while bench.py measures (rsvld_amd.measure.hooks), else None
 
-    def set_precision(self, ae_dtype, diffusion_dtype):
+    def set_precision(self, ae_dtype, diffusion_dtype, policy=None, ae_policy=None):
         """The reference fixes both in the constructor (SR_model.py:28-33); here they can also be switched on a loaded model.
+        ``policy`` / ``ae_policy`` (``ops.SplitPolicy``; "split" only): which layer inputs of the UNet + ControlNet / of the VAE are
+        handed over in fp16 inside the split precision; default ``ops.UNET_POLICY`` (attention operands, to_out and FeedForward
+        inputs) / ``ops.VAE_POLICY`` (none).  An explicit argument, never the environment; ``precision_key()`` names the composition.
         "fp32" (either one) runs that network on the fp32-operand kernel family (csrc/f32.hip) -- the reference without
         autocast, i.e. what its CPU path computes; "bf16" / "fp16" run the fast 16-bit kernels (fp32 accumulation);
         "split" (an addition) keeps fp32 tensors and fp32 arithmetic everywhere except the matrix products, whose operands are
@@ -44,9 +47,20 @@ class SR_backbone(DiffusionEngine):
             raise RuntimeError("fp16 cause NaN in AE")
         self.ae_dtype = {"fp32": torch.float32, "split": torch.float32, "bf16": torch.bfloat16}[ae_dtype]
         self.model.dtype = {"fp32": torch.float32, "split": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[diffusion_dtype]
-        self.model.split = diffusion_dtype == "split"
-        self.first_stage_model.split = ae_dtype == "split"
+        from .. import ops
+        for pol in (policy, ae_policy):
+            if pol is not None and not isinstance(pol, ops.SplitPolicy):
+                raise TypeError("set_precision: policy must be an rsvld_amd.ops.SplitPolicy")
+        self.model.split = (policy or ops.UNET_POLICY) if diffusion_dtype == "split" else None
+        self.first_stage_model.split = (ae_policy or ops.VAE_POLICY) if ae_dtype == "split" else None
         self.first_stage_model.set_compute_dtype(self.ae_dtype)
+        self._precision_names = (ae_dtype, diffusion_dtype)
+
+    def precision_key(self):
+        """(ae_dtype, diffusion_dtype, VAE policy, UNet policy) -- what a captured graph or a bench line has to name."""
+        ae, df = self._precision_names
+        fs, md = self.first_stage_model.split, self.model.split
+        return (ae, df, None if fs is None else fs.key(), None if md is None else md.key())
 
     # ---- first stage ------------------------------------------------------------------------
     @torch.no_grad()

@@ -74,8 +74,8 @@ class ZeroCrossAttn(nn.Module):
         assert self.mask is False
         B, H, W, Cq = x.shape
         n1, n2 = self.norm1, self.norm2
-        xq = ops.group_norm(x, n1.weight, n1.bias, n1.num_groups, n1.eps, planes=True).reshape(B, H * W, Cq)   # feed linears only
-        ctx = ops.group_norm(context, n2.weight, n2.bias, n2.num_groups, n2.eps, planes=True)
+        xq = ops.group_norm(x, n1.weight, n1.bias, n1.num_groups, n1.eps, planes=True, group="qkv").reshape(B, H * W, Cq)   # feed linears only
+        ctx = ops.group_norm(context, n2.weight, n2.bias, n2.num_groups, n2.eps, planes=True, group="qkv")
         ctx = ctx.reshape(B, ctx.shape[1] * ctx.shape[2], ctx.shape[3])
         cache, rt.cache_context_kv = rt.cache_context_kv, False   # the control features change every step
         try:

@@ -12,7 +12,6 @@ dispatch on the tensor's dtype (the VAE under ``ae_dtype: fp32``, the UNet / Con
 import contextlib
 import ctypes as C
 import math
-import os
 
 import torch
 
@@ -64,31 +63,90 @@ def plan_units(n):
 
 
 # ----------------------------------------------------------------------------- split-operand precision mode
-# Inside ``with f32_split(True)`` the matrix products of the fp32-operand family (conv2d / linear / attention on fp32 tensors) run
-# with every operand split into hi + lo bf16 and three 16-bit MFMAs per product (csrc/f32.hip, SPLIT instantiations): ~1e-5
-# relative instead of fp32's 1e-7, at a fraction of the fp32 matrix time.  Set by the owning network (``precision "split"``).
+class SplitPolicy:
+    """What runs at which width inside a network in the "split" precision (fp32 tensors; a matrix product = three bf16 MFMAs on
+    hi + lo operands).  A policy is an ARGUMENT of the owning network (``SR_backbone.set_precision(..., policy=...)``, SR3's
+    ``set_compute_dtype("split", policy=...)``), never the environment; it is part of the hipGraph key and printed by bench.py.
+
+    ``impl``        "planes": the product path (bf16 planes + weight triples through gemm256 / conv_halo / conv_igemm);
+                    "f32": round 3's on-the-fly split inside the fp32 family's simple kernels (an independent implementation of the
+                    same arithmetic, kept for tests and A/B runs).
+    ``f16_inputs``  the layer groups whose INPUT may be rounded to fp16 (11 significant bits) -- each measured against the reference's
+                    CPU runs after 50 + 50 steps and at full depth on the device.  Their weights keep ~22 bits:
+                    the layer runs as fp16 activation x fp16 weight pair [W_lo | W_hi], two MFMAs per product (dtype RSVLD_F16W2).
+                      "attn"      the attention operands q, k, v, P: the 16-bit attention kernels (attn_d64c / attn_d512b)
+                      "attn_out"  the input of ``to_out``: with "attn" it IS the fp16 attention output (no further rounding)
+                      "ff"        the two inputs of a FeedForward: LayerNorm3's output and the GEGLU product
+                      "qkv", "proj", "conv": to_q / to_k / to_v, proj_in / proj_out, the convolutions -- measured, NOT inside the bar
+                    together with "attn" (1.2e-3 / 3.4e-3 on the CPU restatement): accepted by the class for experiments only."""
+
+    __slots__ = ("impl", "f16_inputs")
+    GROUPS = ("attn", "attn_out", "ff", "qkv", "proj", "conv")
+
+    def __init__(self, impl="planes", f16_inputs=("attn", "attn_out", "ff")):
+        if impl not in ("planes", "f32"):
+            raise ValueError(f"SplitPolicy.impl {impl!r}: planes or f32")
+        bad = [g for g in f16_inputs if g not in self.GROUPS]
+        if bad:
+            raise ValueError(f"SplitPolicy.f16_inputs {bad}: one of {self.GROUPS}")
+        self.impl, self.f16_inputs = impl, frozenset(f16_inputs)
+        if self.f16_inputs - {"attn"} and "attn" not in self.f16_inputs:
+            raise ValueError("SplitPolicy: fp16 layer inputs go with fp16 attention operands (\"attn\")")
+        if self.f16_inputs and impl != "planes":
+            raise ValueError("SplitPolicy: fp16 layer inputs exist in the product path (impl \"planes\") only")
+
+    def key(self):
+        return (self.impl, tuple(sorted(self.f16_inputs)))
+
+    def describe(self):
+        return {"impl": self.impl, "f16_inputs": sorted(self.f16_inputs)}
+
+    def __eq__(self, o):
+        return isinstance(o, SplitPolicy) and self.key() == o.key()
+
+    def __hash__(self):
+        return hash(self.key())
+
+    def __repr__(self):
+        return f"SplitPolicy(impl={self.impl!r}, f16_inputs={sorted(self.f16_inputs)})"
+
+
+UNET_POLICY = SplitPolicy()                                   # the UNets / ControlNet of Stage 2
+ALL_SPLIT = SplitPolicy(f16_inputs=())                        # every product in three MFMAs, attention in the split kernels
+VAE_POLICY = ALL_SPLIT                                        # the VAE (its single-head attentions are a third of the Stage-2 distance in fp16)
+
+# Inside ``with f32_split(policy)`` the matrix products of fp32 tensors run in the split precision under that policy
+# (``True`` = UNET_POLICY, ``False`` / ``None`` = off).  Set by the owning network around its forward.
+_POLICY = None
 _F32_SPLIT = False
 
 
 @contextlib.contextmanager
 def f32_split(on):
-    global _F32_SPLIT
-    old, _F32_SPLIT = _F32_SPLIT, bool(on)
+    global _POLICY, _F32_SPLIT
+    old = _POLICY
+    _POLICY = UNET_POLICY if on is True else (on if isinstance(on, SplitPolicy) else None)
+    _F32_SPLIT = _POLICY is not None
     try:
         yield
     finally:
-        _F32_SPLIT = old
-
-
-# Which kernels run the split mode.  "planes" (round 4, default): the product path -- bf16 planes + weight triples through the tuned
-# 16-bit kernels (gemm256, conv_halo, conv_igemm with dtype RSVLD_SPLIT), the fused split attention for d = 64, attention as two
-# split GEMMs + a row softmax otherwise.  "f32": round 3's on-the-fly split inside the fp32 family's simple kernels (csrc/f32.hip),
-# kept as an independent implementation of the same arithmetic for tests and A/B runs.
-SPLIT_IMPL = os.environ.get("RSVLD_SPLIT_IMPL", "planes")
+        _POLICY = old
+        _F32_SPLIT = _POLICY is not None
 
 
 def _split_fast():
-    return _F32_SPLIT and SPLIT_IMPL == "planes"
+    return _POLICY is not None and _POLICY.impl == "planes"
+
+
+def precision_token():
+    """Hashable name of the precision the current call runs in (None outside a split-precision network): cached intermediate tensors
+    (the text context's K | V) are keyed on it."""
+    return None if _POLICY is None else _POLICY.key()
+
+
+def f16_group(group):
+    """Does the current policy hand the inputs of layer group ``group`` over as fp16?"""
+    return group is not None and _split_fast() and group in _POLICY.f16_inputs
 
 
 class Planes:
@@ -187,27 +245,9 @@ def maybe_planes(x):
     return x
 
 
-def _tune_from_env():
-    """Developer A/B switches -> rsvld_conv_desc.tune.  The environment is read HERE, once, by the Python tools layer;
-    the C ABI itself reads no environment (it is stateless)."""
-    e = os.environ
-    t = L.TUNE_TILE.get(e.get("RSVLD_CONV_TILE", ""), 0)
-    if e.get("RSVLD_CONV_STAGES"):
-        t |= (int(e["RSVLD_CONV_STAGES"]) & 7) << L.TUNE_STAGES_SHIFT
-    if e.get("RSVLD_CONV_KSPLIT", "1")[:1] == "0":
-        t |= L.TUNE_NO_KSPLIT
-    if e.get("RSVLD_CONV_STAGING", "")[:1] == "r":
-        t |= L.TUNE_REG_STAGING
-    if e.get("RSVLD_HALO_NW"):
-        t |= L.TUNE_HALO_NW8 if e["RSVLD_HALO_NW"][:1] == "8" else L.TUNE_HALO_NW4
-    if e.get("RSVLD_GEMM256_OFF") is not None:
-        t |= L.TUNE_NO_GEMM256
-    if e.get("RSVLD_GEMM256_ONE_TILE") is not None:
-        t |= L.TUNE_GEMM_ONE_TILE
-    return t
-
-
-TUNE = _tune_from_env()
+# Developer A/B overrides -> rsvld_conv_desc.tune (every combination computes the same function).  0 = the library's own choice.
+# Set by the tools layer (rsvld_amd.devtools.apply_env); neither this module nor the C ABI reads the environment.
+TUNE = 0
 
 
 # ----------------------------------------------------------------------------- launch profiling
@@ -239,7 +279,7 @@ class LaunchProfiler:
 
 
 _PROFILER = None
-PROFILE_DETAIL = bool(os.environ.get("RSVLD_PROFILE_DETAIL"))   # tools: append the layer shape to the profiler group name
+PROFILE_DETAIL = False   # tools (devtools.apply_env / bench.py --profile-detail): append the layer shape to the profiler group name
 
 
 def set_profiler(p):
@@ -257,16 +297,14 @@ def _launch(name, flops, nbytes, fn):
 class PackedConv:
     """K-major 16-bit weights of a Conv2d / Linear: ``w[Cout_p, KH*KW*Cin_p]``, bias fp32."""
 
-    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu", "w3")
+    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu", "w3", "w2")
 
     def __init__(self, w, bias, cin, cout, cin_p, cout_p, kh, kw, geglu=False):
         self.w, self.bias = w, bias
         self.w3 = None     # split product path: bf16 triples [Cout_p][KH*KW][W_hi | W_lo | W_hi], packed on first use from the fp32 ``w``
+        self.w2 = None     # fp16 pairs [Cout_p][KH*KW][W_lo | W_hi] (dtype RSVLD_F16W2: fp16 activations), likewise
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.kh, self.kw, self.geglu = kh, kw, geglu
-
-
-_EXP_W16 = {"f16": torch.float16, "bf16": torch.bfloat16}.get(os.environ.get("RSVLD_EXP_W16", ""))   # measurement only
 
 
 def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
@@ -280,8 +318,6 @@ def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
     # (the re-layout runs where the master weights live: on the device for a loaded network -- no 15 GB round trip over PCIe and no
     #  host-side permute of 3.9 B values when a precision is switched -- on the host for weights that are still there)
     w = weight.detach().to(torch.float32)
-    if dtype == torch.float32 and _EXP_W16 is not None:   # precision experiment (tools/tolerance_check.py --w16): weights rounded to 16 bits
-        w = w.to(_EXP_W16).to(torch.float32)
     if w.dim() == 2:
         w = w[:, :, None, None]
     cout, cin, kh, kw = w.shape
@@ -315,12 +351,14 @@ def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
 
 # ----------------------------------------------------------------------------- conv / linear
 USE_HALO = True      # route eligible 3x3 convs through conv_halo.hip (set False to A/B against the gather kernel)
-HALO_MIN_WGS = int(os.environ.get("RSVLD_HALO_MIN_WGS", "256"))   # below one workgroup per CU the 8x32-pixel halo tile under-fills the chip (measured 130 vs
+HALO_MIN_WGS = 256   # below one workgroup per CU the 8x32-pixel halo tile under-fills the chip (measured 130 vs
                      # 334 TFLOP/s on 32x32 maps): such layers use the 64x128 gather kernel with the 3-stage ring
+SPLIT_HALO_MIN_WGS = 128   # the split precision: its gather kernel runs at 190-200 effective TFLOP/s where the halo kernel does 385-400, so the
+                     # halo tile pays from half a chip of workgroups per planning unit (the 86 x 86 x 512 tiles of the tiled VAE: 132)
 
 
 def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, residual=None,
-           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False, out_planes=False):
+           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False, out_planes=False, out_group=None):
     """NHWC convolution.  ``pad`` = int or (top, left, bottom, right).
 
     ``norm=(gamma, beta, groups, eps, silu)``: a GroupNorm(+SiLU) over the input ([x | x2]) precedes the
@@ -332,14 +370,26 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     (``_gn_part``), so the consumer's ``norm=`` needs no statistics pass at all.
 
     ``out_planes=True`` (honoured in the split precision only, ignored otherwise): the output only feeds another matrix
-    product (q|k|v, GEGLU, ...) and is returned as ``Planes``."""
+    product (q|k|v, GEGLU, ...) and is returned as ``Planes`` -- or as fp16 when the policy hands the inputs of its consumer's
+    layer group ``out_group`` over in fp16 (``SplitPolicy.f16_inputs``).
+
+    fp16 ``x`` with weights packed in fp32 (a network in the split precision whose policy rounds this layer's input to fp16, or SR3's
+    compute dtype "w2"): dtype RSVLD_F16W2, fp16 activation x fp16 weight pair [W_lo | W_hi], two MFMAs per product; in a
+    split-precision network the output is fp32 (+ fp32 residual) unless ``out_planes`` asks for the fp16 hand-over."""
     _need_gpu(x, x2, pc.w, rowvec, residual)
     if isinstance(x, Planes) or (x.dtype == torch.float32 and _split_fast()):
         return _conv2d_split(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
-                             act=act, alpha=alpha, beta=beta, norm=norm, stats=stats, out_planes=out_planes)
+                             act=act, alpha=alpha, beta=beta, norm=norm, stats=stats, out_planes=out_planes, out_group=out_group)
     if x.dtype == torch.float32:
         return _conv2d_f32(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
                            act=act, alpha=alpha, beta=beta, norm=norm)
+    w2 = pc.w.dtype == torch.float32         # fp32 masters under a 16-bit activation: the weight-pair form
+    if w2:
+        if x.dtype != torch.float16:
+            raise L.RsvldError("conv2d: fp32-packed weights take fp16 activations (RSVLD_F16W2), fp32 tensors or planes")
+        if _split_fast():
+            out_f32 = not out_planes
+    wt = _w2(pc) if w2 else pc.w
     B, H, W, Cin = x.shape
     Cin2 = 0 if x2 is None else x2.shape[-1]
     if Cin + Cin2 != pc.cin_p:
@@ -358,21 +408,23 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     out = torch.empty((B, Ho, Wo, c_out), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise L.RsvldError("conv2d: inputs must be contiguous NHWC")
-    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()):
-        raise L.RsvldError("conv2d: residual must match the output shape")
+    if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()
+                                 or (w2 and residual.dtype != out.dtype)):
+        raise L.RsvldError("conv2d: residual must match the output shape (weight-pair form: and the output's type)")
     rv_stride = 0
     if rowvec is not None:
         if tuple(rowvec.shape) != (B, pc.cout_p) or rowvec.dtype != torch.float32 or rowvec.stride(1) != 1:
             raise L.RsvldError("conv2d: rowvec must be fp32 [B, Cout] with unit inner stride")
         rv_stride = rowvec.stride(0) if B > 1 else pc.cout_p
     d = L.ConvDesc(
-        x=x.data_ptr(), x2=None if x2 is None else x2.data_ptr(), w=pc.w.data_ptr(),
+        x=x.data_ptr(), x2=None if x2 is None else x2.data_ptr(), w=wt.data_ptr(),
         bias=None if pc.bias is None else pc.bias.data_ptr(),
         rowvec=None if rowvec is None else rowvec.data_ptr(),
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride,
-        pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=_dt(x), out_f32=int(out_f32),
+        pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=L.F16W2 if w2 else _dt(x), out_f32=int(out_f32),
         act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=_PLAN_DIV, tune=TUNE)
+    sfx = "_w2" if w2 else ""
     lib = L.load()
     halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
     Bp = -(-B // _PLAN_DIV)            # batch rows of one planning unit: every plan decision below uses Bp / Mp
@@ -383,11 +435,11 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         gamma, nbeta, groups, eps, silu = norm
         xn = group_norm(x, gamma, nbeta, groups, eps, x2=x2, silu=silu)
         return conv2d(xn, pc, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
-                      out_f32=out_f32, act=act, alpha=alpha, beta=beta, stats=stats)
+                      out_f32=out_f32, act=act, alpha=alpha, beta=beta, stats=stats, out_planes=out_planes)
     esz = x.element_size()
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
-    nbytes = (x.numel() + (0 if x2 is None else x2.numel()) + pc.w.numel()) * esz + out.numel() * out.element_size() \
-        + (0 if residual is None else residual.numel() * esz)
+    nbytes = (x.numel() + (0 if x2 is None else x2.numel()) + wt.numel()) * esz + out.numel() * out.element_size() \
+        + (0 if residual is None else residual.numel() * residual.element_size())
     if halo:
         ab, silu = None, 0
         part1 = getattr(x, "_gn_part", None)
@@ -407,9 +459,9 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
                     lambda: L.check(lib.rsvld_groupnorm_scale_shift(_ptr(x), _ptr(x2), _ptr(gamma), _ptr(nbeta), _ptr(ab), B,
                                                                     H * W, Cin, Cin2, groups, eps, _dt(x), _ptr(ws), _stream()),
                                     "rsvld_groupnorm_scale_shift"))
-        name = "conv_halo_64" if pc.cout_p <= 64 else "conv_halo_128"
+        name = ("conv_halo_64" if pc.cout_p <= 64 else "conv_halo_128") + sfx
         part_out = None
-        if stats and not out_f32:
+        if stats and (w2 or not out_f32):
             ntiles = ((Ho + 7) // 8) * ((Wo + 31) // 32)
             part_out = torch.empty((B, ntiles, pc.cout_p, 2), device=x.device, dtype=torch.float32)
         _launch(name + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes, lambda: L.check(lib.rsvld_conv3x3_halo_nhwc(C.byref(d), _ptr(ab), int(silu), _ptr(part_out),
@@ -420,8 +472,8 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     M = B * Ho * Wo
     Mp = -(-M // _PLAN_DIV)
     if (pc.kh == 1 and pc.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not upsample and x2 is None and rowvec is None
-            and not out_f32 and Cin % 32 == 0 and pc.cout_p >= 256 and Mp >= 4096
-            and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128 and 256 * Cin * 2 < 2 ** 32
+            and (w2 or not out_f32) and Cin % 32 == 0 and pc.cout_p >= 256 and Mp >= 4096
+            and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128 and 256 * Cin * (4 if w2 else 2) < 2 ** 32
             and not (TUNE & L.TUNE_NO_GEMM256)):   # mirrors rsvld_gemm256_try in csrc/gemm.hip (profiler label only)
         variant = "gemm_256x256"
     elif pc.cout_p <= 32:
@@ -432,7 +484,9 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         wg128 = ((Mp + 127) // 128) * ((pc.cout_p + 127) // 128)
         wg64 = ((Mp + 63) // 64) * ((pc.cout_p + 127) // 128)
         variant = "conv_igemm_64x64" if wg64 < 256 else ("conv_igemm_64x128" if wg128 < 256 else "conv_igemm_128x128")
-    _launch(variant + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes, lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
+    _launch(variant + sfx + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes, lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
+    if out_f32 and out.dim() == 4:
+        out._nhwc = True     # an fp32 4-d tensor is otherwise taken for NCHW by the VAE's input adapter
     return out
 
 
@@ -493,6 +547,18 @@ def _w3(pc):
     return pc.w3
 
 
+def _w2(pc):
+    """fp16 weight pairs [W_lo | W_hi] of a PackedConv (fp32 K-major ``w``), packed once on the device."""
+    if pc.w2 is None:
+        if pc.w.dtype != torch.float32:
+            raise L.RsvldError("weight pairs: weights must be packed in fp32 (the owning network's compute_dtype)")
+        taps = pc.kh * pc.kw
+        w2 = torch.empty((pc.cout_p, taps * 2 * pc.cin_p), device=pc.w.device, dtype=torch.float16)
+        L.check(L.load().rsvld_pack_weight_pairs(_ptr(pc.w), _ptr(w2), pc.cout_p, taps, pc.cin_p, _stream()), "rsvld_pack_weight_pairs")
+        pc.w2 = w2
+    return pc.w2
+
+
 def _gn_scale_shift_f32(x, x2, gamma, nbeta, groups, eps):
     """(scale, shift) fp32 ``[B, C1+C2, 2]`` of a GroupNorm over fp32 NHWC ``[x | x2]``: from the producers' epilogue partials when
     every source carries them (no pass over the tensors), else one statistics pass."""
@@ -516,7 +582,7 @@ def _gn_scale_shift_f32(x, x2, gamma, nbeta, groups, eps):
     return ab
 
 
-def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None):
+def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None, f16=False):
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
     Cc = C1 + C2
@@ -526,13 +592,18 @@ def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None):
         if (mod_shift.stride(-2) != mod_stride or mod_scale1p.stride(-1) != 1 or mod_shift.stride(-1) != 1
                 or mod_scale1p.dtype != torch.float32 or mod_shift.dtype != torch.float32):
             raise L.RsvldError("group_norm: modulation tensors must be fp32, share a row stride and be channel-contiguous")
-    if planes:
+    f16 = f16 and planes          # the fp16 hand-over replaces a planes output only
+    if f16:
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float16)
+    elif planes:
         out = torch.empty((B, H, W, 2, Cc), device=x.device, dtype=torch.bfloat16)
     else:
         out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
-    _launch("groupnorm_apply_split", 0.0, 8.0 * B * H * W * Cc, lambda: L.check(L.load().rsvld_groupnorm_apply_split(
+    _launch("groupnorm_apply_split", 0.0, (6.0 if f16 else 8.0) * B * H * W * Cc, lambda: L.check(L.load().rsvld_groupnorm_apply_split(
         _ptr(x), _ptr(x2), _ptr(out), _ptr(ab), _ptr(mod_scale1p), _ptr(mod_shift), mod_stride, B, H * W, C1, C2, int(silu),
-        int(not planes), _stream()), "rsvld_groupnorm_apply_split"))
+        2 if f16 else int(not planes), _stream()), "rsvld_groupnorm_apply_split"))
+    if f16:
+        return out
     if planes:
         return Planes(out)
     out._nhwc = True
@@ -545,9 +616,11 @@ def _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample):
     return f" [{B}x{Ho}x{Wo} {Cin}+{Cin2}->{pc.cout_p} k{pc.kh} s{stride}{' up' if upsample else ''}]"
 
 
-def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm, stats, out_planes):
+def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm, stats, out_planes, out_group=None):
     """The split-operand product path of conv2d / linear: bf16 planes in (split here when the caller hands fp32), weight triples,
-    the 16-bit kernels with dtype RSVLD_SPLIT; fp32 (or Planes) out, fp32 residual."""
+    the 16-bit kernels with dtype RSVLD_SPLIT; fp32 (or Planes, or -- a 1x1 layer whose consumer group takes fp16 -- fp16) out,
+    fp32 residual."""
+
     if norm is not None:      # GroupNorm(+SiLU) over [x | x2]: its own apply pass writes ONE planes tensor (no concat, no fp32 copy)
         gamma, nbeta, groups, eps, silu = norm
         if isinstance(x, Planes) or isinstance(x2, Planes):
@@ -576,7 +649,11 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
         if isinstance(residual, Planes) or residual.dtype != torch.float32 or tuple(residual.shape) != (B, Ho, Wo, c_out) \
                 or not residual.is_contiguous():
             raise L.RsvldError("conv2d (split): residual must be fp32 and match the output shape")
-    if out_planes:
+    # fp16 hand-over: a Linear / 1x1 layer (the implicit-GEMM kernels write it) whose consumer's layer group takes fp16 inputs
+    out_f16 = bool(out_planes and f16_group(out_group) and pc.kh == 1 and pc.kw == 1 and stride == 1 and x2 is None and not upsample)
+    if out_f16:
+        out = torch.empty((B, Ho, Wo, c_out), device=x.device, dtype=torch.float16)
+    elif out_planes:
         out = torch.empty((B, Ho, Wo, 2, c_out), device=x.device, dtype=torch.bfloat16)
     else:
         out = torch.empty((B, Ho, Wo, c_out), device=x.device, dtype=torch.float32)
@@ -591,17 +668,17 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
         bias=None if pc.bias is None else pc.bias.data_ptr(), rowvec=None if rowvec is None else rowvec.data_ptr(),
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo,
-        upsample=int(upsample), dtype=L.SPLIT, out_f32=int(not out_planes), act=act, alpha=alpha, beta=beta,
+        upsample=int(upsample), dtype=L.SPLIT, out_f32=2 if out_f16 else int(not out_planes), act=act, alpha=alpha, beta=beta,
         rowvec_stride=rv_stride, plan_div=_PLAN_DIV, tune=TUNE)
     lib = L.load()
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
-    nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + out.numel() / (2 if out_planes else 1)
+    nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + out.numel() / (2 if (out_planes or out_f16) else 1)
                     + (0 if residual is None else residual.numel())) + 6.0 * pc.w.numel()
     Bp = -(-B // _PLAN_DIV)
     halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
     if halo:
         bn = 64 if pc.cout_p <= 64 else 128
-        halo = Bp * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= HALO_MIN_WGS
+        halo = Bp * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= SPLIT_HALO_MIN_WGS
     if halo:
         part_out = None
         if stats and not out_planes:
@@ -619,31 +696,35 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
                 and 256 * Cin * 6 < 2 ** 32 and not (TUNE & L.TUNE_NO_GEMM256))   # mirrors rsvld_gemm256_try
         _launch(("gemm_256x256_split" if g256 else "conv_igemm_split") + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes,
                 lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
+    if out_f16:
+        return out
     if out_planes:
         return Planes(out)
     out._nhwc = True
     return out
 
 
-def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0, out_planes=False):
+def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0, out_planes=False, out_group=None):
     """``[..., Cin] -> [..., Cout]`` on token-major tensors (a 1x1 conv over rows)."""
     shp = x.shape
     rows = x.numel() // shp[-1]
     res = None if residual is None else residual.reshape(1, 1, rows, residual.shape[-1])
-    y = conv2d(x.reshape(1, 1, rows, shp[-1]), pc, pad=0, residual=res, act=act, alpha=alpha, beta=beta, out_planes=out_planes)
+    y = conv2d(x.reshape(1, 1, rows, shp[-1]), pc, pad=0, residual=res, act=act, alpha=alpha, beta=beta, out_planes=out_planes,
+               out_group=out_group)
     return y.reshape(*shp[:-1], y.shape[-1])
 
 
 # ----------------------------------------------------------------------------- norms
-def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None, planes=False):
+def group_norm(x, gamma, beta, groups, eps, *, x2=None, silu=False, mod_scale1p=None, mod_shift=None, planes=False, group=None):
     """GroupNorm(+SiLU) over NHWC ``x`` (or the channel concat [x | x2]).  ``mod_scale1p`` / ``mod_shift``
     (ZeroSFT) may be channel slices of one stacked tensor: only their row stride must agree.
-    ``planes=True`` (split precision only, ignored otherwise): the result only feeds a matrix product -> ``Planes``."""
+    ``planes=True`` (split precision only, ignored otherwise): the result only feeds a matrix product -> ``Planes``, or fp16 when
+    the policy hands the inputs of that product's layer group ``group`` over in fp16."""
     if x.dtype == torch.float32 and _split_fast() and not isinstance(x, Planes):
         _need_gpu(x, x2, gamma, beta)
         ab = _gn_scale_shift_f32(x, x2, gamma, beta, groups, eps)
         return _gn_apply_split(x, x2, ab, silu, planes, as_f32(mod_scale1p) if mod_scale1p is not None else None,
-                               as_f32(mod_shift) if mod_shift is not None else None)
+                               as_f32(mod_shift) if mod_shift is not None else None, f16=f16_group(group))
     mod_stride = 0
     if mod_scale1p is not None:
         mod_stride = mod_scale1p.stride(-2)
@@ -734,21 +815,25 @@ def group_norm_apply(x, stats, gamma, beta, groups, eps, *, x2=None, silu=False,
     return y
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, planes=False):
-    """``planes=True`` (split precision only, ignored otherwise): the result only feeds matrix products -> ``Planes``."""
+def layer_norm(x, gamma, beta, eps=1e-5, planes=False, group=None):
+    """``planes=True`` (split precision only, ignored otherwise): the result only feeds matrix products -> ``Planes``, or fp16 when
+    the policy hands the inputs of those products' layer group ``group`` over in fp16."""
     _need_gpu(x, gamma, beta)
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     if x.dtype == torch.float32 and _split_fast():
         if not x.is_contiguous():
             raise L.RsvldError("layer_norm (split): contiguous rows expected")
-        if planes:
+        f16 = planes and f16_group(group)
+        if f16:
+            y = torch.empty(x.shape, device=x.device, dtype=torch.float16)
+        elif planes:
             y = torch.empty(tuple(x.shape[:-1]) + (2, Cc), device=x.device, dtype=torch.bfloat16)
         else:
             y = torch.empty_like(x)
-        _launch("layernorm_split", 0.0, 8.0 * x.numel(), lambda: L.check(L.load().rsvld_layernorm_split(
-            _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, int(not planes), _stream()), "rsvld_layernorm_split"))
-        return Planes(y) if planes else y
+        _launch("layernorm_split", 0.0, (6.0 if f16 else 8.0) * x.numel(), lambda: L.check(L.load().rsvld_layernorm_split(
+            _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), rows, Cc, eps, 2 if f16 else int(not planes), _stream()), "rsvld_layernorm_split"))
+        return y if f16 else (Planes(y) if planes else y)
     y = torch.empty_like(x)
     if x.dtype == torch.float32:
         if not x.is_contiguous():
@@ -762,14 +847,16 @@ def layer_norm(x, gamma, beta, eps=1e-5, planes=False):
 
 
 # ----------------------------------------------------------------------------- attention
-def attention(q, k, v, heads, scale=None, split_attn=None):
+def attention(q, k, v, heads, scale=None):
     """q ``[B, Nq, heads*D]``, k/v ``[B, Nk, heads*D]`` (views with a token stride are fine, e.g.
     slices of a fused qkv tensor) -> ``[B, Nq, heads*D]`` contiguous.
-    ``split_attn`` (split precision only): ``"split"`` keeps THIS attention in the split kernels whatever ``SPLIT_ATTN`` says -- the
-    VAE's single-head attentions pass it: they are a rounding error of the image's time and a third of the mode's Stage-2 distance
-    from the reference when run in fp16 (4.4e-4 -> 3.0e-4 max, 5.6e-5 -> 4.3e-5 mean after 50 steps)."""
+    In the split precision the policy decides (``SplitPolicy.f16_inputs``): with "attn" the operands are fp16 (handed over as fp16 by
+    their producers, or converted here) and the 16-bit kernels run; the result is fp16 when "attn_out" is set (its consumer then runs
+    as fp16 x weight pairs) and planes otherwise.  Without "attn" (the VAE's policy: its single-head attentions are a rounding error
+    of the image's time and a third of the mode's Stage-2 distance from the reference when run in fp16, 4.4e-4 -> 3.0e-4 max after
+    50 steps) the fused split kernels run on planes."""
     if any(isinstance(t, Planes) for t in (q, k, v)) or (q.dtype == torch.float32 and _split_fast()):
-        return _attention_split(q, k, v, heads, scale, split_attn or SPLIT_ATTN)
+        return _attention_split(q, k, v, heads, scale)
     _need_gpu(q, k, v)
     B, Nq, HD = q.shape
     Nk = k.shape[1]
@@ -794,8 +881,7 @@ def attention(q, k, v, heads, scale=None, split_attn=None):
         return out
     ws_bytes = lib.rsvld_attention_ws_bytes(B, heads, Nq, Nk, D, _PLAN_DIV)   # split-KV partials (D = 512, small grids)
     ws = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8) if ws_bytes > 0 else None
-    # developer A/B switch (read here, by the Python tools layer: the C ABI reads no environment): RSVLD_D64_KERNEL=b|c|p
-    tune = {"b": 1, "c": 2, "p": 3}.get(os.environ.get("RSVLD_D64_KERNEL", ""), 0)
+    tune = D64_KERNEL_TUNE
     # (profiler group: the short cross-attention launches -- 77 text keys -- are a different kernel and a different regime than
     #  the self-attention of the same layer: kept apart so that the roofline of the dominant group describes ONE kind of launch)
     _launch(f"attention_d{D}" + ("_cross" if (D == 64 and Nk != Nq) else ""), flops, nbytes, lambda: L.check(
@@ -803,11 +889,14 @@ def attention(q, k, v, heads, scale=None, split_attn=None):
                                   q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                                   out.stride(0), out.stride(1), scale, _dt(q), _PLAN_DIV, _ptr(ws), _stream(), tune),
         "rsvld_attention"))
+    if _split_fast() and not f16_group("attn_out"):   # a split-precision network whose to_out wants planes (exact: 11 bits fit hi + lo)
+        return _f16_to_planes(out)
     return out
 
 
-SPLIT_D512_FUSED_MIN = int(os.environ.get("RSVLD_SPLIT_D512_FUSED_MIN", "2048"))   # query rows from which the fused d = 512 kernel runs (64 per workgroup)
-SPLIT_ATTN_S_BYTES = int(os.environ.get("RSVLD_SPLIT_ATTN_S_BYTES", str(32 << 30)))   # fp32 score block of the GEMM form (P planes: as much again)
+D64_KERNEL_TUNE = 0              # developer A/B (devtools.d64_kernel): 1 / 2 / 3 = force attn_d64b / attn_d64c / attn_d64p (bit-identical forms)
+SPLIT_D512_FUSED_MIN = 2048      # query rows from which the fused split d = 512 kernel runs (64 per workgroup)
+SPLIT_ATTN_S_BYTES = 32 << 30    # fp32 score block of the GEMM form (P planes: as much again)
 
 
 def _split_gemm(xt, w3, out, M, K, N, out_f32, name):
@@ -818,14 +907,6 @@ def _split_gemm(xt, w3, out, M, K, N, out_f32, name):
                    dtype=L.SPLIT, out_f32=int(out_f32), act=L.ACT_NONE, alpha=1.0, beta=1.0, rowvec_stride=0, plan_div=1, tune=TUNE)
     _launch(name, 2.0 * M * K * N, 4.0 * M * K + 6.0 * N * K + 4.0 * M * N,
             lambda: L.check(L.load().rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
-
-
-# How the split mode runs its attentions.  "f16" (default): the operands leave the planes as fp16 and the 16-BIT attention kernels run
-# (attn_d64c / attn_d512b at 1 100-1 240 TFLOP/s instead of the three-MFMA kernels at 400-440 effective) -- every other product of the
-# network stays in the split precision.  Measured against the reference's CPU runs after 50 + 50 steps: see DESIGN.md (the attention
-# operands are the one place where 11 significant bits are enough: rounding ONLY them costs 4e-5 in Stage 1 and 2.5e-4 in Stage 2 on the
-# CPU restatement, where rounding the weights costs 2e-3 and every activation 3e-3).  "split": the fused split attention kernels.
-SPLIT_ATTN = os.environ.get("RSVLD_SPLIT_ATTN", "f16")
 
 
 def _planes_to_f16(x):
@@ -851,12 +932,16 @@ def _f16_to_planes(x):
     return Planes(t)
 
 
-def _attention_split(q, k, v, heads, scale, mode=None):
-    if (mode or SPLIT_ATTN) == "f16" and q.shape[-1] % 8 == 0:
+def _attention_split(q, k, v, heads, scale):
+    """Planes / fp32 operands in a split-precision network.  Policy "attn": the operands leave the planes as fp16 and the 16-BIT attention
+    kernels run (attn_d64c / attn_d512b at 1 100-1 240 TFLOP/s instead of the three-MFMA kernels at 400-440 effective; measured against
+    the reference's CPU runs after 50 + 50 steps, rounding ONLY q, k, v, P costs 4e-5 in Stage 1 and 2.5e-4 in Stage 2, where rounding
+    the weights costs 2e-3 and every activation 3e-3: DESIGN.md).  Otherwise: the fused split attention kernels."""
+    if f16_group("attn") and q.shape[-1] % 8 == 0:
         shared = k is v
         q16, k16 = _planes_to_f16(q), _planes_to_f16(k)
         v16 = k16 if shared else _planes_to_f16(v)
-        return _f16_to_planes(attention(q16, k16, v16, heads, scale))
+        return attention(q16, k16, v16, heads, scale)     # (-> fp16 or planes, by "attn_out")
     return _attention_split_kernels(q, k, v, heads, scale)
 
 

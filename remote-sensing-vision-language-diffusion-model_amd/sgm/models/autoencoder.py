@@ -40,7 +40,7 @@ class AutoencoderKL(HipNet):
 
     def moments(self, x, encoder=None):
         """posterior parameters, fp32 NHWC ``[B, h, w, 8]`` (mean | logvar)."""
-        with ops.f32_split(self.split and self.compute_dtype == torch.float32):
+        with ops.f32_split(self.split if self.compute_dtype == torch.float32 else None):
             h = (encoder or self.encoder)(x)
             return ops.conv2d(h, self.pk(self.quant_conv), pad=0, out_f32=True)
 
@@ -50,7 +50,7 @@ class AutoencoderKL(HipNet):
 
     def decode(self, z, **decoder_kwargs):
         """z fp32 NCHW ``[B,4,h,w]`` -> fp32 NCHW image ``[B,3,8h,8w]``."""
-        with ops.f32_split(self.split and self.compute_dtype == torch.float32):
+        with ops.f32_split(self.split if self.compute_dtype == torch.float32 else None):
             zin = ops.nchw_to_nhwc(z.float().contiguous(), self.compute_dtype)
             h = ops.conv2d(zin, self.pk(self.post_quant_conv), pad=0)
             dec = self.decoder(h, **decoder_kwargs)

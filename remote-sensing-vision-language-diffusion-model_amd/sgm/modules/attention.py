@@ -46,7 +46,9 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim))
 
     def run(self, rt, x_norm, residual):
-        g = ops.linear(x_norm, rt.pk(self.net[0].proj, "geglu", geglu=True), act=ACT_GEGLU, out_planes=True)   # feeds a linear only
+        # (split precision: ``x_norm`` arrives as planes, or as fp16 when the policy's "ff" group is set -- then both layers run as
+        #  fp16 activation x weight pair, the GEGLU product stays fp16 and only the residual stream is fp32)
+        g = ops.linear(x_norm, rt.pk(self.net[0].proj, "geglu", geglu=True), act=ACT_GEGLU, out_planes=True, out_group="ff")   # feeds a linear only
         return ops.linear(g, rt.pk(self.net[2]), residual=residual)
 
 
@@ -66,21 +68,21 @@ class CrossAttention(nn.Module):
         """x ``[B,N,C]`` (already normalised), context ``[B,M,Cc]`` or None -> to_out(attn)*alpha + residual."""
         inner = self.heads * self.dim_head
         if context is None:
-            qkv = ops.linear(x, rt.pk_cat([self.to_q, self.to_k, self.to_v], "qkv"), out_planes=True)   # feeds the attention only
+            qkv = ops.linear(x, rt.pk_cat([self.to_q, self.to_k, self.to_v], "qkv"), out_planes=True, out_group="attn")   # feeds the attention only
             q, k, v = qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:]
         else:
-            q = ops.linear(x, rt.pk(self.to_q), out_planes=True)
+            q = ops.linear(x, rt.pk(self.to_q), out_planes=True, out_group="attn")
             rows = None
             if isinstance(context, RowSubset):   # a sub-batch of a cached context: project the full one, pick rows
                 context, rows = context.full, context.rows
             # valid only while the very same tensor object (held alive here) is passed, unmodified
             # (keyed on the precision too: fp32 and split share one pack dictionary, and a cached K/V is a tensor of ONE of them)
-            ckey = ("ctx_kv", id(self), ops._split_fast())
+            ckey = ("ctx_kv", id(self), ops.precision_token())
             ent = rt._pk.get(ckey) if rt.cache_context_kv else None
             if ent is not None and ent[0] is context and ent[1] == context._version:
                 kv = ent[2]
             else:
-                kv = ops.linear(context, rt.pk_cat([self.to_k, self.to_v], "kv"), out_planes=True)
+                kv = ops.linear(context, rt.pk_cat([self.to_k, self.to_v], "kv"), out_planes=True, out_group="attn")
                 if rt.cache_context_kv:
                     rt._pk[ckey] = (context, context._version, kv)
             if rows is not None:
@@ -109,11 +111,11 @@ class BasicTransformerBlock(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
 
     def run(self, rt, x, context=None):
-        n = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, planes=True)
+        n = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, planes=True, group="qkv")
         x = self.attn1.run(rt, n, context if self.disable_self_attn else None, residual=x)
-        n = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, planes=True)
+        n = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, planes=True, group="qkv")
         x = self.attn2.run(rt, n, context, residual=x)
-        n = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps, planes=True)
+        n = ops.layer_norm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps, planes=True, group="ff")
         return self.ff.run(rt, n, residual=x)
 
 
@@ -146,7 +148,7 @@ class SpatialTransformer(nn.Module):
         """x NHWC ``[B,H,W,C]`` -> same shape."""
         B, H, W, Cc = x.shape
         contexts = context if isinstance(context, list) else [context]
-        h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, planes=True)
+        h = ops.group_norm(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, planes=True, group="proj")
         h = ops.linear(h.reshape(B, H * W, Cc), rt.pk(self.proj_in))
         for i, blk in enumerate(self.transformer_blocks):
             h = blk.run(rt, h, contexts[i if len(contexts) > 1 else 0])

@@ -104,7 +104,7 @@ class AttnBlock(nn.Module):
         B, H, W, Cc = x.shape
         h = _gn(x, self.norm, False, norm_stats)
         qkv = ops.conv2d(h, rt.pk_cat([self.q, self.k, self.v], "qkv"), pad=0, out_planes=True).reshape(B, H * W, 3 * Cc)
-        o = ops.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads=1, scale=Cc ** -0.5, split_attn="split")
+        o = ops.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads=1, scale=Cc ** -0.5)
         return ops.conv2d(o.reshape(B, H, W, Cc), rt.pk(self.proj_out), pad=0, residual=x)
 
 

@@ -23,7 +23,7 @@ class ControlWrapper(nn.Module):
         self.diffusion_model = diffusion_model
         self.control_model = None
         self.dtype = dtype
-        self.split = False     # with dtype fp32: the split-operand precision mode (SR_backbone.set_precision(..., "split"))
+        self.split = None      # with dtype fp32: the ops.SplitPolicy of the split-operand precision (SR_backbone.set_precision(..., "split")), else None
 
     def load_control_model(self, control_model):
         self.control_model = control_model
@@ -44,7 +44,7 @@ class ControlWrapper(nn.Module):
         return ops.nchw_to_nhwc(t, dt)
 
     def forward(self, x, t, c, control_scale=1, fbcache_mode="none", partial_info=None, **kwargs):
-        with ops.f32_split(self.split and self._compute_dtype() == torch.float32):
+        with ops.f32_split(self.split if self._compute_dtype() == torch.float32 else None):
             return self._forward(x, t, c, control_scale, fbcache_mode, partial_info, **kwargs)
 
     def _forward(self, x, t, c, control_scale=1, fbcache_mode="none", partial_info=None, **kwargs):

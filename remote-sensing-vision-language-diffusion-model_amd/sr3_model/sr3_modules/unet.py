@@ -145,7 +145,8 @@ class UNet(nn.Module):
         self.final_conv = Block(cur, self.out_channel, groups=norm_groups)
 
         self.compute_dtype = torch.float16   # storage / MFMA operand type of the activations
-        self.split = False                   # with compute_dtype fp32: matrix products on split operands ("split")
+        self.pack_dtype = torch.float16      # type the weights are packed in: = compute_dtype, or fp32 masters under fp16 activations ("w2")
+        self.split = None                    # with compute_dtype fp32: the ops.SplitPolicy of the split precision ("split"), else None
         self._pk = None                      # packed weights, built lazily on the parameters' device
 
     # ------------------------------------------------------------------ weight packing
@@ -157,19 +158,31 @@ class UNet(nn.Module):
         self._pk = None
         self.pack_version += 1
 
-    def set_compute_dtype(self, dt):
+    def set_compute_dtype(self, dt, policy=None):
         """fp16 (default) / bf16: 16-bit storage, fp32 accumulation; fp32: the fp32-operand kernel family (what the reference's
-        own Stage 1 computes in: it runs without autocast)."""
-        split = dt == "split"           # fp32 tensors, matrix products on split operands (three 16-bit MFMAs per product)
-        if split != self.split:         # captured hipGraphs bake the mode in: a new version drops them
+        own Stage 1 computes in: it runs without autocast); "split": fp32 tensors, matrix products on split operands (three 16-bit
+        MFMAs per product) under ``policy`` (an ``ops.SplitPolicy``, default ``ops.UNET_POLICY``); "w2" (round 5): fp16 tensors like
+        "fp16", but every weight as the fp16 PAIR [W_lo | W_hi] (dtype RSVLD_F16W2, two MFMAs per product) -- the rounding of the
+        WEIGHTS is the whole distance of "fp16" from the reference's CPU path after T = 50 steps."""
+        split = None
+        if dt == "split":               # captured hipGraphs bake the mode in: a new version drops them
+            split = policy or ops.UNET_POLICY
+            if not isinstance(split, ops.SplitPolicy):
+                raise TypeError("set_compute_dtype: policy must be an rsvld_amd.ops.SplitPolicy")
+        if split != self.split:
             self.split = split
             self.pack_version += 1
-        dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32, "split": torch.float32}.get(dt, dt)
+        pack = torch.float32 if dt == "w2" else None
+        dt = {"fp16": torch.float16, "w2": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32, "split": torch.float32}.get(dt, dt)
         if dt not in (torch.float16, torch.bfloat16, torch.float32):
-            raise ValueError(f"compute_dtype {dt!r}: fp16, bf16, fp32 or split")
-        if dt != self.compute_dtype:
-            self.compute_dtype = dt
+            raise ValueError(f"compute_dtype {dt!r}: fp16, w2, bf16, fp32 or split")
+        pack = pack or dt
+        if dt != self.compute_dtype or pack != self.pack_dtype:
+            self.compute_dtype, self.pack_dtype = dt, pack
             self.invalidate_packed()
+
+    def precision_key(self):
+        return (str(self.compute_dtype), str(self.pack_dtype), None if self.split is None else self.split.key())
 
     def load_state_dict(self, *a, **k):
         self.invalidate_packed()
@@ -193,7 +206,7 @@ class UNet(nn.Module):
         dev = self.noise_level_mlp[1].weight.device
         if dev.type != "cuda":
             raise RsvldError("SR3 UNet: parameters must be on the GPU (there is no CPU execution path)")
-        dt = self.compute_dtype
+        dt = self.pack_dtype
         pk = {}
 
         def conv(m, **kw):
@@ -250,7 +263,7 @@ class UNet(nn.Module):
         pk = self._pk
         if key not in pk:
             m = rb.res_conv
-            pk[key] = ops.pack_conv(m.weight, m.bias, self.compute_dtype, m.weight.device, cin_split=split)
+            pk[key] = ops.pack_conv(m.weight, m.bias, self.pack_dtype, m.weight.device, cin_split=split)
         return pk[key]
 
     # ------------------------------------------------------------------ forward pieces
@@ -288,7 +301,7 @@ class UNet(nn.Module):
     def forward_nhwc(self, x, noise_level):
         """x: 16-bit NHWC ``[B,H,W,pad8(in_channel)]``; noise_level fp32 ``[B,1]`` -> fp32 NHWC eps
         ``[B,H,W,pad8(out_channel)]`` (channels beyond out_channel are zero)."""
-        with ops.f32_split(self.split and self.compute_dtype == torch.float32):
+        with ops.f32_split(self.split if self.compute_dtype == torch.float32 else None):
             return self._forward_nhwc(x, noise_level)
 
     def _forward_nhwc(self, x, noise_level):

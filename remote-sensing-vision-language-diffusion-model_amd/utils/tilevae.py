@@ -89,7 +89,7 @@ def _attn(rt, at, x):
     B, H, W, Cc = x.shape
     h = yield from _norm(x, at.norm, False)
     qkv = ops.conv2d(h, rt.pk_cat([at.q, at.k, at.v], "qkv"), pad=0, out_planes=True).reshape(B, H * W, 3 * Cc)
-    o = ops.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads=1, scale=Cc ** -0.5, split_attn="split")
+    o = ops.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads=1, scale=Cc ** -0.5)
     return ops.conv2d(o.reshape(B, H, W, Cc), rt.pk(at.proj_out), pad=0, residual=x)
 
 

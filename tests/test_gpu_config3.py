@@ -147,12 +147,9 @@ def test_config3_stage2_latent512_one_guided_call(cuda, full_model):
         m.set_precision("bf16", "fp32")
         x32 = call()
         m.set_precision("bf16", "split")
-        xsp = call()                                  # the mode as shipped: attention operands in fp16
-        keep, ops.SPLIT_ATTN = ops.SPLIT_ATTN, "split"
-        try:
-            xsf = call()                              # its attentions in the split kernels too
-        finally:
-            ops.SPLIT_ATTN = keep
+        xsp = call()                                  # the mode as shipped: ops.UNET_POLICY (attention operands, to_out and FeedForward inputs in fp16)
+        m.set_precision("bf16", "split", policy=ops.ALL_SPLIT)
+        xsf = call()                                  # every product in three MFMAs, the attentions in the split kernels too
     finally:
         m.set_precision("bf16", "fp16")
     mx, mn = _rel(x16, x32, "configs[3] Stage 2 at latent 512: guided x0, fp16 vs fp32 family")

@@ -24,14 +24,11 @@ REL_SPLIT = 1e-4
 MODES = ["fp32", "split"]
 
 
-@pytest.fixture(autouse=True)
-def _split_attention_kernels():
-    """Kernel-level bounds: the split mode's attentions run the split kernels here (ops.SPLIT_ATTN = "split"), not the mode's default
-    composition with the 16-bit attention kernels (tests/test_gpu_split.py::test_attention_split_mode_f16_composition)."""
+def _split_ctx(on):
+    """Kernel-level bounds: every product of the split mode in three MFMAs, its attentions in the split kernels (ops.ALL_SPLIT), not
+    the UNets' default composition with fp16 hand-overs (tests/test_gpu_split.py has those)."""
     from rsvld_amd import ops
-    keep, ops.SPLIT_ATTN = ops.SPLIT_ATTN, "split"
-    yield
-    ops.SPLIT_ATTN = keep
+    return ops.f32_split(ops.ALL_SPLIT if on else None)
 
 
 
@@ -87,7 +84,7 @@ def test_conv2d_f32(cuda, case, mode):
         want = want + res
     xd = ops.nchw_to_nhwc(x.to(cuda), torch.float32)
     assert xd.shape[-1] == Cin and getattr(xd, "_nhwc", False)
-    with ops.f32_split(mode == "split"):
+    with _split_ctx(mode == "split"):
         got = ops.conv2d(xd, pc, stride=stride, pad=pad, upsample=up, residual=None if res is None else _nhwc(res, cuda),
                          act=L.ACT_SILU if silu else L.ACT_NONE)
     assert got.dtype == torch.float32 and got.shape == (B, want.shape[2], want.shape[3], Cout)
@@ -139,7 +136,7 @@ def test_attention_f32(cuda, B, heads, Nq, Nk, D, mode):
         qd, kd, vd = q.to(cuda), k.to(cuda), v.to(cuda)
     sp = lambda t, n: t.reshape(B, n, heads, D).transpose(1, 2)
     want = F.scaled_dot_product_attention(sp(q, Nq), sp(k, Nk), sp(v, Nk)).transpose(1, 2).reshape(B, Nq, heads * D)
-    with ops.f32_split(mode == "split"):
+    with _split_ctx(mode == "split"):
         got = ops.attention(qd, kd, vd, heads)
     assert got.dtype == torch.float32
     _cmp(got, want, REL if mode == "fp32" else REL_SPLIT, f"attention_f32[{mode}] B{B} h{heads} {Nq}x{Nk} d{D}")

@@ -43,8 +43,8 @@ def test_pipeline_cli_flow(cuda, tmp_path, prec):
     want_dt = torch.float32 if prec in ("fp32", "split") else torch.float16
     assert pipe.sr3_model.netG.denoise_fn.compute_dtype == want_dt and pipe.refinement_model.model.dtype == want_dt
     assert pipe.refinement_model.first_stage_model.compute_dtype == (torch.bfloat16 if prec == "default" else torch.float32)
-    assert pipe.sr3_model.netG.denoise_fn.split == (prec == "split") and pipe.refinement_model.model.split == (prec == "split")
-    assert pipe.refinement_model.first_stage_model.split == (prec in ("split", "vae_split"))
+    assert (pipe.sr3_model.netG.denoise_fn.split is not None) == (prec == "split") and (pipe.refinement_model.model.split is not None) == (prec == "split")
+    assert (pipe.refinement_model.first_stage_model.split is not None) == (prec in ("split", "vae_split"))
     # zero-initialised output convs would make Stage 2 a no-op: give them small seeded weights
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():

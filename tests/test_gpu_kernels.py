@@ -443,11 +443,13 @@ def test_attention_d512_shared_kv_tile(cuda, dtype, shape):
 
 
 @pytest.fixture(params=["b", "c", "p"])
-def d64_kernel(request, monkeypatch):
+def d64_kernel(request):
     """Both d = 64 kernels on every case: ``b`` (four waves per SIMD) and ``c`` (ping-pong, 512 query rows per workgroup), which
-    the library otherwise chooses between by the number of query rows (csrc/attention.hip, RSVLD_D64_KERNEL)."""
-    monkeypatch.setenv("RSVLD_D64_KERNEL", request.param)
-    return request.param
+    the library otherwise chooses between by the number of query rows (csrc/attention.hip; rsvld_amd.devtools.d64_kernel)."""
+    from rsvld_amd import devtools
+    devtools.d64_kernel(request.param)
+    yield request.param
+    devtools.d64_kernel("")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -535,9 +537,13 @@ def test_attention_d64_pingpong_equals_four_wave_kernel_bit_for_bit(cuda, dtype,
     k[0, Nk - 5, :D] = q[0, 33, :D] * 4.0
     q, k, v = (t.to(cuda, dtype) for t in (q, k, v))
     outs = {}
-    for kern in ("b", "c", "p"):
-        monkeypatch.setenv("RSVLD_D64_KERNEL", kern)
-        outs[kern] = ops.attention(q, k, v, heads=heads)
+    from rsvld_amd import devtools
+    try:
+        for kern in ("b", "c", "p"):
+            devtools.d64_kernel(kern)
+            outs[kern] = ops.attention(q, k, v, heads=heads)
+    finally:
+        devtools.d64_kernel("")
     assert bool(torch.isfinite(outs["c"]).all()) and bool(torch.isfinite(outs["p"]).all())
     assert torch.equal(outs["b"], outs["c"])
     assert torch.equal(outs["b"], outs["p"])

@@ -14,14 +14,12 @@ pytestmark = pytest.mark.gpu
 REL = 1e-4
 
 
-@pytest.fixture(autouse=True)
-def _split_attention_kernels():
-    """The kernel-level bounds of this file are those of the split attention KERNELS: run them (ops.SPLIT_ATTN = "split"); the default
-    composition of the mode -- attention operands to fp16, the 16-bit attention kernels -- has its own test at the bottom."""
+def _all_split():
+    """The kernel-level bounds of this file are those of the split KERNELS (three MFMAs per product, the split attention kernels):
+    policy ``ops.ALL_SPLIT``.  The compositions that hand some layer inputs over in fp16 (``ops.UNET_POLICY``: the 16-bit attention
+    kernels, the weight-pair form RSVLD_F16W2) have their own tests at the bottom."""
     from rsvld_amd import ops
-    keep, ops.SPLIT_ATTN = ops.SPLIT_ATTN, "split"
-    yield
-    ops.SPLIT_ATTN = keep
+    return ops.f32_split(ops.ALL_SPLIT)
 
 
 def _cmp(got, want, rel, what):
@@ -87,7 +85,7 @@ def test_linear_split(cuda, case):
         y = y * 0.5 + res.double()
     pc = ops.pack_conv(w, b, torch.float32, cuda, geglu=geglu)
     xd = x.to(cuda)
-    with ops.f32_split(True):
+    with _all_split():
         got_p = ops.linear(ops.to_planes(xd), pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
                            alpha=0.5 if use_res else 1.0, out_planes=out_planes)
         got_f = ops.linear(xd, pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
@@ -98,13 +96,9 @@ def test_linear_split(cuda, case):
     _cmp(got_p, y, REL, f"linear split (planes in) {case}")
     _cmp(got_f, y, REL, f"linear split (fp32 in)   {case}")
     # the round-3 implementation of the same arithmetic (on-the-fly split inside the fp32 family): an independent check
-    old, ops.SPLIT_IMPL = ops.SPLIT_IMPL, "f32"
-    try:
-        with ops.f32_split(True):
-            ref = ops.linear(xd, pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
-                             alpha=0.5 if use_res else 1.0)
-    finally:
-        ops.SPLIT_IMPL = old
+    with ops.f32_split(ops.SplitPolicy(impl="f32", f16_inputs=())):
+        ref = ops.linear(xd, pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
+                         alpha=0.5 if use_res else 1.0)
     _cmp(got_f, ref.cpu(), REL, "  planes path vs the fp32 family's split kernel")
 
 
@@ -158,7 +152,7 @@ def test_conv2d_split(cuda, case):
     if use_rv:
         rvd = torch.zeros(B, pc.cout_p, device=cuda)
         rvd[:, :cout_real] = rv.to(cuda)
-    with ops.f32_split(True):
+    with _all_split():
         got = ops.conv2d(xd, pc, x2=x2d, stride=stride, pad=pad, upsample=up, rowvec=rvd, residual=None if res is None else _nhwc(res, cuda),
                          stats=stats)
     assert got.dtype == torch.float32 and got.shape == (B, want.shape[2], want.shape[3], pc.cout_p)
@@ -188,7 +182,7 @@ def test_group_norm_split(cuda, shape, silu, two):
     c1 = Cc // 2 if two else Cc
     xd = _nhwc(x[:, :c1], cuda)
     x2d = _nhwc(x[:, c1:], cuda) if two else None
-    with ops.f32_split(True):
+    with _all_split():
         got = ops.group_norm(xd, gamma.to(cuda), beta.to(cuda), 32, 1e-6, x2=x2d, silu=silu)
         gp = ops.group_norm(xd, gamma.to(cuda), beta.to(cuda), 32, 1e-6, x2=x2d, silu=silu, planes=True)
     assert got.dtype == torch.float32 and isinstance(gp, ops.Planes)
@@ -205,7 +199,7 @@ def test_group_norm_split_modulated(cuda):
     gb = torch.randn(B, H, W, 2 * Cc, generator=g) * 0.5
     want = F.group_norm(x.double(), 32, None, None, eps=1e-5) * (1 + gb[..., :Cc].permute(0, 3, 1, 2).double()) + gb[..., Cc:].permute(0, 3, 1, 2).double()
     gbd = gb.to(cuda)
-    with ops.f32_split(True):
+    with _all_split():
         got = ops.group_norm(_nhwc(x, cuda), None, None, 32, 1e-5, mod_scale1p=gbd[..., :Cc], mod_shift=gbd[..., Cc:])
     _cmp(got.permute(0, 3, 1, 2), want, 2e-5, "group_norm split, modulated")
 
@@ -217,7 +211,7 @@ def test_layer_norm_split(cuda, rows, Cc):
     x = torch.randn(rows, Cc, generator=g) * 2 + 0.5
     gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
     want = F.layer_norm(x.double(), (Cc,), gamma.double(), beta.double(), 1e-5)
-    with ops.f32_split(True):
+    with _all_split():
         got = ops.layer_norm(x.to(cuda), gamma.to(cuda), beta.to(cuda), 1e-5)
         gp = ops.layer_norm(x.to(cuda), gamma.to(cuda), beta.to(cuda), 1e-5, planes=True)
     _cmp(got, want, 1e-5, f"layer_norm split {rows}x{Cc} fp32 out")
@@ -254,7 +248,7 @@ def test_attention_split_d64(cuda, B, heads, Nq, Nk, peaky):
         qp = ops.to_planes(q.to(cuda))
         kv = ops.to_planes(torch.cat([k, v], -1).to(cuda))
         kp, vp = kv[..., :HD], kv[..., HD:]
-    with ops.f32_split(True):
+    with _all_split():
         got = ops.attention(qp, kp, vp, heads=heads, scale=0.125)
         got32 = ops.attention(q.to(cuda), k.to(cuda), v.to(cuda), heads=heads, scale=0.125)   # fp32 in: split on demand
     assert isinstance(got, ops.Planes) and got.shape == (B, Nq, HD)
@@ -273,7 +267,7 @@ def test_attention_split_gemm_form(cuda, B, Nq, Nk, D, shared):
     v = k if shared else torch.randn(B, Nk, D, generator=g)
     want = _attn_ref(q, k, v, 1, D ** -0.5)
     kd = ops.to_planes(k.to(cuda))
-    with ops.f32_split(True):
+    with _all_split():
         got = ops.attention(ops.to_planes(q.to(cuda)), kd, kd if shared else ops.to_planes(v.to(cuda)), heads=1, scale=D ** -0.5)
     _cmp(got.f32(), want, REL, f"attention split (GEMM form) d{D} {Nq}x{Nk} shared={shared}")
 
@@ -301,7 +295,7 @@ def test_transformer_block_split_planes_vs_fp32_family(cuda):
         return ops.linear(gg, w2, residual=h)
 
     want = run(False).cpu()                      # fp32 family
-    with ops.f32_split(True):
+    with _all_split():
         got = run(True)
     _cmp(got, want, REL, "transformer block: split product path vs fp32 family")
 
@@ -318,7 +312,7 @@ def test_attention_split_d512_fused(cuda, B, Nq, Nk):
     qp, xp = ops.to_planes(q.to(cuda)), ops.to_planes(x.to(cuda))
     old = ops.SPLIT_D512_FUSED_MIN
     try:
-        with ops.f32_split(True):
+        with _all_split():
             ops.SPLIT_D512_FUSED_MIN = 1
             got = ops.attention(qp, xp, xp, heads=1, scale=512 ** -0.5)
             ops.SPLIT_D512_FUSED_MIN = 1 << 30
@@ -339,7 +333,7 @@ def test_attention_split_d64_pingpong_vs_four_wave(cuda, B, heads, Nq, Nk):
     qkv = torch.randn(B, max(Nq, Nk), 3 * HD, device=cuda, generator=g) * 1.3
     pl = ops.to_planes(qkv)
     q, k, v = pl[:, :Nq, :HD], pl[:, :Nk, HD:2 * HD], pl[:, :Nk, 2 * HD:]
-    with ops.f32_split(True):
+    with _all_split():
         ref = ops.attention(q, k, v, heads=heads, scale=0.125)          # the library's choice: the 4-wave kernel
     got_t = torch.empty_like(ref.t)
     lib = L.load()
@@ -357,8 +351,9 @@ def test_attention_split_d64_pingpong_vs_four_wave(cuda, B, heads, Nq, Nk):
 @pytest.mark.parametrize("B,heads,Nq,Nk,D,shared", [(2, 5, 1024, 1024, 64, False), (1, 20, 300, 77, 64, False), (1, 1, 2304, 2304, 512, True),
                                                     (1, 1, 1000, 1000, 512, False)])
 def test_attention_split_mode_f16_composition(cuda, B, heads, Nq, Nk, D, shared):
-    """ops.SPLIT_ATTN = "f16" (the mode's default): q | k | v leave the planes as fp16 (rsvld_planes_to_f16, channel slices of a fused
-    planes tensor read in place), the 16-bit attention kernels run, the fp16 result returns as planes (rsvld_f16_to_planes, exact).
+    """Policy group "attn" (without "attn_out"): q | k | v leave the planes as fp16 (rsvld_planes_to_f16, channel slices of a fused
+    planes tensor read in place), the 16-bit attention kernels run, the fp16 result returns as planes (rsvld_f16_to_planes, exact);
+    with "attn_out" (the UNets' default policy) the fp16 result itself is returned for the weight-pair form of ``to_out``.
     Against fp64 on the host at the 16-bit kernels' tolerance, and against the same kernels called on fp16(fp32) operands."""
     from rsvld_amd import ops
     g = torch.Generator().manual_seed(Nq + D)
@@ -373,10 +368,12 @@ def test_attention_split_mode_f16_composition(cuda, B, heads, Nq, Nk, D, shared)
     else:
         qp, kp = ops.to_planes(q.to(cuda)), ops.to_planes(k.to(cuda))
         vp = kp if shared else ops.to_planes(v.to(cuda))
-    ops.SPLIT_ATTN = "f16"
-    with ops.f32_split(True):
+    with ops.f32_split(ops.SplitPolicy(f16_inputs=("attn",))):
         got = ops.attention(qp, kp, vp, heads=heads, scale=D ** -0.5)
+    with ops.f32_split(ops.UNET_POLICY):
+        got16 = ops.attention(qp, kp, vp, heads=heads, scale=D ** -0.5)
     assert isinstance(got, ops.Planes) and got.shape == (B, Nq, HD)
+    assert got16.dtype == torch.float16 and torch.equal(got16.float(), got.f32())
     _cmp(got.f32(), want, 4e-3, f"split mode, attention in fp16: B{B} h{heads} {Nq}x{Nk} d{D}")
     q16, k16 = q.to(cuda).half(), k.to(cuda).half()
     ref16 = ops.attention(q16, k16, k16 if shared else v.to(cuda).half(), heads=heads, scale=D ** -0.5)
@@ -387,3 +384,168 @@ def test_attention_split_mode_f16_composition(cuda, B, heads, Nq, Nk, D, shared)
     x16 = torch.randn(3, 70, 136, generator=g).half()
     back = ops._f16_to_planes(ops._planes_to_f16(ops.to_planes(x16.float().to(cuda))))
     assert torch.equal(back.f32().cpu(), x16.float())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 5: the weight-pair form (dtype RSVLD_F16W2: fp16 activation x fp16 [W_lo | W_hi], two MFMAs per product) and the fp16 hand-over
+# of the split kernels.  Reference = fp64 on the host over the SAME fp16-rounded activation (the rounding of the input is the policy's
+# decision, measured end to end in DESIGN.md section 4; here the KERNEL must add nothing beyond the weights' ~2^-22).
+W2_LINEAR_CASES = [
+    # rows, K, N, residual (fp32), geglu, f16 out
+    (8192, 640, 5120, False, True, True),        # GEGLU feed-forward, fp16 out: the persistent gemm256 (SEG = 2)
+    (8192 + 77, 2560, 640, True, False, False),  # ff.net.2 with the fp32 residual: one-tile form, fp32 epilogue, ragged rows
+    (16384, 1280, 1280, True, False, False),     # to_out on the fp16 attention output
+    (4096, 64, 320, False, False, True),         # K' = 128: four K tiles, the persistent form's minimum
+    (300, 640, 640, True, False, False),         # small M: the implicit-GEMM kernel (SEG = 2)
+    (1000, 72, 80, False, True, True),           # K, N multiples of 8 only, GEGLU, fp16 out
+    (2048, 640, 5120, False, True, False),       # GEGLU on the implicit-GEMM kernel, fp32 out
+]
+
+
+@pytest.mark.parametrize("case", W2_LINEAR_CASES)
+def test_linear_weight_pairs(cuda, case):
+    from rsvld_amd import _lib as L, ops
+    rows, K, N, use_res, geglu, f16_out = case
+    g = torch.Generator().manual_seed(rows + K + N)
+    x16 = torch.randn(rows, K, generator=g).half()
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    y = x16.double() @ w.double().t() + b.double()
+    if geglu:
+        y = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    res = torch.randn(y.shape, generator=g) if use_res else None
+    if use_res:
+        y = y * 0.5 + res.double()
+    pc = ops.pack_conv(w, b, torch.float32, cuda, geglu=geglu)
+    with ops.f32_split(ops.UNET_POLICY):      # inside a split-precision network: fp32 out unless the consumer takes fp16 (out_planes)
+        got = ops.linear(x16.to(cuda), pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
+                         alpha=0.5 if use_res else 1.0, out_planes=f16_out, out_group="ff")
+    assert got.dtype == (torch.float16 if f16_out else torch.float32) and got.shape == tuple(y.shape)
+    # fp16 out: one rounding of the result (2^-11 of its magnitude); fp32 out: the weights' lo half keeps the product at ~2^-21
+    _cmp(got, y, 6e-4 if f16_out else 3e-6, f"linear, weight pairs {case}")
+    # the pair itself: [W_lo | W_hi] with W_hi = fp16(W), W_lo = fp16(W - W_hi)
+    w2 = ops._w2(pc).view(pc.cout_p, 2, pc.cin_p).float().cpu()
+    wp = pc.w.cpu()
+    assert torch.equal(w2[:, 1], wp.half().float()) and torch.equal(w2[:, 0], (wp - wp.half().float()).half().float())
+
+
+@pytest.mark.parametrize("rows,K,N,geglu", [(8192, 640, 1920, False), (4096 + 13, 1280, 2560, True), (500, 320, 960, False)])
+def test_linear_split_fp16_hand_over(cuda, rows, K, N, geglu):
+    """RSVLD_SPLIT with out_f32 = 2: planes in, three MFMAs per product, fp16 OUT (q | k | v on their way to the 16-bit attention kernels):
+    equal to the planes output rounded to fp16 up to the double rounding of a tie."""
+    from rsvld_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(rows + N)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    y = x.double() @ w.double().t()
+    if geglu:
+        y = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+    pc = ops.pack_conv(w, None, torch.float32, cuda, geglu=geglu)
+    with ops.f32_split(ops.UNET_POLICY):
+        got = ops.linear(ops.to_planes(x.to(cuda)), pc, act=L.ACT_GEGLU if geglu else L.ACT_NONE, out_planes=True, out_group="attn")
+        pl = ops.linear(ops.to_planes(x.to(cuda)), pc, act=L.ACT_GEGLU if geglu else L.ACT_NONE, out_planes=True, out_group=None)
+    assert got.dtype == torch.float16 and isinstance(pl, ops.Planes)
+    _cmp(got, y, 6e-4, f"linear split -> fp16 ({rows}, {K}, {N})")
+    _cmp(got, pl.f32().cpu(), 6e-4, "  against the planes output")
+
+
+W2_CONV_CASES = [
+    # B, Cin, Cin2, Cout, H, W, upsample, residual, rowvec, norm, fp32 out
+    (1, 64, 0, 64, 250, 260, False, True, True, True, False),        # conv_halo_64 with the fused GroupNorm + SiLU, fp16 out + fp16 residual
+    (2, 128, 0, 128, 128, 250, False, True, True, True, False),      # conv_halo32 NW = 4, fused norm
+    (1, 192, 64, 128, 512, 256, False, False, False, True, False),   # two sources, NW = 8, fused norm over the concat
+    (1, 256, 0, 256, 100, 128, True, False, False, False, False),    # nearest x2
+    (2, 128, 0, 128, 128, 250, False, True, False, False, True),     # fp32 out + fp32 residual (a split-precision network's conv on an fp16 input)
+    (1, 64, 0, 64, 96, 128, False, True, True, True, False),         # small map: norm unfused, the gather kernel (SEG = 2)
+]
+
+
+@pytest.mark.parametrize("case", W2_CONV_CASES)
+def test_conv3x3_weight_pairs(cuda, case):
+    """SR3's compute dtype "w2": fp16 tensors, every weight as the pair -- the fp16 path's launches (fused GroupNorm prologue, epilogue
+    statistics) with dtype RSVLD_F16W2.  Against fp64 over the fp16 inputs; the fused prologue rounds the normalised input to fp16 once."""
+    from rsvld_amd import ops
+    B, Cin, Cin2, Cout, H, W, up, use_res, use_rv, use_norm, f32_out = case
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    x2 = torch.randn(B, Cin2, H, W, generator=g).half() if Cin2 else None
+    w = torch.randn(Cout, Cin + Cin2, 3, 3, generator=g) / math.sqrt(9 * (Cin + Cin2))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xin = x.double() if x2 is None else torch.cat([x.double(), x2.double()], 1)
+    gamma = torch.randn(Cin + Cin2, generator=g) * 0.2 + 1.0
+    beta = torch.randn(Cin + Cin2, generator=g) * 0.1
+    if use_norm:
+        xin = F.silu(F.group_norm(xin, 32, gamma.double(), beta.double(), 1e-5)).half().double()   # (the prologue's one rounding)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    y = F.conv2d(xin, w.double(), b.double(), padding=1)
+    rv = torch.randn(B, Cout, generator=g) if use_rv else None
+    if use_rv:
+        y = y + rv.double()[:, :, None, None]
+    Ho, Wo = y.shape[-2:]
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+    if use_res:
+        res = res if f32_out else res.half().float()
+        y = y + res.double()
+    pc = ops.pack_conv(w, b, torch.float32, cuda, cin_split=None if x2 is None else (Cin, Cin2))
+    kw = dict(x2=None if x2 is None else _nhwc(x2, cuda), upsample=up, rowvec=None if rv is None else rv.to(cuda),
+              norm=(gamma.to(cuda), beta.to(cuda), 32, 1e-5, True) if use_norm else None, stats=True, out_f32=f32_out)
+    if use_res:
+        kw["residual"] = _nhwc(res, cuda) if f32_out else _nhwc(res, cuda).half()
+    got = ops.conv2d(_nhwc(x, cuda), pc, **kw)
+    assert got.dtype == (torch.float32 if f32_out else torch.float16)
+    want = y.permute(0, 2, 3, 1)
+    # fused norm: the device normalises with fp32 statistics of the fp16 input, the host rounds ITS normalised tensor: neighbouring fp16
+    # values where the two differ in the last bit -> 2^-11 of one input per tap, averaged over 9 C terms
+    _cmp(got, want, 2e-3 if (use_norm or not f32_out) else 3e-6, f"conv3x3, weight pairs {case}")
+    part = getattr(got, "_gn_part", None)
+    if part is not None:       # the epilogue's statistics are those of the stored tensor
+        s = part[0].double().sum(1).cpu()          # [B, Cout, 2]
+        gd = got.double().cpu()
+        assert torch.allclose(s[..., 0], gd.sum((1, 2)), rtol=1e-3, atol=1e-1) and torch.allclose(s[..., 1], (gd * gd).sum((1, 2)), rtol=1e-3, atol=1e-1)
+
+
+def test_norms_fp16_hand_over(cuda):
+    """LayerNorm / GroupNorm of fp32 -> fp16 (out mode 2): the input of a weight-pair layer; equal to the fp32 output rounded once."""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(2, 40, 24, 640, generator=g) * 3 + 0.5).to(cuda)
+    ga, be = (torch.randn(640, generator=g) * 0.2 + 1).to(cuda), (torch.randn(640, generator=g) * 0.1).to(cuda)
+    with ops.f32_split(ops.UNET_POLICY):
+        ln16 = ops.layer_norm(x, ga, be, 1e-5, planes=True, group="ff")
+        ln32 = ops.layer_norm(x, ga, be, 1e-5)
+        lnp = ops.layer_norm(x, ga, be, 1e-5, planes=True, group="qkv")          # "qkv" is not in the default policy: planes
+        gn16 = ops.group_norm(x, ga, be, 32, 1e-6, silu=True, planes=True, group="ff")
+        gn32 = ops.group_norm(x, ga, be, 32, 1e-6, silu=True)
+    assert ln16.dtype == torch.float16 and gn16.dtype == torch.float16 and isinstance(lnp, ops.Planes)
+    assert torch.equal(ln16, ln32.half()) and torch.equal(gn16, gn32.half())
+
+
+def test_transformer_block_policy_composition(cuda):
+    """One BasicTransformerBlock (sgm/modules/attention.py:376-486) at 640 channels x 4096 tokens under the UNets' default policy
+    (attention operands, to_out and FeedForward inputs in fp16; everything else three MFMAs) against the all-split policy and the
+    fp32 family: the composition is a numerics decision of ~1e-3 of the block's range per call, the plumbing must be exact."""
+    from rsvld_amd import ops
+    from rsvld_amd.hipnn import HipNet
+    from rsvld_amd.sgm.modules.attention import BasicTransformerBlock
+
+    class Net(HipNet):
+        def __init__(self):
+            super().__init__()
+            self.blk = BasicTransformerBlock(640, 10, 64, context_dim=2048)
+
+    torch.manual_seed(3)
+    net = Net().to(cuda).eval()
+    net.compute_dtype = torch.float32
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 4096, 640, generator=g).to(cuda)
+    ctx = torch.randn(2, 77, 2048, generator=g).to(cuda)
+    outs = {}
+    for name, pol in (("fp32", None), ("all_split", ops.ALL_SPLIT), ("unet", ops.UNET_POLICY)):
+        with ops.f32_split(pol):
+            outs[name] = net.blk.run(net, x, ctx).float().cpu()
+    rng = float(outs["fp32"].abs().max())
+    e_all = float((outs["all_split"] - outs["fp32"]).abs().max()) / rng
+    e_pol = float((outs["unet"] - outs["fp32"]).abs().max()) / rng
+    print(f"transformer block vs the fp32 family: all-split {e_all:.2e}, UNet policy {e_pol:.2e} of the range {rng:.2f}")
+    assert e_all < 1e-4 and e_pol < 2e-3

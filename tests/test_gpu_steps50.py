@@ -17,7 +17,7 @@ import s2_common as S
 pytestmark = pytest.mark.gpu
 
 PREC = {"shipped": ("bf16", "fp16"), "vae32": ("fp32", "fp16"), "allfp32": ("fp32", "fp32"), "split": ("split", "split"),
-        "split_full": ("split", "split")}   # split = the mode as shipped (attention operands in fp16); split_full = its attentions in the split kernels too
+        "split_full": ("split", "split")}   # split = the mode as shipped (ops.UNET_POLICY: attention operands, to_out and FeedForward inputs in fp16); split_full = ops.ALL_SPLIT (every product three MFMAs, the split attention kernels)
 # (max|d|, mean|d|) on an output of range 2.6 = 2 x measured.  Measured on MI355X, cache off / on (6 steps: test_gpu_s2.PIPE_BOUNDS):
 #   shipped (bf16 VAE, fp16 UNets)  3.17e-2 / 4.6e-3   3.21e-2 / 4.7e-3   -- the same as after 6 steps: the bf16 VAE passes dominate
 #   vae32   (fp32 VAE, fp16 UNets)  6.0e-3  / 6.1e-4   8.3e-3  / 7.6e-4   -- 2 x the 6-step figure: the drift of fp16 over 50 steps
@@ -42,15 +42,11 @@ def _run(m, cuda, prec, **over):
     opt = dict(S.PIPE_OPT, **over)
     from rsvld_amd import ops
     m.noise_source = "cpu"
-    m.set_precision(*PREC[prec])
-    keep = ops.SPLIT_ATTN
-    if prec == "split_full":
-        ops.SPLIT_ATTN = "split"
+    m.set_precision(*PREC[prec], policy=ops.ALL_SPLIT if prec == "split_full" else None)
     try:
         torch.manual_seed(7)
         out = m.just_sampling(img, [""], p_p="", n_p="", **opt)
     finally:
-        ops.SPLIT_ATTN = keep
         m.noise_source = "device"
         m.set_precision("bf16", "fp16")
     return out.cpu(), [step[0] for step in m.cache_trace]

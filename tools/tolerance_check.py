@@ -18,7 +18,7 @@ for p in (ROOT, GOLDEN):
         sys.path.insert(0, p)
 
 
-def stage1_t50(dev, prec):
+def stage1_t50(dev, prec, policy=None):
     """Stage 1 (SR3): the config-1 image through T = 50 ancestral steps, CPU noise order -> max / mean |delta| of the final frame."""
     from oracle import seeded, sr3_oracle as O
     from rsvld_amd.sr3_model.sr3_modules.diffusion import GaussianDiffusion
@@ -30,7 +30,7 @@ def stage1_t50(dev, prec):
     net = GaussianDiffusion(unet, image_size=c["image_size"], channels=3, conditional=True)
     seeded.seed_module(net, 1234)
     net.to(dev).eval()
-    net.denoise_fn.set_compute_dtype(prec)
+    net.denoise_fn.set_compute_dtype(prec, policy=policy)
     net.set_new_noise_schedule(dict(schedule="linear", n_timestep=50, linear_start=1e-6, linear_end=1e-2), dev)
     net.noise_source = "cpu"
     z = np.load(os.path.join(GOLDEN, "sr3_pipeline_t50.npz"))
@@ -41,7 +41,7 @@ def stage1_t50(dev, prec):
     return {"max": float(d.max()), "mean": float(d.mean())}
 
 
-def stage2_50(dev, ae, diff, cache=False):
+def stage2_50(dev, ae, diff, cache=False, policy=None):
     """Stage 2: ``just_sampling`` over 50 EDM steps at 64^2 (reduced-depth networks of the goldens), cache off or 0.3."""
     import s2_common as S
     from oracle import seeded
@@ -52,7 +52,7 @@ def stage2_50(dev, ae, diff, cache=False):
     img = seeded.synthetic_image((1, 3, 64, 64), seed=80, smooth=3).to(dev)
     opt = dict(S.PIPE_OPT, num_steps=50, **({} if cache else {"img_threshold": 0.0}))
     m.noise_source = "cpu"
-    m.set_precision(ae, diff)
+    m.set_precision(ae, diff, policy=policy)
     torch.manual_seed(7)
     out = m.just_sampling(img, [""], p_p="", n_p="", **opt).cpu()
     z = np.load(os.path.join(GOLDEN, "s2_pipeline_50.npz"))
@@ -66,10 +66,11 @@ def stage2_50(dev, ae, diff, cache=False):
     return res
 
 
-def errors_after_50_steps(dev, sr3_prec, ae, diff):
-    """-> {stage1: {max, mean}, stage2: {max, mean, range}} vs the reference's CPU runs (same seeds, same noise order)."""
+def errors_after_50_steps(dev, sr3_prec, ae, diff, policy=None, sr3_policy=None):
+    """-> {stage1: {max, mean}, stage2: {max, mean, range}} vs the reference's CPU runs (same seeds, same noise order).
+    ``policy`` / ``sr3_policy``: the ops.SplitPolicy of the Stage-2 UNets / of SR3 when their precision is "split" (None = the default)."""
     with torch.random.fork_rng(devices=[dev]):
-        return {"stage1_T50_256px": stage1_t50(dev, sr3_prec), "stage2_50_steps_64px": stage2_50(dev, ae, diff),
+        return {"stage1_T50_256px": stage1_t50(dev, sr3_prec, sr3_policy), "stage2_50_steps_64px": stage2_50(dev, ae, diff, policy=policy),
                 "reference": "tests/golden/sr3_pipeline_t50.npz, s2_pipeline_50.npz (the reference's own CPU runs)"}
 
 
@@ -77,16 +78,16 @@ if __name__ == "__main__":
     import json
     dev = torch.device("cuda:0")
     from rsvld_amd import ops
-    # split = the mode as shipped (ops.SPLIT_ATTN = "f16": attention operands in fp16); split_full = its attentions in the split kernels too
-    modes = {"shipped": ("fp16", "bf16", "fp16"), "vae_split": ("fp16", "split", "fp16"), "split": ("split", "split", "split"),
-             "split_full": ("split", "split", "split")}
+    P = ops.SplitPolicy
+    # name -> (SR3 precision, VAE, UNets, UNet policy, SR3 policy); split = the mode as shipped
+    modes = {"shipped": ("fp16", "bf16", "fp16", None, None), "vae_split": ("fp16", "split", "fp16", None, None),
+             "split": ("split", "split", "split", None, None),
+             "split_s1w2": ("w2", "split", "split", None, None),                            # Stage 1: fp16 tensors x weight pairs
+             "split_r04": ("split", "split", "split", P(f16_inputs=("attn",)), P(f16_inputs=("attn",))),   # round 4's composition
+             "split_qkv": ("split", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv")), None),
+             "split_proj": ("split", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "proj")), None),
+             "split_full": ("split", "split", "split", ops.ALL_SPLIT, ops.ALL_SPLIT)}
     if "--only" in sys.argv:
         modes = {k: v for k, v in modes.items() if k in sys.argv[sys.argv.index("--only") + 1].split(",")}
-    for name, (s1, ae, df) in modes.items():
-        keep = ops.SPLIT_ATTN
-        if name == "split_full":
-            ops.SPLIT_ATTN = "split"
-        try:
-            print(name, json.dumps(errors_after_50_steps(dev, s1, ae, df)))
-        finally:
-            ops.SPLIT_ATTN = keep
+    for name, (s1, ae, df, pol, pol1) in modes.items():
+        print(name, json.dumps(errors_after_50_steps(dev, s1, ae, df, policy=pol, sr3_policy=pol1)), flush=True)
