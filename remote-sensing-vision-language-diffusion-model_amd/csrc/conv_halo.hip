@@ -696,6 +696,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     halo_epilogue<T, BN, TM, TN, NW, SEG>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
 }
 
+// one-time registration of a kernel's dynamic LDS size, keyed on the KERNEL (see conv_igemm.hip: a generic lambda's static is shared by
+// every kernel of one function type -- here the NORM and the K-segment variants of a tile)
+template <auto KERN> hipError_t halo_smem_once(int smem) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    return attr;
+}
+#define HALO_K(...) std::integral_constant<void (*)(HaloArgs), &__VA_ARGS__>{}
+
 template <typename T, int BN, int NW>
 int launch_halo32(HaloArgs a, hipStream_t s) {
     constexpr int THT = 2 * NW;
@@ -707,26 +715,25 @@ int launch_halo32(HaloArgs a, hipStream_t s) {
     a.tiles_y = (a.H + THT - 1) / THT;
     const int64_t nwg = (int64_t)a.tiles_x * a.tiles_y * a.B * ((a.Cout + BN - 1) / BN);
     if (nwg >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
-    auto go = [&](auto kern) -> int {
-        // one-time, thread-safe; the lambda is instantiated once per kernel type
-        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    auto go = [&](auto kern_c) -> int {
+        constexpr auto kern = decltype(kern_c)::value;
+        if (halo_smem_once<kern>(smem) != hipSuccess) return RSVLD_ELAUNCH;   // one-time, thread-safe, per KERNEL
         hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), smem, s, a);
         return rsvld_check_launch();
     };
     if constexpr (__is_same(T, bf16)) {   // RSVLD_SPLIT: planes in, no fused norm (checked by the entry point)
-        if (a.seg == 3) return go(conv_halo32_kernel<T, BN, 0, NW, 3>);
+        if (a.seg == 3) return go(HALO_K(conv_halo32_kernel<T, BN, 0, NW, 3>));
     } else {                              // RSVLD_F16W2: fp16 in, weight pairs, the fused norm available
         if (a.seg == 2) {
-            if (norm == 0) return go(conv_halo32_kernel<T, BN, 0, NW, 2>);
-            if (norm == 1) return go(conv_halo32_kernel<T, BN, 1, NW, 2>);
-            return go(conv_halo32_kernel<T, BN, 2, NW, 2>);
+            if (norm == 0) return go(HALO_K(conv_halo32_kernel<T, BN, 0, NW, 2>));
+            if (norm == 1) return go(HALO_K(conv_halo32_kernel<T, BN, 1, NW, 2>));
+            return go(HALO_K(conv_halo32_kernel<T, BN, 2, NW, 2>));
         }
     }
     if (a.seg != 1) return RSVLD_EUNSUPPORTED;
-    if (norm == 0) return go(conv_halo32_kernel<T, BN, 0, NW>);
-    if (norm == 1) return go(conv_halo32_kernel<T, BN, 1, NW>);
-    return go(conv_halo32_kernel<T, BN, 2, NW>);
+    if (norm == 0) return go(HALO_K(conv_halo32_kernel<T, BN, 0, NW, 1>));
+    if (norm == 1) return go(HALO_K(conv_halo32_kernel<T, BN, 1, NW, 1>));
+    return go(HALO_K(conv_halo32_kernel<T, BN, 2, NW, 1>));
 }
 
 template <typename T, int BN, int WAVES_M, int TPS>
@@ -736,19 +743,19 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
     constexpr int smem = stage > epi ? stage : epi;
     const int64_t nwg = (int64_t)a.tiles_x * a.tiles_y * a.B * ((a.Cout + BN - 1) / BN);
     if (nwg >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
-    auto go = [&](auto kern) -> int {
-        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    auto go = [&](auto kern_c) -> int {
+        constexpr auto kern = decltype(kern_c)::value;
+        if (halo_smem_once<kern>(smem) != hipSuccess) return RSVLD_ELAUNCH;
         hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), smem, s, a);
         return rsvld_check_launch();
     };
     if constexpr (__is_same(T, bf16)) {
-        if (a.seg == 3) return go(conv_halo_kernel<T, BN, WAVES_M, TPS, 3>);
+        if (a.seg == 3) return go(HALO_K(conv_halo_kernel<T, BN, WAVES_M, TPS, 3>));
     } else {
-        if (a.seg == 2) return go(conv_halo_kernel<T, BN, WAVES_M, TPS, 2>);
+        if (a.seg == 2) return go(HALO_K(conv_halo_kernel<T, BN, WAVES_M, TPS, 2>));
     }
     if (a.seg != 1) return RSVLD_EUNSUPPORTED;
-    return go(conv_halo_kernel<T, BN, WAVES_M, TPS>);
+    return go(HALO_K(conv_halo_kernel<T, BN, WAVES_M, TPS, 1>));
 }
 
 template <typename T>

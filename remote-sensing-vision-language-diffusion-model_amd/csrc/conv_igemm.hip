@@ -32,6 +32,7 @@
 #include <string.h>
 
 #include "rsvld_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -473,29 +474,37 @@ __global__ __launch_bounds__(256 * KS) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
+// one-time registration of a kernel's dynamic LDS size: a function-local static of an instantiation keyed on the KERNEL (a generic
+// lambda's static would be shared by every kernel of one function type: the plain and the multi-segment instantiations of a tile)
+template <auto KERN> hipError_t conv_smem_once(int smem) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    return attr;
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GLDS, int STAGES = 2, int KS = 1>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int stage = KS * STAGES * (BM + BN) * BK_BYTES;
     constexpr int epi = BM * (BN + 4) * 4;
     constexpr int smem = stage > epi ? stage : epi;
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
-    auto go = [&](auto kern) -> int {
-        // one-time, thread-safe (C++11 magic static), per instantiation
-        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (attr != hipSuccess) return RSVLD_ELAUNCH;
+    auto go = [&](auto kern_c) -> int {
+        constexpr auto kern = decltype(kern_c)::value;
+        if (conv_smem_once<kern>(smem) != hipSuccess) return RSVLD_ELAUNCH;   // one-time, thread-safe (C++11 magic static), per KERNEL
         hipLaunchKernelGGL(kern, grid, dim3(256 * KS), smem, s, a);
         return rsvld_check_launch();
     };
+#define CONV_K(SEG) std::integral_constant<void (*)(ConvArgs), &conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS, SEG>>{}
     if constexpr (__is_same(T, bf16) && GLDS) {   // RSVLD_SPLIT: its own instantiation (bf16, LDS-DMA staging), so that the 16-bit kernels stay as they were
-        if (a.seg == 3) return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS, 3>);
+        if (a.seg == 3) return go(CONV_K(3));
         if (a.seg != 1) return RSVLD_EUNSUPPORTED;
     } else if constexpr (__is_same(T, f16) && GLDS) {   // RSVLD_F16W2 likewise (fp16, LDS-DMA staging)
-        if (a.seg == 2) return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS, 2>);
+        if (a.seg == 2) return go(CONV_K(2));
         if (a.seg != 1) return RSVLD_EUNSUPPORTED;
     } else {
         if (a.seg != 1) return RSVLD_EUNSUPPORTED;
     }
-    return go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, GLDS, STAGES, KS>);
+    return go(CONV_K(1));
+#undef CONV_K
 }
 
 // Tile choice.  Cout <= 32: 256x32.  Cout <= 64: 128x64 (48 KiB LDS -> 3 workgroups per CU: these layers

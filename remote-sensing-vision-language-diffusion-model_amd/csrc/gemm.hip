@@ -125,11 +125,13 @@ template <int N> __device__ __forceinline__ void g_wait_vm() { asm volatile("s_w
 // activation its 11: x W = x W_lo + x W_hi is ONE fp16 GEMM over K' = 2 K whose second segment re-reads the activation row.
 // TO = the 16-bit OUTPUT type: T for a plain GEMM, fp16 for both multi-segment forms (a tensor that goes on to an fp16-operand
 // consumer: the 16-bit attention kernels, another F16W2 layer); their fp32 / planes outputs leave through the one-tile SEG epilogue.
-// WIDE (one-tile form of the multi-segment GEMMs): true = the fp32 / planes epilogue, false = the 16-bit one -- a template parameter,
-// because a kernel that holds BOTH epilogues spills (220 scratch instructions; a scratch reload shares vmcnt with the LDS-DMA ring).
-template <typename T, int SEG = 1, bool PERSIST = false, int PV = 0, bool WIDE = false>
+// WIDE (one-tile form of the multi-segment GEMMs): 0 = the 16-bit epilogue, 1 = the fp32 / planes epilogue without a residual (any
+// activation), 2 = fp32 out + fp32 residual (no GEGLU) -- a template parameter, because a kernel that holds several epilogues spills
+// (220 scratch instructions with two, 119 with the residual registers beside the GEGLU / planes staging code; a scratch reload
+// shares vmcnt with the LDS-DMA ring).
+template <typename T, int SEG = 1, bool PERSIST = false, int PV = 0, int WIDE = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
-    static_assert(!WIDE || (SEG > 1 && !PERSIST), "the fp32 / planes epilogue belongs to the one-tile multi-segment kernels");
+    static_assert(WIDE == 0 || (SEG > 1 && !PERSIST), "the fp32 / planes epilogue belongs to the one-tile multi-segment kernels");
     static_assert(SEG >= 1 && SEG <= 3, "1 plain, 2 fp16 x weight pairs, 3 bf16 planes x weight triples");
     static_assert(SEG == 1 || !(PV & 8), "the persistent residual variants are 16-bit residuals (plain GEMM only)");
     static_assert(PERSIST || PV == 0, "PV is the persistent epilogue's variant");
@@ -935,21 +937,36 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     if (p.M > 0) return;   // diagnostic build: no epilogue at all (the accumulators stay live for the compiler)
 #endif
 
-    if constexpr (WIDE) {
+    if constexpr (WIDE != 0) {
         // ---- SEG epilogue (fp32 / planes out; a 16-bit output takes the plain epilogue below): the 256 x 256 fp32 tile (256 KiB; as planes lo | hi the same bytes) does not fit the 128 KiB ring, so it
         // leaves in two halves of 128 rows = the rows of group 0, then of group 1: the owning group stages bias / activation / alpha
         // in registers -> LDS (16-byte chunks XOR-swizzled by the row), all 512 threads move whole 16-byte chunks out as contiguous
         // runs and add the fp32 residual on that side.  Twice the bytes of the 16-bit epilogue behind three times its K loop.
-        const bool geglu = p.act == RSVLD_ACT_GEGLU;
+        const bool geglu = WIDE == 1 && p.act == RSVLD_ACT_GEGLU;
         const int ncol = geglu ? 128 : 256;                       // columns of the stored tile
         const int n_out0 = geglu ? (n0 >> 1) : n0;
-        const bool planes = p.out_kind == 2;
+        const bool planes = WIDE == 1 && p.out_kind == 2;
         // fp32: row = ncol * 4 bytes = ncol / 4 chunks; planes: row = lo (ncol * 2 bytes) | hi (ncol * 2 bytes) = ncol / 4 chunks as well
         const int rchunks = ncol >> 2;                            // 64 or 32 16-byte chunks per staged row
         const int rbytes = rchunks << 4;
         auto s_off = [&](int row, int chunk) { return row * rbytes + ((chunk ^ (row & 15)) << 4); };
+        // The fp32 residual pieces a thread adds on the way out (rows tid / 64 + 8 i of the half, its 16-byte chunk) are requested BEFORE
+        // the half is staged, so that their HBM round trip runs under the staging pass and its barrier (round 4 loaded each piece inside
+        // the store loop, behind a row test: 16 dependent round trips per half -- ~50 us of a 150 us tile at K = 1 280).  The residual
+        // never comes with GEGLU or a planes output: rchunks = 64, 16 rows per thread.
+        constexpr bool has_res = WIDE == 2;
+        f32x4 rvw[has_res ? 16 : 1];
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
+            if constexpr (has_res) {
+                const int oc = n_out0 + (tid & 63) * 4;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = m0 + half * 128 + (tid >> 6) + 8 * i;
+                    rvw[has_res ? i : 0] = (m < p.M && oc < p.N_out) ? *(const f32x4*)((const float*)p.residual + (int64_t)m * p.N_out + oc)
+                                                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
             if (grp == half) {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
@@ -1008,7 +1025,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             const bool hi_sec = planes && chunk >= (rchunks >> 1);
             // global column (elements) of this chunk: fp32 = 4 columns per chunk; planes = 8 columns per chunk inside its section
             const int ocol = planes ? n_out0 + (chunk - (hi_sec ? (rchunks >> 1) : 0)) * 8 : n_out0 + chunk * 4;
-            if (ocol < p.N_out) {
+            if constexpr (has_res) {            // rchunks = 64, rstep = 8: compile-time indices into rvw[]
+                if (ocol < p.N_out) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = (tid >> 6) + 8 * i;
+                        const int m = m0 + half * 128 + row;
+                        if (m >= p.M) continue;
+                        f32x4 f = *(const f32x4*)(smem + s_off(row, chunk));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] += p.beta * rvw[has_res ? i : 0][e];
+                        *(f32x4*)((float*)p.out + (int64_t)m * p.N_out + ocol) = f;
+                    }
+                }
+            } else if (ocol < p.N_out) {
                 for (int row = tid / rchunks; row < 128; row += rstep) {
                     const int m = m0 + half * 128 + row;
                     if (m >= p.M) break;
@@ -1017,13 +1047,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                         bf16* o = (bf16*)p.out + (int64_t)m * (2 * p.N_out) + (hi_sec ? p.N_out : 0) + ocol;
                         *(u32x4*)o = v;
                     } else {
-                        f32x4 f = __builtin_bit_cast(f32x4, v);
-                        if (p.residual != nullptr) {
-                            const f32x4 r = *(const f32x4*)((const float*)p.residual + (int64_t)m * p.N_out + ocol);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) f[e] += p.beta * r[e];
-                        }
-                        *(f32x4*)((float*)p.out + (int64_t)m * p.N_out + ocol) = f;
+                        *(f32x4*)((float*)p.out + (int64_t)m * p.N_out + ocol) = __builtin_bit_cast(f32x4, v);
                     }
                 }
             }
@@ -1272,10 +1296,13 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
             }
         }
     }
-    if (split) return a.out_kind != 0 ? gemm_go<gemm256_kernel<bf16, 3, false, 0, true>, G_SMEM>(grid1, s, a)
-                                      : gemm_go<gemm256_kernel<bf16, 3, false, 0, false>, G_SMEM>(grid1, s, a);
-    if (w2) return a.out_kind != 0 ? gemm_go<gemm256_kernel<f16, 2, false, 0, true>, G_SMEM>(grid1, s, a)
-                                   : gemm_go<gemm256_kernel<f16, 2, false, 0, false>, G_SMEM>(grid1, s, a);
+    const int wide = a.out_kind == 0 ? 0 : (a.out_kind == 1 && a.residual != nullptr) ? 2 : 1;
+    if (split) return wide == 2 ? gemm_go<gemm256_kernel<bf16, 3, false, 0, 2>, G_SMEM>(grid1, s, a)
+                    : wide == 1 ? gemm_go<gemm256_kernel<bf16, 3, false, 0, 1>, G_SMEM>(grid1, s, a)
+                                : gemm_go<gemm256_kernel<bf16, 3, false, 0, 0>, G_SMEM>(grid1, s, a);
+    if (w2) return wide == 2 ? gemm_go<gemm256_kernel<f16, 2, false, 0, 2>, G_SMEM>(grid1, s, a)
+                 : wide == 1 ? gemm_go<gemm256_kernel<f16, 2, false, 0, 1>, G_SMEM>(grid1, s, a)
+                             : gemm_go<gemm256_kernel<f16, 2, false, 0, 0>, G_SMEM>(grid1, s, a);
     return d->dtype == RSVLD_F16 ? gemm_go<gemm256_kernel<f16, 1, false>, G_SMEM>(grid1, s, a)
                                  : gemm_go<gemm256_kernel<bf16, 1, false>, G_SMEM>(grid1, s, a);
 }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void planes_to_f16_kernel(const bf16* __restri
         unpack8<bf16>(*(const u32x4*)(y + row * ld + c), l);
         unpack8<bf16>(*(const u32x4*)(y + row * ld + ps + c), h);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] += l[e];
+        for (int e = 0; e < 8; ++e) h[e] = fminf(fmaxf(h[e] + l[e], -65504.f), 65504.f);   // saturate: a finite fp32 value stays finite (NaN passes)
         *(u32x4*)(o + row * old + c) = pack8<f16>(h);
     }
 }
@@ -1201,6 +1201,8 @@ extern "C" int rsvld_attention_split_d64(const void* q, const void* k, const voi
     if ((q_batch_stride | q_tok_stride | q_plane | k_batch_stride | k_tok_stride | k_plane | v_batch_stride | v_tok_stride | v_plane) % 8 != 0)
         return RSVLD_EINVAL;   // 16-byte vector accesses
     if ((o_batch_stride | o_tok_stride | o_plane) % 4 != 0) return RSVLD_EINVAL;
+    // the kernel forms 32-bit lane offsets row * row_bytes with row <= 15 inside a 16-row piece group
+    if (16 * k_tok_stride * 2 >= ((int64_t)1 << 32) || 16 * v_tok_stride * 2 >= ((int64_t)1 << 32)) return RSVLD_EUNSUPPORTED;
     AttnSplitArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.out = out; a.Nq = Nq; a.Nk = Nk;
     a.q_bs = q_batch_stride; a.q_ts = q_tok_stride; a.q_pl = q_plane; a.k_bs = k_batch_stride; a.k_ts = k_tok_stride; a.k_pl = k_plane;

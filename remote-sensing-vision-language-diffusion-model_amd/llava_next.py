@@ -402,14 +402,39 @@ class FastDecoder:
             h = h + self._lin(torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:], layer.mlp.down_proj.weight)
         return self._lin(self._rms(h[-1:], m.norm), self.model.lm_head.weight, self.model.lm_head.bias)
 
-    def _pick(self, logits, do_sample, temperature):
+    def _pick(self, logits, do_sample, temperature, top_k=0, top_p=1.0):
+        """``generate``'s sampling chain (transformers' TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> multinomial).
+        The reference calls ``generate(do_sample=True, temperature=0.2)`` (models/util.py:50-60) and thereby inherits the generation
+        config's ``top_k`` (transformers' default: 50): sampling the full softmax instead would be a different sampler."""
         if not do_sample:
             return logits.argmax(-1)
-        return torch.multinomial(torch.softmax(logits.float() / temperature, dim=-1), 1)[:, 0]
+        scores = logits.float() / temperature
+        if top_k and top_k > 0:
+            kth = torch.topk(scores, min(int(top_k), scores.shape[-1]))[0][..., -1, None]
+            scores = scores.masked_fill(scores < kth, float("-inf"))
+        if top_p is not None and top_p < 1.0:
+            srt, idx = torch.sort(scores, descending=False)
+            remove = srt.softmax(dim=-1).cumsum(dim=-1) <= (1.0 - top_p)
+            remove[..., -1:] = False                                   # min_tokens_to_keep = 1
+            scores = scores.masked_fill(remove.scatter(-1, idx, remove), float("-inf"))
+        return torch.multinomial(torch.softmax(scores, dim=-1), 1)[:, 0]
+
+    def _sampling_defaults(self, do_sample, top_k, top_p):
+        """``None`` = what ``generate`` would take from the model's generation_config for a sampling call (top_k 50, top_p 1.0 unless
+        the checkpoint says otherwise)."""
+        g = getattr(self.model, "generation_config", None)
+        if top_k is None:
+            top_k = getattr(g, "top_k", 50) if do_sample else 0
+        if top_p is None:
+            top_p = getattr(g, "top_p", 1.0) if do_sample else 1.0
+        return (top_k or 0), (1.0 if top_p is None else top_p)
 
     @torch.no_grad()
-    def generate(self, inputs_embeds, max_new_tokens, do_sample=False, temperature=1.0, eos_token_id=None, use_graph=None):
-        """-> ``[n]`` generated token ids (n <= max_new_tokens; stops after an ``eos_token_id``, which is included)."""
+    def generate(self, inputs_embeds, max_new_tokens, do_sample=False, temperature=1.0, eos_token_id=None, use_graph=None,
+                 top_k=None, top_p=None):
+        """-> ``[n]`` generated token ids (n <= max_new_tokens; stops after an ``eos_token_id``, which is included).
+        ``top_k`` / ``top_p``: None = the generation config's values, as ``generate`` resolves them."""
+        top_k, top_p = self._sampling_defaults(do_sample, top_k, top_p)
         T0 = inputs_embeds.shape[1]
         if T0 + max_new_tokens > self.max_len:
             raise ValueError(f"FastDecoder: prompt {T0} + {max_new_tokens} new tokens exceed the cache ({self.max_len})")
@@ -421,7 +446,7 @@ class FastDecoder:
             torch.cuda.synchronize()
             t_start = time.perf_counter()
         logits = self.forward(inputs_embeds.to(self.dt), torch.arange(T0, device=self.dev))
-        tok = self._pick(logits, do_sample, temperature)
+        tok = self._pick(logits, do_sample, temperature, top_k, top_p)
         out = [tok]
         if self.profile is not None:
             torch.cuda.synchronize()
@@ -446,7 +471,7 @@ class FastDecoder:
                 logits = self._logits
             else:
                 logits = self.forward(embed(tok)[None], torch.tensor([T0 + n - 1], device=self.dev))
-            tok = self._pick(logits, do_sample, temperature)
+            tok = self._pick(logits, do_sample, temperature, top_k, top_p)
             out.append(tok)
         if self.profile is not None:
             torch.cuda.synchronize()
@@ -611,7 +636,12 @@ def get_img_describe(image_tensor, image, model, tokenizer, prompt, conv_templat
     mdev = next(model.parameters()).device
     fast = (mdev.type == "cuda" and num_beams == 1) if fast is None else fast
     if fast and _has_logits_warpers(model):
-        fast = False     # FastDecoder samples with temperature only: a generation_config with top_k / top_p / penalties goes through generate()
+        # FastDecoder implements generate()'s temperature / top_k / top_p chain; a generation_config with typical_p, min_p, penalties or
+        # banned tokens goes through transformers' generate() (~4 x slower per token), and says so
+        import warnings
+        warnings.warn("llava_next: the checkpoint's generation_config asks for logits processors FastDecoder does not implement; "
+                      "captioning through transformers' generate()")
+        fast = False
 
     def run():
         if fast:   # (no_grad, not inference_mode: tensors made in inference mode cannot be updated in place by a later call
@@ -633,19 +663,18 @@ def get_img_describe(image_tensor, image, model, tokenizer, prompt, conv_templat
 
 
 def _has_logits_warpers(model):
-    """True when the checkpoint's generation_config asks for logits processing FastDecoder does not implement (it applies the
-    temperature and samples): top_k / top_p / typical_p / penalties.  transformers' defaults (top_k 50 included) count as unset
-    only when they are the library defaults AND sampling would not use them -- top_k = 50 is a default that generate() DOES apply,
-    so any top_k counts."""
+    """True when the checkpoint's generation_config asks for logits processing FastDecoder does not implement.  It implements what the
+    reference's call uses: temperature, top_k (the config's value; transformers' default 50 IS applied by a sampling generate())
+    and top_p; typical_p / min_p / penalties / banned or suppressed tokens are not."""
     g = getattr(model, "generation_config", None)
     if g is None:
         return False
     def differs(name, neutral):
         v = getattr(g, name, None)
         return v is not None and v != neutral
-    return (differs("top_p", 1.0) or differs("typical_p", 1.0) or differs("repetition_penalty", 1.0) or differs("no_repeat_ngram_size", 0)
-            or differs("min_p", None) or (getattr(g, "do_sample", False) and differs("top_k", 0) and differs("top_k", None) and getattr(g, "top_k", 50) != 50)
-            or differs("encoder_repetition_penalty", 1.0) or bool(getattr(g, "bad_words_ids", None)) or bool(getattr(g, "suppress_tokens", None)))
+    return (differs("typical_p", 1.0) or differs("repetition_penalty", 1.0) or differs("no_repeat_ngram_size", 0)
+            or differs("min_p", None) or differs("encoder_repetition_penalty", 1.0) or bool(getattr(g, "bad_words_ids", None))
+            or bool(getattr(g, "suppress_tokens", None)))
 
 
 def caption_tokens_fast(model, input_ids, images, image_sizes, max_new_tokens, do_sample, temperature, eos_ids=None):

@@ -82,14 +82,14 @@ S2_SHIPPED_BOUND = (1.2e-1, 1.5e-2)
 
 @pytest.fixture(scope="module")
 def s1_runs(cuda):
-    """BASELINE configs[1] (128 -> 512 x4, batch 4) over all T = 50 ancestral steps in the three Stage-1 precisions."""
+    """BASELINE configs[1] (128 -> 512 x4, batch 4) over all T = 50 ancestral steps in the four Stage-1 precisions."""
     import bench
     net, _ = bench.build_stage1(50)
     cond = bench.stage1_input([0, 1, 2, 3], 128, 4).to(cuda)
     net.noise_source = "cpu"
     net.use_graph = False
     res = {}
-    for prec in ("fp32", "split", "fp16"):
+    for prec in ("fp32", "split", "w2", "fp16"):
         net.denoise_fn.set_compute_dtype(prec)
         torch.manual_seed(0)
         res[prec] = net.super_resolution(cond, continous=True)[-4:].cpu()
@@ -102,6 +102,10 @@ def test_stage1_config1_T50_batch4_split_inside_1e3(s1_runs):
     d = (s1_runs["split"] - want).abs()
     print(f"Stage 1, configs[1] (512^2, batch 4), T = 50: split vs fp32 family max|d| = {float(d.max()):.3e}, mean|d| = {float(d.mean()):.3e}")
     assert float(d.max()) < 1e-3 and float(d.mean()) < 1e-4
+    # "w2" = what bench.py's headline runs Stage 1 in: fp16 tensors, every weight as the fp16 pair [W_lo | W_hi] (two MFMAs per product)
+    dw = (s1_runs["w2"] - want).abs()
+    print(f"Stage 1, configs[1] (512^2, batch 4), T = 50: w2 (fp16 x weight pairs) vs fp32 family max|d| = {float(dw.max()):.3e}, mean|d| = {float(dw.mean()):.3e}")
+    assert float(dw.max()) < 1e-3 and float(dw.mean()) < 1e-4
     d16 = (s1_runs["fp16"] - want).abs()
     print(f"Stage 1, configs[1] (512^2, batch 4), T = 50: fp16 vs fp32 family max|d| = {float(d16.max()):.3e}, mean|d| = {float(d16.mean()):.3e}")
     assert float(d16.max()) < 1e-2 and float(d16.mean()) < 1e-3

@@ -514,7 +514,7 @@ def test_norms_fp16_hand_over(cuda):
     with ops.f32_split(ops.UNET_POLICY):
         ln16 = ops.layer_norm(x, ga, be, 1e-5, planes=True, group="ff")
         ln32 = ops.layer_norm(x, ga, be, 1e-5)
-        lnp = ops.layer_norm(x, ga, be, 1e-5, planes=True, group="qkv")          # "qkv" is not in the default policy: planes
+        lnp = ops.layer_norm(x, ga, be, 1e-5, planes=True, group="proj")         # "proj" is not in the default policy: planes
         gn16 = ops.group_norm(x, ga, be, 32, 1e-6, silu=True, planes=True, group="ff")
         gn32 = ops.group_norm(x, ga, be, 32, 1e-6, silu=True)
     assert ln16.dtype == torch.float16 and gn16.dtype == torch.float16 and isinstance(lnp, ops.Planes)

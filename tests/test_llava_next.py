@@ -171,3 +171,25 @@ def test_fast_decoder_reproduces_the_reference_generations(setup, n):
         sampled = LN.caption_tokens_fast(model, ids, images, [img.size], 16, True, 0.2, LN._eos_ids(model, tok))
     assert greedy.tolist() == z[f"i{n}.greedy"].tolist()
     assert sampled.tolist() == z[f"i{n}.sampled"].tolist()
+
+
+def test_fast_decoder_sampling_chain_equals_transformers_warpers():
+    """FastDecoder._pick = generate()'s chain for the reference's call (models/util.py:50-60: do_sample, temperature 0.2, the generation
+    config's top_k = 50 and top_p): the same masked scores as transformers' own warpers, hence the same draw for one generator state."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    from rsvld_amd.llava_next import FastDecoder
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(4, 1000, generator=g) * 3
+    ids = torch.zeros(4, 1, dtype=torch.long)
+    for temp, k, p in ((0.2, 50, 1.0), (0.7, 0, 0.9), (1.0, 5, 0.5), (0.2, 0, 1.0)):
+        want = TemperatureLogitsWarper(temp)(ids, logits.clone())
+        if k:
+            want = TopKLogitsWarper(k)(ids, want)
+        if p < 1.0:
+            want = TopPLogitsWarper(p)(ids, want)
+        torch.manual_seed(11)
+        tok_w = torch.multinomial(torch.softmax(want, dim=-1), 1)[:, 0]
+        torch.manual_seed(11)
+        tok = FastDecoder._pick(None, logits, True, temp, k, p)
+        assert torch.equal(tok, tok_w), (temp, k, p)
+    assert torch.equal(FastDecoder._pick(None, logits, False, 1.0), logits.argmax(-1))

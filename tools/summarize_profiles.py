@@ -16,13 +16,25 @@ import os
 import re
 
 
+SEG_SFX = {"1": "", "2": "_w2", "3": "_split"}   # round 5: the K-segment template parameter of the matrix kernels (pairs / triples)
+
+
 def short_name(n):
-    m = re.search(r"conv_halo(?:32)?_kernelI(\w+?)Li(\d+)E", n)   # conv_halo32 is the Cout > 64 variant: same bench label
+    m = re.search(r"conv_halo(?:32)?_kernelI(\w+?)Li(\d+)ELi\d+ELi\d+ELi(\d)E", n)   # <T, BN, ., ., SEG>
+    if m:
+        return "conv_halo_%s%s" % (m.group(2), SEG_SFX.get(m.group(3), ""))
+    m = re.search(r"conv_halo(?:32)?_kernelI(\w+?)Li(\d+)E", n)   # conv_halo32 is the Cout > 64 variant: same bench label (rounds 1-4 names)
     if m:
         return "conv_halo_%s" % m.group(2)
+    m = re.search(r"conv_igemm_kernelI\w+?Li(\d+)ELi(\d+)ELi\d+ELi\d+ELb[01]ELi\d+ELi\d+ELi(\d)E", n)   # <T, BM, BN, ., ., GLDS, STAGES, KS, SEG>
+    if m:
+        return "conv_igemm_%sx%s%s" % (m.group(1), m.group(2), SEG_SFX.get(m.group(3), ""))
     m = re.search(r"conv_igemm_kernelI\w+?Li(\d+)ELi(\d+)E", n)
     if m:
         return "conv_igemm_%sx%s" % (m.group(1), m.group(2))
+    m = re.search(r"gemm256_kernelI\w+?Li(\d)ELb[01]E", n)   # <T, SEG, PERSIST, PV, WIDE>
+    if m:
+        return "gemm256" + SEG_SFX.get(m.group(1), "")
     m = re.search(r"attn_d(\d+)b?_kernel", n)
     if m:
         return "attn_d%s" % m.group(1)
