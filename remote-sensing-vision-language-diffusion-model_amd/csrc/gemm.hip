@@ -131,7 +131,9 @@ template <int N> __device__ __forceinline__ void g_wait_vm() { asm volatile("s_w
 // shares vmcnt with the LDS-DMA ring).
 template <typename T, int SEG = 1, bool PERSIST = false, int PV = 0, int WIDE = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
-    static_assert(WIDE == 0 || (SEG > 1 && !PERSIST), "the fp32 / planes epilogue belongs to the one-tile multi-segment kernels");
+    static_assert(WIDE == 0 || SEG > 1, "the fp32 / planes epilogues belong to the multi-segment kernels");
+    static_assert(!(PERSIST && WIDE == 1), "persistent form: the 16-bit epilogue (WIDE 0) or fp32 out + fp32 residual (WIDE 2, PV 4 = none)");
+    static_assert(!(PERSIST && WIDE == 2) || PV == 0, "the persistent fp32 epilogue has one variant: no activation, alpha, + beta * residual");
     static_assert(SEG >= 1 && SEG <= 3, "1 plain, 2 fp16 x weight pairs, 3 bf16 planes x weight triples");
     static_assert(SEG == 1 || !(PV & 8), "the persistent residual variants are 16-bit residuals (plain GEMM only)");
     static_assert(PERSIST || PV == 0, "PV is the persistent epilogue's variant");
@@ -290,11 +292,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     // MFMA slot) -- and a branch around every piece.  Here the tile's row base is a scalar (SGPR pair), the lane's row / swizzle
     // offset a 32-bit VGPR that lives across the loop, and M0 (the LDS destination) is written inside the statement and
     // declared clobbered: nothing else in this file uses M0 (tools/audit_m0.py checks the assembly).
+    // (the tile's row bases are wave-uniform by construction; behind the per-lane store guards of the persistent fp32 epilogue hipcc's
+    //  uniformity analysis gave up on them and handed the asm statements VGPR pairs: readfirstlane states the fact -- in THAT instantiation
+    //  only: it does not fold away where the value already lives in SGPRs (+59 instructions per kernel when applied everywhere))
+    auto uni = [](const char* q) __attribute__((always_inline)) {
+        if constexpr (!(PERSIST && WIDE == 2)) return q;
+        const uint64_t v = (uint64_t)(uintptr_t)q;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    };
     auto dma_piece = [&](int kt, int j) {
 #if G_ASMDMA
         const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024);
         const int ktx = (G_ABL & 8) ? (kt & 3) : xk(kt);
-        const char* base = (j & 1) ? Wb + ((G_ABL & 8) ? (kt & 3) : kt) * 64 : Xb + ktx * 64;
+        const char* base = uni((j & 1) ? Wb + ((G_ABL & 8) ? (kt & 3) : kt) * 64 : Xb + ktx * 64);
         const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[j >> 1];
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
 #else
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     for (int ks = 0; ks < 2; ++ks) fbh_off[ks] = g_off(grp * 64 + l31, 2 * ks + lh);
     auto dma_piece_h = [&](int kt, int j) {   // j = 0: the wave's X rows; 1, 3: its W rows as in a whole tile
         const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + ((j & 1) ? wave * 2048 + 16384 + (j >> 1) * 1024 : wave * 1024));
-        const char* base = (j & 1) ? Wb + kt * 64 : Xb + xk(kt) * 64;
+        const char* base = uni((j & 1) ? Wb + kt * 64 : Xb + xk(kt) * 64);
         const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[0];
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
     };
@@ -696,6 +707,56 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             // then): hipcc's own wait insertion does not see the LDS-DMA statements and would count them short, i.e. wait for the
             // ring in front of every residual use.  vmcnt counts in order on gfx9, stores included.
             const int m0e = m0, n0e = n0;
+            if constexpr (WIDE == 2) {
+                // ---- fp32 out + fp32 residual (round 5: ff.net.2, to_out, proj_out of the tolerance-compliant composition; the one-tile
+                // form left 25-30 % of such a tile outside its K loop).  The wave's eight 32 x 32 fp32 half-blocks (4 KiB: the private
+                // buffer's size) go accumulators -> P -> registers as whole 128-byte rows, 8 rows per store instruction; the residual
+                // pieces of half-block hb + 1 are requested before half-block hb is read back.  The next tile's ring pieces are requested
+                // FIRST: every later wait for a residual piece (a load the compiler sees and counts) then covers them -- vmcnt retires
+                // in order -- and they have the whole epilogue to land in.
+                if (has_next) {
+                    setup_tile(t_next, h_next);
+                    dma_bias(n0);
+                    if (h_next < 0) { dma_tile(0); dma_tile(1); dma_tile(2); }
+                    else { dma_tile_h(0); dma_tile_h(1); dma_tile_h(2); }
+                }
+                const int rrow = lane >> 3, rchunk = lane & 7;
+                const int wb32 = l31 * 128, x7w = l31 & 7;
+                const int rb32 = rrow * 128 + ((rchunk ^ (rrow & 7)) << 4);        // + i * 1024: rows rrow + 8 i (same row & 7)
+                const int ncol = n0e + wn * 64 + 4 * rchunk;                        // + 32 ni
+                const int mrow = m0e + grp * (32 * MI) + rrow;                      // + 32 mi + 8 i
+                f32x4 rvp[2][4];
+                auto load_res = [&](int hb, f32x4 (&r)[4]) {
+                    const int n = ncol + (hb & 1) * 32;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {   // rows / columns past the end re-read a valid address (never stored)
+                        const int m = mrow + (hb >> 1) * 32 + 8 * i;
+                        r[i] = *(const f32x4*)((const float*)p.residual + (int64_t)min(m, p.M - 1) * p.N_out + (n < p.N_out ? n : 0));
+                    }
+                };
+                load_res(0, rvp[0]);
+#pragma unroll
+                for (int hb = 0; hb < 2 * MI; ++hb) {
+                    const int mi = hb >> 1, ni = hb & 1;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e] * p.alpha;
+                        *(f32x4*)(P + wb32 + (((2 * g + lh) ^ x7w) << 4)) = v;
+                    }
+                    if (hb + 1 < 2 * MI) load_res(hb + 1, rvp[(hb + 1) & 1]);
+                    const int n = ncol + ni * 32;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 o = *(const f32x4*)(P + rb32 + i * 1024);
+                        const int m = mrow + mi * 32 + 8 * i;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += p.beta * rvp[hb & 1][i][e];
+                        if (m < p.M && n < p.N_out && !((G_ABL & 1) && p.M > 0)) *(f32x4*)((float*)p.out + (int64_t)m * p.N_out + n) = o;
+                    }
+                }
+            } else
             // ---- every wave: its four 32-row blocks through the private buffer.  ONE dispatch on (activation, alpha == 1, residual)
             // around everything that follows, so that the 64 residual registers exist in the residual variants only.
             {
@@ -1267,7 +1328,8 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     const unsigned nmt = (unsigned)((M + 255) / 256), nnt = (unsigned)((d->Cout + 255) / 256);
     const dim3 grid1(nmt, nnt);
     // the persistent form: 16-bit output, at least four K tiles (its K loop peels tile 0 and requests three tiles ahead)
-    if (!(d->tune & RSVLD_TUNE_GEMM_ONE_TILE) && a.out_kind == 0 && seg * d->Cin >= 128) {
+    const bool wide_res = seg > 1 && a.out_kind == 1 && a.residual != nullptr && a.act == RSVLD_ACT_NONE;   // fp32 out + fp32 residual
+    if (!(d->tune & RSVLD_TUNE_GEMM_ONE_TILE) && (a.out_kind == 0 || wide_res) && seg * d->Cin >= 128) {
         static const int n_cu = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -1277,7 +1339,10 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
             const dim3 pgrid((unsigned)min((int64_t)nmt * nnt, (int64_t)n_cu));
             const int pv = (a.act == RSVLD_ACT_GEGLU ? 2 : a.act == RSVLD_ACT_SILU ? 1 : 0) | (a.alpha == 1.0f ? 4 : 0) | (a.residual != nullptr ? 8 : 0);
             const bool h = d->dtype == RSVLD_F16;
-            if (seg == 1) {
+            if (wide_res) {
+                return split ? gemm_go<gemm256_kernel<bf16, 3, true, 0, 2>, G_SMEM_P>(pgrid, s, a)
+                             : gemm_go<gemm256_kernel<f16, 2, true, 0, 2>, G_SMEM_P>(pgrid, s, a);
+            } else if (seg == 1) {
 #define G_PV_CASE(V) case V: return h ? gemm_go<gemm256_kernel<f16, 1, true, V>, G_SMEM_P>(pgrid, s, a) : gemm_go<gemm256_kernel<bf16, 1, true, V>, G_SMEM_P>(pgrid, s, a);
                 switch (pv) {
                     G_PV_CASE(0) G_PV_CASE(4) G_PV_CASE(8) G_PV_CASE(12)      // no activation: alpha, alpha == 1, + residual

@@ -394,7 +394,9 @@ W2_LINEAR_CASES = [
     # rows, K, N, residual (fp32), geglu, f16 out
     (8192, 640, 5120, False, True, True),        # GEGLU feed-forward, fp16 out: the persistent gemm256 (SEG = 2)
     (8192 + 77, 2560, 640, True, False, False),  # ff.net.2 with the fp32 residual: one-tile form, fp32 epilogue, ragged rows
-    (16384, 1280, 1280, True, False, False),     # to_out on the fp16 attention output
+    (16384, 1280, 1280, True, False, False),     # to_out on the fp16 attention output: the persistent form's fp32 + residual epilogue, half tiles
+    (20000, 640, 640, True, False, False),       # the same, ragged rows and a ragged last column tile (N = 640 = 2.5 tiles)
+    (66000, 320, 256, True, False, False),       # one column tile, 258 row tiles over 256 workgroups
     (4096, 64, 320, False, False, True),         # K' = 128: four K tiles, the persistent form's minimum
     (300, 640, 640, True, False, False),         # small M: the implicit-GEMM kernel (SEG = 2)
     (1000, 72, 80, False, True, True),           # K, N multiples of 8 only, GEGLU, fp16 out
