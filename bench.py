@@ -446,23 +446,57 @@ def bench_headline(args, dev, rank, world):
     build_s = time.perf_counter() - t0
     thr = args.s2_threshold
 
-    def image_inputs(img_id):
-        return stage1_input([img_id], args.lr_side, args.scale).to(dev)
+    # A work unit = the BPG images one GPU holds per pass (--batch-per-gpu; BASELINE configs[3] says 16, the default line runs 1: a
+    # 4096^2 image saturates the chip by itself, so the per-image time is the same and 16 x 25 iterations do not fit the driver's
+    # clock).  Images are independent (infer_dir.py:196-201 runs them one at a time): inside a unit Stage 1 and Stage 2 run in
+    # sub-batches (--s1-chunk / --s2-chunk) sized so that the 4096^2 activations of a sub-batch stay resident; with the feature cache
+    # on, every image of a Stage-2 sub-batch takes its own decision.
+    side_stream = torch.cuda.Stream(device=dev)
+    BPG = max(1, args.batch_per_gpu)
+    c1, c2 = max(1, min(args.s1_chunk, BPG)), max(1, min(args.s2_chunk, BPG))
 
-    def one_image(img_id, cond, n_iter, ph, gather=True):
-        """Stage 1 -> hand-off -> caption -> Stage 2 -> uint8 -> all-gather; ``n_iter`` sampler iterations per stage (None = all)."""
-        torch.manual_seed(42 + img_id)                      # per-image RNG streams: results do not depend on the GPU count
+    def image_inputs(unit):
+        return stage1_input([unit * BPG + i for i in range(BPG)], args.lr_side, args.scale).to(dev)
+
+    def one_image(unit, cond, n_iter, ph, gather=True):
+        """One unit: Stage 1 -> hand-off -> caption -> Stage 2 -> uint8 -> all-gather; ``n_iter`` sampler iterations per stage (None = all)."""
+        torch.manual_seed(42 + unit)                        # per-unit RNG streams: results do not depend on the GPU count
         ph.start()
-        with measure.hooks(net, stamp=ph, max_steps=n_iter):
-            sr = net.super_resolution(cond, continous=True)[-1:]
+        srs = []
+        for i0 in range(0, BPG, c1):
+            nb = min(c1, BPG - i0)
+            with measure.hooks(net, stamp=ph, max_steps=n_iter):
+                srs.append(net.super_resolution(cond[i0:i0 + nb], continous=True)[-nb:])
+        sr = srs[0] if len(srs) == 1 else torch.cat(srs)
         u8 = parallel.to_uint8(sr)                          # utils/tensor2img.py:4-21: the 8-bit hand-off
         lq = u8.float() / 127.5 - 1.0                       # models/util.py:132-156 (4096 is a multiple of 64)
+        del srs, sr
         ph("handoff")
-        caption = captioner(u8, seed=42 + img_id) if live else ""          # infer.py:145-166
+        # Stage 2's three opening VAE passes depend on the image only: with a live caption pass they are issued on a second HIP stream
+        # and run BESIDE the token loop (weight streaming: the matrix pipes idle), as rsvld_amd.infer.SuperResolutionPipeline.process
+        # does (--serial-caption restores the reference's serial order; same kernels, same random draws, same images)
+        fronts = [None] * ((BPG + c2 - 1) // c2)
+        if live and not args.serial_caption:
+            main_s = torch.cuda.current_stream()
+            side_stream.wait_stream(main_s)
+            with torch.cuda.stream(side_stream):
+                fronts = [m.vae_front(lq[i0:i0 + c2]) for i0 in range(0, BPG, c2)]
+        captions = [captioner(u8[i:i + 1], seed=42 + unit * BPG + i) if live else "" for i in range(BPG)]   # infer.py:145-166
+        if fronts[0] is not None:
+            main_s.wait_stream(side_stream)
+            for f in fronts:
+                for t in f:
+                    t.record_stream(main_s)
         ph("caption")
-        with measure.hooks(m, stamp=ph, max_steps=n_iter):
-            out = m.just_sampling(lq, [caption], **dict(S2_KW, img_threshold=thr, num_steps=T))
-        res = parallel.to_uint8(out)
+        outs, traces = [], []
+        for j, i0 in enumerate(range(0, BPG, c2)):
+            nb = min(c2, BPG - i0)
+            with measure.hooks(m, stamp=ph, max_steps=n_iter):
+                outs.append(parallel.to_uint8(m.just_sampling(lq[i0:i0 + nb], captions[i0:i0 + nb], vae_front=fronts[j],
+                                                              **dict(S2_KW, img_threshold=thr, num_steps=T))))
+            traces.append(m.cache_trace)
+        one_image.cache_traces = traces
+        res = outs[0] if len(outs) == 1 else torch.cat(outs)
         if gather:
             res = parallel.gather_images(res, world)        # one RCCL all-gather of finished uint8 images
         ph("gather")
@@ -518,11 +552,11 @@ def bench_headline(args, dev, rank, world):
     fixed = sum(v for k, v in a.items() if k not in ("s1_loop", "edm_sampler_loop"))
     dt, s1_loop, s2_loop, fixed = dist_max([dt, s1_loop, s2_loop, fixed], dev, world)
     if full:
-        value = world * K / dt
+        value = world * BPG * K / dt
         it1, it2, fx = s1_loop / (K * T), s2_loop / (K * T), fixed / K
     else:
-        it1, it2, fx = s1_loop / K, s2_loop / K, fixed
-        value = world / (T * it1 + T * it2 + fx)
+        it1, it2, fx = s1_loop / K, s2_loop / K, fixed     # (per unit of BPG images)
+        value = world * BPG / (T * it1 + T * it2 + fx)
     finite = bool(torch.isfinite(out.float()).all())
 
     # ---- data-parallel self-check (outside the timed region): every rank runs ONE iteration per stage + the fixed part on
@@ -537,13 +571,20 @@ def bench_headline(args, dev, rank, world):
             same = {}
             for probe in probes:
                 ref = one_image(probe, image_inputs(probe), 1, Phases(), gather=False)
-                same[str(probe)] = bool(torch.equal(chk[probe].cpu(), ref[0].cpu()))
+                same[str(probe)] = bool(torch.equal(chk[probe * BPG:(probe + 1) * BPG].cpu(), ref.cpu()))
             dp_check = {"images": probes, "iterations_per_stage": 1, "bit_identical_to_single_rank_run": all(same.values()),
                         "per_image": same}
         barrier(world)
 
     headline_prec = PRECISION
-    extras = rank == 0 and world == 1 and not full and not args.no_extras
+    extras = rank == 0 and world == 1 and not full and not args.no_extras and BPG == 1
+    # per-image feature-cache decisions of the timed unit (threshold > 0): hits per image over the iterations that ran
+    cache_per_image = None
+    if thr > 0 and getattr(one_image, "cache_traces", None):
+        cache_per_image = []
+        for tr in one_image.cache_traces:                      # one trace per Stage-2 sub-batch: [step][image] = (threshold, diff, hit)
+            n_img = len(tr[0]) if tr else 0
+            cache_per_image += [{"hits": int(sum(bool(step[i][2]) for step in tr)), "decisions": len(tr)} for i in range(n_img)]
 
     def guarded(fn):
         """An extra (outside `value`) must never cost the line its headline figure: an exception becomes {"error": ...}."""
@@ -642,7 +683,7 @@ def bench_headline(args, dev, rank, world):
                 "workload": ((f"BASELINE configs[3]/[4] shape = the metric's configuration: " if is_metric_cfg else
                               "BASELINE configs[2] shape (Stage 1 + Stage 2, cached text embeds): " if (args.lr_side, args.scale) == (512, 4)
                               else "two-stage pipeline: ") + f"{args.lr_side}x{args.lr_side} -> {side}x{side} "
-                             f"x{args.scale} SR, one image per GPU per pass: Stage 1 SR3 {T} ancestral DDPM steps at {side}^2 + 8-bit "
+                             f"x{args.scale} SR, {BPG} image{'s' if BPG > 1 else ''} per GPU per pass: Stage 1 SR3 {T} ancestral DDPM steps at {side}^2 + 8-bit "
                              f"hand-off + Stage 2 {T} EDM steps at latent {latent} (ControlNet + UNet, CFG pair, feature cache "
                              f"{'OFF (threshold 0): uniform work per iteration' if thr <= 0 else thr}), tiled VAE 512/64, Wavelet colour "
                              f"fix, uint8 all-gather; " + ("live LLaVA-NeXT caption pass (Llama-3-8B + CLIP-L/336 architecture, fp16, "
@@ -653,19 +694,24 @@ def bench_headline(args, dev, rank, world):
                                     f"one sampler iteration of EACH stage at the real shapes; the timed region = the per-image fixed "
                                     f"part once + exactly {K} iterations per stage; value = n_gpus / ({T}*t_S1_iter + {T}*t_S2_iter + "
                                     f"t_fixed)"),
-                "global_batch": world, "parallelism": f"dp{world}",
+                "global_batch": world * BPG, "batch_per_gpu": BPG,
+                "sub_batches": None if BPG == 1 else {"stage1_images_per_launch": c1, "stage2_images_per_launch": c2,
+                                                      "why": "images are independent units (infer_dir.py:196-201); a sub-batch keeps its 4096^2 activations resident"},
+                "max_memory_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                "parallelism": f"dp{world}",
                 "precision_mode": PRECISION, "precision": precision_report(net, m),
                 "t_s1_iter_ms": round(it1 * 1e3, 1), "t_s2_iter_ms": round(it2 * 1e3, 1), "t_fixed_ms": round(fx * 1e3, 1),
                 "t_caption_ms": round(a.get("caption", 0.0) / (K if full else 1) * 1e3, 1) if live else None,
+                "caption_overlaps_vae_front": bool(live and not args.serial_caption),
                 "t_conditioner_ms": round(a.get("conditioner", 0.0) / (K if full else 1) * 1e3, 1),
                 "caption_new_tokens": getattr(captioner, "last_tokens", None) if live else None,
                 "caption_breakdown": getattr(captioner, "breakdown", None) if live else None,
-                "seconds_per_image": round(T * it1 + T * it2 + fx, 2),
+                "seconds_per_image": round((T * it1 + T * it2 + fx) / BPG, 2),
                 "phases_ms": {k: round(v * 1e3, 1) for k, v in a.items()},
                 "timed_region_s": round(dt, 2), "model_build_s": round(build_s, 1), "finite": finite,
-                "algorithmic_tflops_whole_image": round(tf_img / (T * it1 + T * it2 + fx), 1),
+                "algorithmic_tflops_whole_image": round(tf_img * BPG / (T * it1 + T * it2 + fx), 1),
                 "mfma_busy_instrumented_pass_pmc": mfma_busy_of_pass(summ, pmc),
-                "feature_cache": "off" if thr <= 0 else thr, "dp_self_check": dp_check,
+                "feature_cache": "off" if thr <= 0 else thr, "cache_decisions_per_image": cache_per_image, "dp_self_check": dp_check,
                 "tolerance": tolerance, "reference_gpu_policy": ref_gpu, "cache_on": cache_on,
                 "collective": {"backend": (torch.distributed.get_backend() if world > 1 else None), "world_size_reported":
                                (torch.distributed.get_world_size() if world > 1 else 1), "rccl_version": rccl,
@@ -853,6 +899,10 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (c2: 4, s2: 1, c3: 8)")
+    ap.add_argument("--batch-per-gpu", type=int, default=1, help="c4 / c4full: images per GPU per pass (BASELINE configs[3] says 16; "
+                                                                "default 1: the per-image time is the same and the driver's clock is kept)")
+    ap.add_argument("--s1-chunk", type=int, default=4, help="c4 with --batch-per-gpu: images per Stage-1 launch")
+    ap.add_argument("--s2-chunk", type=int, default=2, help="c4 with --batch-per-gpu: images per Stage-2 launch (per-image cache decisions inside)")
     ap.add_argument("--lr-side", type=int, default=None)
     ap.add_argument("--scale", type=int, default=None)
     ap.add_argument("--ddpm-steps", type=int, default=50)
@@ -868,7 +918,11 @@ def main():
                     help="tolerance (c4 / c4full default): the composition inside north_star's 1e-3 of the reference's CPU path -- `value` is "
                          "timed in it, the reference's GPU policy beside it (config.reference_gpu_policy); reference-gpu = default: fp16 "
                          "UNets, bf16 VAE (what rounds 1-4 quoted; the secondary workloads' default); split / fp32 / vae-split: secondary")
+    ap.add_argument("--serial-caption", action="store_true", help="c4: the reference's serial order (caption pass, THEN Stage 2's opening VAE "
+                                                                  "passes) instead of the VAE passes on a second HIP stream beside the caption")
     ap.add_argument("--no-graph", action="store_true", help="c2: launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--unet-f16-groups", default=None, help="experiment: the ops.SplitPolicy.f16_inputs of the Stage-2 UNets (comma list) "
+                                                           "instead of ops.UNET_POLICY's")
     ap.add_argument("--profile-detail", action="store_true", help="append every matrix layer's shape to its group in roofline.by_kernel")
     ap.add_argument("--dev-env", action="store_true", help="apply the developer A/B switches of the environment (rsvld_amd.devtools.apply_env)")
     ap.add_argument("--pmc-pass", action="store_true", help="c4: one iteration of each stage + the fixed part and nothing "
@@ -900,6 +954,8 @@ def main():
         devtools.apply_env()
     if args.profile_detail:
         ops.PROFILE_DETAIL = True
+    if args.unet_f16_groups is not None:     # (the default policy object is what set_precision takes when none is passed)
+        ops.UNET_POLICY = ops.SplitPolicy(f16_inputs=tuple(g for g in args.unet_f16_groups.split(",") if g))
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

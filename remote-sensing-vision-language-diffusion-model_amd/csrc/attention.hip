@@ -86,6 +86,14 @@ constexpr float A5_DEFER_LOG2 = 8.0f;   // rescale O only when a row's running m
 #ifndef A5B_STEADY_LOOP
 #define A5B_STEADY_LOOP 1
 #endif
+// A5B_KEYWRAP = n > 0 (diagnostic build, round 5; results WRONG, timing only): the steady-state LDS-DMA requests of key tile t read tile
+// t mod n (n a power of two), i.e. the whole key stream of a launch cycles over n x 32 KiB -- n = 64: 2 MiB, resident in every XCD's
+// 4 MiB L2 -- with the same loop trip count, the same LDS traffic and the same MFMAs.  What the L2-MISS traffic of the real launch
+// (70 GB per 262 144-key launch by FETCH_SIZE, served by the Infinity Cache) costs in time = this build against the shipped one
+// (tools/attn_d512_l2_ab.sh, profiles/r05_attn_d512_l2_resident_ab.txt).
+#ifndef A5B_KEYWRAP
+#define A5B_KEYWRAP 0
+#endif
 #ifndef A5B_ABL
 #define A5B_ABL 0   // diagnostic builds (tools/ablate_attn.sh): 1 no softmax VALU, 2 no V reads, 4 no DMA, 8 no K reads, 16 no per-tile barrier
 #endif
@@ -201,9 +209,10 @@ __global__ __launch_bounds__(256) void attn_d512b_kernel(AttnArgs p, int keys_pe
         }
     };
     // the same requests for tiles known to be full (the steady-state copy of the loop body): no bounds test, no branch
-    auto dma_kb_fast = [&](int t, int buf, int i) { dma_one(k_tile0 + (int64_t)t * 32 * k_rowb, kvo[i], lds0 + buf * A5B_TILE + (wu * 8 + i) * 1024); };
+    auto tw = [](int t) { return A5B_KEYWRAP > 0 ? (t & (A5B_KEYWRAP - 1)) : t; };   // (diagnostic build: see A5B_KEYWRAP)
+    auto dma_kb_fast = [&](int t, int buf, int i) { dma_one(k_tile0 + (int64_t)tw(t) * 32 * k_rowb, kvo[i], lds0 + buf * A5B_TILE + (wu * 8 + i) * 1024); };
     auto dma_k_fast = [&](int t, int i) { dma_kb_fast(t, t & 1, i); };
-    auto dma_v_fast = [&](int t, int i) { dma_one(v_tile0 + (int64_t)t * 32 * v_rowb, vvo[i], lds0 + (2 + (t & 1)) * A5B_TILE + (wu * 8 + i) * 1024); };
+    auto dma_v_fast = [&](int t, int i) { dma_one(v_tile0 + (int64_t)tw(t) * 32 * v_rowb, vvo[i], lds0 + (2 + (t & 1)) * A5B_TILE + (wu * 8 + i) * 1024); };
     // Software pipeline: iteration t runs S(t+1) beside softmax(t), then PV(t).  K is therefore fetched two tiles ahead
     // of its PV (K(t+2) lands in the buffer S(t) read in iteration t-1), V one tile ahead.
     if constexpr (SH) {   // X(0) -> buffer 0, X(1) -> buffer 1

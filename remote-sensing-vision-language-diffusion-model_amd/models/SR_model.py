@@ -92,6 +92,22 @@ class SR_backbone(DiffusionEngine):
     def batchify_denoise(self, x, is_stage1=False):
         return self.decode_first_stage(self.encode_first_stage_with_denoise(x, use_sample=False, is_stage1=is_stage1))
 
+    @torch.no_grad()
+    def vae_front(self, x, num_samples=1):
+        """The three VAE passes that open ``just_sampling`` (:236-246: denoise-encode, decode, re-encode) -> ``(_z, x_stage1, z_stage1)``
+        for ``just_sampling(..., vae_front=...)``.  They depend on the image only, not on the caption: a caller may issue them on a
+        second HIP stream while the caption pass (a weight-streaming token loop that leaves the matrix pipes idle) runs on the first.
+        Same kernels, same order of random draws (the posterior sample is the only one; the caption samples inside a forked generator)."""
+        from .. import ops
+        x = x.float().contiguous()
+        if num_samples > 1:
+            x = x.repeat(num_samples, 1, 1, 1)
+        with ops.plan_units(len(x)):
+            _z = self.encode_first_stage_with_denoise(x, use_sample=False)
+            x_stage1 = self.decode_first_stage(_z)
+            z_stage1 = self.encode_first_stage(x_stage1)
+        return _z, x_stage1, z_stage1
+
     def init_tile_vae(self, encoder_tile_size=512, decoder_tile_size=64):
         from ..utils.tilevae import VAEHook
         fs = self.first_stage_model
@@ -171,12 +187,16 @@ class SR_backbone(DiffusionEngine):
                 _stamp(name)
 
         x = x.float().contiguous()
-        _z = self.encode_first_stage_with_denoise(x, use_sample=False)
-        stamp("vae_denoise_encode")
-        x_stage1 = self.decode_first_stage(_z)
-        stamp("vae_decode_stage1")
-        z_stage1 = self.encode_first_stage(x_stage1)
-        stamp("vae_encode_stage1")
+        front = kwargs.pop("vae_front", None)
+        if front is None:
+            _z = self.encode_first_stage_with_denoise(x, use_sample=False)
+            stamp("vae_denoise_encode")
+            x_stage1 = self.decode_first_stage(_z)
+            stamp("vae_decode_stage1")
+            z_stage1 = self.encode_first_stage(x_stage1)
+            stamp("vae_encode_stage1")
+        else:       # computed ahead of the call (``vae_front``), e.g. on a second stream beside the caption pass
+            _z, x_stage1, z_stage1 = front
         c_img, uc_img = self.prepare_condition(_z, p, p_p, n_p, N)
         stamp("conditioner")
 

@@ -79,12 +79,15 @@ class SplitPolicy:
                       "ff"        the two inputs of a FeedForward: LayerNorm3's output and the GEGLU product
                       "qkv"       the inputs of to_q / to_k / to_v: LayerNorm1 / LayerNorm2's outputs (ZeroCrossAttn: its two GroupNorms)
                       "proj"      the inputs of proj_in / proj_out -- measured (+1.3e-4 after 50 steps for two GEMMs per transformer): not
-                                  in the default.  (Convolution inputs are not offered: 3.4e-3 on the CPU restatement.)
+                                  in the default.
+                      "conv"      the inputs of the ResBlocks' two 3x3 convolutions (GroupNorm + SiLU outputs; NOT conv_in, the
+                                  Down / Upsample and ZeroSFT convolutions or the output convolution) -- an experiment: every
+                                  convolution input in fp16 is 3.4e-3 on the CPU restatement.
                     Measured after 50 Stage-2 steps against the reference's CPU run (tools/tolerance_check.py, round 5, max / mean):
                     ("attn",) 2.5e-4 / 3.8e-5; + attn_out + ff 3.5e-4 / 4.6e-5; + qkv 3.5e-4 / 5.3e-5; + proj 4.8e-4 / 6.5e-5."""
 
     __slots__ = ("impl", "f16_inputs")
-    GROUPS = ("attn", "attn_out", "ff", "qkv", "proj")
+    GROUPS = ("attn", "attn_out", "ff", "qkv", "proj", "conv")
 
     def __init__(self, impl="planes", f16_inputs=("attn", "attn_out", "ff", "qkv")):
         if impl not in ("planes", "f32"):
@@ -356,12 +359,13 @@ def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
 USE_HALO = True      # route eligible 3x3 convs through conv_halo.hip (set False to A/B against the gather kernel)
 HALO_MIN_WGS = 256   # below one workgroup per CU the 8x32-pixel halo tile under-fills the chip (measured 130 vs
                      # 334 TFLOP/s on 32x32 maps): such layers use the 64x128 gather kernel with the 3-stage ring
-SPLIT_HALO_MIN_WGS = 128   # the split precision: its gather kernel runs at 190-200 effective TFLOP/s where the halo kernel does 385-400, so the
-                     # halo tile pays from half a chip of workgroups per planning unit (the 86 x 86 x 512 tiles of the tiled VAE: 132)
+SPLIT_HALO_MIN_WGS = 64    # the split precision: its gather kernel runs at 190-200 effective TFLOP/s where the halo kernel does 385-400, and
+                     # the small maps of this precision are the tiles of the tiled VAE, stacked 7-49 per launch (86 x 86 x 512: 132 workgroups
+                     # per planning unit, 72 x 72: 108, 86 x 64: 88): the halo tile from a quarter of a chip per unit
 
 
 def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, residual=None,
-           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False, out_planes=False, out_group=None):
+           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False, out_planes=False, out_group=None, norm_group=None):
     """NHWC convolution.  ``pad`` = int or (top, left, bottom, right).
 
     ``norm=(gamma, beta, groups, eps, silu)``: a GroupNorm(+SiLU) over the input ([x | x2]) precedes the
@@ -382,7 +386,8 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     _need_gpu(x, x2, pc.w, rowvec, residual)
     if isinstance(x, Planes) or (x.dtype == torch.float32 and _split_fast()):
         return _conv2d_split(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
-                             act=act, alpha=alpha, beta=beta, norm=norm, stats=stats, out_planes=out_planes, out_group=out_group)
+                             act=act, alpha=alpha, beta=beta, norm=norm, stats=stats, out_planes=out_planes, out_group=out_group,
+                             norm_group=norm_group)
     if x.dtype == torch.float32:
         return _conv2d_f32(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
                            act=act, alpha=alpha, beta=beta, norm=norm)
@@ -619,7 +624,8 @@ def _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample):
     return f" [{B}x{Ho}x{Wo} {Cin}+{Cin2}->{pc.cout_p} k{pc.kh} s{stride}{' up' if upsample else ''}]"
 
 
-def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm, stats, out_planes, out_group=None):
+def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm, stats, out_planes, out_group=None,
+                  norm_group=None):
     """The split-operand product path of conv2d / linear: bf16 planes in (split here when the caller hands fp32), weight triples,
     the 16-bit kernels with dtype RSVLD_SPLIT; fp32 (or Planes, or -- a 1x1 layer whose consumer group takes fp16 -- fp16) out,
     fp32 residual."""
@@ -629,6 +635,10 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
         if isinstance(x, Planes) or isinstance(x2, Planes):
             raise L.RsvldError("conv2d (split): norm= needs the fp32 tensors")
         ab = _gn_scale_shift_f32(x, x2, gamma, nbeta, groups, eps)
+        if f16_group(norm_group):     # the policy hands this convolution's input over in fp16: the weight-pair form (fp32 out, fp32 residual)
+            x16 = _gn_apply_split(x, x2, ab, silu, planes=True, f16=True)
+            return conv2d(x16, pc, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual, act=act, alpha=alpha,
+                          beta=beta, stats=stats, out_planes=out_planes)
         x, x2 = _gn_apply_split(x, x2, ab, silu, planes=True), None
     x = to_planes(x)
     x2 = None if x2 is None else to_planes(x2)
