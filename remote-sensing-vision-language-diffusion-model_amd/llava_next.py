@@ -443,13 +443,13 @@ class FastDecoder:
         embed = self.model.model.embed_tokens
         if self.profile is not None:
             import time
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()   # (this stream only: a caller may run other work on a second stream beside the token loop)
             t_start = time.perf_counter()
         logits = self.forward(inputs_embeds.to(self.dt), torch.arange(T0, device=self.dev))
         tok = self._pick(logits, do_sample, temperature, top_k, top_p)
         out = [tok]
         if self.profile is not None:
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()   # (this stream only: a caller may run other work on a second stream beside the token loop)
             t_prefill = time.perf_counter()
         if use_graph and self._graph is None:
             self._tok, self._pos = tok.clone(), torch.tensor([T0], device=self.dev)
@@ -474,7 +474,7 @@ class FastDecoder:
             tok = self._pick(logits, do_sample, temperature, top_k, top_p)
             out.append(tok)
         if self.profile is not None:
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()   # (this stream only: a caller may run other work on a second stream beside the token loop)
             self.profile.update(prompt_tokens=T0, prefill_s=t_prefill - t_start, decode_s=time.perf_counter() - t_prefill,
                                 new_tokens=len(out))
         return torch.cat(out)
