@@ -39,10 +39,13 @@ def _s2_run(m, cuda, prec, thr):
 @pytest.fixture(scope="module")
 def s2_runs(cuda, full_model):
     """All six 50-step runs (3 precisions x cache off / 0.3) of the full-size Stage 2 at latent 64, computed once."""
+    import hashlib
     res = {}
     for thr in (0.0, 0.3):
         for prec in S2_MODES:
             res[prec, thr] = _s2_run(full_model, cuda, prec, thr)
+            # (fingerprints: the same tree must print the same digests whatever ran earlier in the process)
+            print(f"   digest [{prec}, cache {thr}]: {hashlib.sha1(res[prec, thr][0].numpy().tobytes()).hexdigest()[:12]}")
     return res
 
 
