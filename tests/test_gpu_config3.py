@@ -47,7 +47,7 @@ def _stage1_step(cuda, side, t, bound_eps, bound_step):
     net._randn = lambda shape, device: noise
     unet = net.denoise_fn
     out = {}
-    for tag, dt in (("f16", "fp16"), ("f32", "fp32")):
+    for tag, dt in (("f16", "fp16"), ("w2", "w2"), ("f32", "fp32")):      # w2 = fp16 tensors x weight pairs: the headline's Stage-1 precision
         unet.set_compute_dtype(dt)
         xin = net._pack_condition(cond, x)
         ops.nchw_to_nhwc(x, unet.compute_dtype, c_off=cond.shape[1], out=xin)
@@ -61,6 +61,9 @@ def _stage1_step(cuda, side, t, bound_eps, bound_step):
     e_mx, _ = _rel(out["f16"][0], out["f32"][0], f"Stage 1 at {side}^2, t = {t}: UNet eps, fp16 vs fp32 family")
     s_mx, _ = _rel(out["f16"][1], out["f32"][1], f"Stage 1 at {side}^2, t = {t}: x_(t-1) after the ancestral step")
     assert e_mx < bound_eps and s_mx < bound_step
+    w_mx, _ = _rel(out["w2"][0], out["f32"][0], f"Stage 1 at {side}^2, t = {t}: UNet eps, w2 (fp16 x weight pairs) vs fp32 family")
+    ws_mx, _ = _rel(out["w2"][1], out["f32"][1], f"Stage 1 at {side}^2, t = {t}: x_(t-1) after the ancestral step, w2")
+    assert w_mx < bound_eps and ws_mx < bound_step      # (exact weights: at most the fp16 figures)
     del net
     torch.cuda.empty_cache()
 

@@ -41,6 +41,8 @@ def s2_runs(cuda, full_model):
     """All six 50-step runs (3 precisions x cache off / 0.3) of the full-size Stage 2 at latent 64, computed once."""
     import hashlib
     res = {}
+    wsum = sum(float(p_.detach().double().sum()) for p_ in full_model.parameters())
+    print(f"   weights fingerprint: {wsum!r}")
     for thr in (0.0, 0.3):
         for prec in S2_MODES:
             res[prec, thr] = _s2_run(full_model, cuda, prec, thr)
