@@ -866,9 +866,12 @@ template <int OUT_F32>
 static void launch_layernorm_split(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int C, float eps,
                                    hipStream_t s) {
     const int chunks_per_lane = (C / 8 + 63) / 64;
+    // at most ~3 resident workgroups per CU of a 256-CU chip: a wave then walks several row groups and its gamma / beta rows (as many
+    // bytes as two rows of x at C = 1 280) are loaded once per wave instead of once per two rows (round 5: 4 096 workgroups of one row
+    // group each ran the 32 768 x 1 280 LayerNorms of Stage 2 at 2.5 TB/s)
     auto blocks = [&](int rows_per_block) {
         const int64_t n = cdiv64(rows, rows_per_block);
-        return (unsigned)(n < 4096 ? n : 4096);
+        return (unsigned)(n < 768 ? n : 768);
     };
     if (chunks_per_lane <= 2) hipLaunchKernelGGL((layernorm_split_kernel<2, 2, OUT_F32>), dim3(blocks(8)), dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
     else if (chunks_per_lane == 3) hipLaunchKernelGGL((layernorm_split_kernel<3, 2, OUT_F32>), dim3(blocks(8)), dim3(256), 0, s, x, y, gamma, beta, rows, C, eps);
