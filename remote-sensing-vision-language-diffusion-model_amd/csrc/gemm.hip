@@ -138,6 +138,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     static_assert(SEG == 1 || !(PV & 8), "the persistent residual variants are 16-bit residuals (plain GEMM only)");
     static_assert(PERSIST || PV == 0, "PV is the persistent epilogue's variant");
     constexpr bool SPLIT = SEG == 3;
+    constexpr bool PAIRED = SEG == 2 && PERSIST;   // (the persistent weight-pair GEMMs: K' tiles in (W_lo, W_hi) pairs per activation tile, see xk / wk)
     typedef typename Mfma<T>::v8 v8;
     typedef typename std::conditional<SEG == 1, T, f16>::type TO;
     typedef typename Mfma<TO>::v4 v4;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         if constexpr (PERSIST) {
             const int c = lid >> 3, qx = t_end - ts;
             const int fr = qx / t_step, rem = qx - fr * t_step;
-            const bool halves = G_HALF_TILES && rem > 0 && 2 * rem <= t_step;
+            const bool halves = G_HALF_TILES && !PAIRED && rem > 0 && 2 * rem <= t_step;   // (the paired K loop exists for whole tiles)
             n_full = fr + ((!halves && c < rem) ? 1 : 0);
             if (halves && c < 2 * rem) {
                 t_half = ts + fr * t_step + (c >> 1);
@@ -209,7 +210,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     const int64_t rowb_w = (int64_t)p.K * (int64_t)sizeof(T) * SEG;              // weight row: K values, the pair lo | hi, or the triple hi | lo | hi
     // K tile kt of the concatenated K' -> the activation's K tile: SPLIT reads the planes lo, hi, hi (tiles >= 2 nk0 alias the hi
     // plane), the pair form reads the one row twice; the weight row is linear
-    auto xk = [&](int kt) { return SEG == 3 ? (kt >= 2 * nk0 ? kt - nk0 : kt) : SEG == 2 ? (kt >= nk0 ? kt - nk0 : kt) : kt; };
+    // PAIRED (round 5; the persistent weight-pair GEMMs): the two K' tiles of one activation K tile are ADJACENT -- tile 2 p = [X(p) | W_lo(p)],
+    // tile 2 p + 1 = [ -- | W_hi(p)] -- so that the second needs neither an LDS-DMA of X nor a fragment read of it: the activation fragments of
+    // tile 2 p stay in registers for its partner.  Per 32 MFMAs a CU then moves 48 KiB into LDS instead of 64 and reads 16 KiB of fragments per
+    // wave pair instead of 24: this K loop is bound by LDS time (7 of the 8 cycles an MFMA takes), not by the matrix pipe.
+    auto xk = [&](int kt) { return PAIRED ? (kt >> 1) : SEG == 3 ? (kt >= 2 * nk0 ? kt - nk0 : kt) : SEG == 2 ? (kt >= nk0 ? kt - nk0 : kt) : kt; };
+    auto wk = [&](int kt) { return PAIRED ? (kt & 1) * nk0 + (kt >> 1) : kt; };   // weight row = [W_lo(K) | W_hi(K)]
     if (G_STAGGER > 0 && !PERSIST) {
         const int lid = blockIdx.x + blockIdx.y * gridDim.x;
         if (lid < 256 && ((lid >> 3) & 1))
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
 #if G_ASMDMA
         const uint32_t dst = lds0 + (uint32_t)((kt & (G_NST - 1)) * G_STAGE + wave * 2048 + (j & 1) * 16384 + (j >> 1) * 1024);
         const int ktx = (G_ABL & 8) ? (kt & 3) : xk(kt);
-        const char* base = uni((j & 1) ? Wb + ((G_ABL & 8) ? (kt & 3) : kt) * 64 : Xb + ktx * 64);
+        const char* base = uni((j & 1) ? Wb + ((G_ABL & 8) ? (kt & 3) : wk(kt)) * 64 : Xb + ktx * 64);
         const uint32_t voff = (j & 1) ? wvo[j >> 1] : xvo[j >> 1];
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(base) : "memory", "m0");
 #else
@@ -317,7 +323,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     };
     auto dma_tile = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma_piece(kt, j);
+        for (int j = 0; j < 4; ++j)
+            if (!PAIRED || !(kt & 1) || (j & 1)) dma_piece(kt, j);      // PAIRED: an odd tile is its two weight pieces
     };
 
     f32x16 acc[2][4];   // [n tile][m tile]
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
             constexpr bool half = decltype(HALF)::value;
             constexpr int MI = half ? 2 : 4;
             // own pieces of K tile 0 (tiles 1, 2 and, from the second tile on, the last stores may stay in flight)
-            if constexpr (half) g_wait_vm<6>();
+            if constexpr (half || PAIRED) g_wait_vm<6>();      // (PAIRED: K tile 1 is two pieces per wave, K tile 2 four)
             else g_wait_vm<8>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -652,6 +659,100 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 }
             }
 #else
+            if constexpr (PAIRED) {
+                // ---- PAIRED K loop (see PAIRED above).  Same slots, same barriers, same ring as the loop below; K' tile kt = 2 p + o:
+                //   o = 0: four pieces (X(p) | W_lo(p)), 12 fragment reads;   o = 1: two pieces (W_hi(p)), 4 fragment reads, fb kept from tile 2 p.
+                // Pieces in flight behind tile kt + 1: tiles kt + 2, kt + 3 = 6 pieces whatever the parity (group 0: vmcnt(6)); tile kt + 2
+                // alone = 4 behind an even kt, 2 behind an odd one (group 1, compile-time by a loop unrolled over the pair).  nk is even and
+                // >= 4, nk_main = nk - 3 is odd: the steady-state trips kt = 1 .. nk - 4 are whole (odd, even) pairs.
+                auto rd_w = [&](int kt) {           // an odd tile: its weight fragments only
+                    const char* st = smem + (kt & (G_NST - 1)) * G_STAGE;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) fa[ks][ni] = *(const v8*)(st + fa_off[ks] + ni * 2048);
+                };
+                // the 16 MFMAs of the tile in registers with the pieces of tile `next` between them: all four (NEXT_W = false: an even
+                // tile) or its two weight pieces (an odd one)
+                auto mmp = [&](int next, auto FIRST, auto NEXT_W) {
+                    constexpr bool first = decltype(FIRST)::value, next_w = decltype(NEXT_W)::value;
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ks][ni], fb[ks][mi], (first && ks == 0) ? bC[ni] : acc[ni][mi]);
+                            if (!next_w || ((2 * ks + ni) & 1)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                dma_piece(next, 2 * ks + ni);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    __builtin_amdgcn_s_setprio(0);
+                };
+                auto wait_pieces = [&](int n) {     // tail only: n in {0, 2, 4, 6}
+                    if (n >= 6) g_wait_vm<6>();
+                    else if (n >= 4) g_wait_vm<4>();
+                    else if (n >= 2) g_wait_vm<2>();
+                    else g_wait_vm<0>();
+                };
+                auto pcs = [&](int kt) { return kt >= nk ? 0 : ((kt & 1) ? 2 : 4); };   // pieces of tile kt per wave
+                if (grp == 0) {
+                    read_tile(0);
+                    read_bias();
+                    slot_end();
+                    mmp(3, std::true_type{}, std::true_type{});
+                    g_wait_vm<6>();
+                    slot_end();
+                    for (int kt = 1; kt < nk_main; kt += 2) {
+                        rd_w(kt);
+                        slot_end();
+                        mmp(kt + 3, std::false_type{}, std::false_type{});
+                        g_wait_vm<6>();
+                        slot_end();
+                        read_tile(kt + 1);
+                        slot_end();
+                        mmp(kt + 4, std::false_type{}, std::true_type{});
+                        g_wait_vm<6>();
+                        slot_end();
+                    }
+                    for (int kt = nk_main; kt < nk; ++kt) {
+                        if (kt & 1) rd_w(kt); else read_tile(kt);
+                        slot_end();
+                        mma_tile(-1);
+                        wait_pieces(pcs(kt + 2) + pcs(kt + 3));     // tile kt + 1 landed (nothing beyond nk - 1 was requested)
+                        slot_end();
+                    }
+                } else {
+                    read_bias();
+                    slot_end();
+                    read_tile(0);
+                    g_wait_vm<4>();                                  // tile 1 landed; tile 2 (four pieces) may stay in flight
+                    slot_end();
+                    mmp(3, std::true_type{}, std::true_type{});
+                    slot_end();
+                    for (int kt = 1; kt < nk_main; kt += 2) {
+                        rd_w(kt);
+                        g_wait_vm<2>();                              // tile kt + 1 landed; tile kt + 2 (odd: two pieces) in flight
+                        slot_end();
+                        mmp(kt + 3, std::false_type{}, std::false_type{});
+                        slot_end();
+                        read_tile(kt + 1);
+                        g_wait_vm<4>();                              // tile kt + 2 landed; tile kt + 3 (even: four pieces) in flight
+                        slot_end();
+                        mmp(kt + 4, std::false_type{}, std::true_type{});
+                        slot_end();
+                    }
+                    for (int kt = nk_main; kt < nk; ++kt) {
+                        if (kt & 1) rd_w(kt); else read_tile(kt);
+                        wait_pieces(pcs(kt + 2));                    // this group has requested up to tile min(kt + 2, nk - 1)
+                        slot_end();
+                        mma_tile(-1);
+                        if (kt != nk - 1) slot_end();
+                    }
+                }
+            } else
             if (grp == 0) {
                 rd(0);
                 read_bias();
