@@ -80,14 +80,19 @@ class SplitPolicy:
                       "qkv"       the inputs of to_q / to_k / to_v: LayerNorm1 / LayerNorm2's outputs (ZeroCrossAttn: its two GroupNorms)
                       "proj"      the inputs of proj_in / proj_out -- measured (+1.3e-4 after 50 steps for two GEMMs per transformer): not
                                   in the default.
-                      "conv"      the inputs of the ResBlocks' two 3x3 convolutions (GroupNorm + SiLU outputs; NOT conv_in, the
-                                  Down / Upsample and ZeroSFT convolutions or the output convolution) -- an experiment: every
-                                  convolution input in fp16 is 3.4e-3 on the CPU restatement.
+                      "conv1", "conv2"  the input of a ResBlock's first / second 3x3 convolution (GroupNorm + SiLU outputs; NOT conv_in,
+                                  the Down / Upsample and ZeroSFT convolutions or the output convolution).  Every convolution input in
+                                  fp16 is 3.4e-3 on the CPU restatement; experiments only: on the reduced-depth goldens the first
+                                  convolution's input costs +1.5e-4 after 50 steps and the second's +3.2e-4, but at full network depth the
+                                  first alone ends at 1.2-1.7e-3 -- the reason the full-depth test exists.
                     Measured after 50 Stage-2 steps against the reference's CPU run (tools/tolerance_check.py, round 5, max / mean):
-                    ("attn",) 2.5e-4 / 3.8e-5; + attn_out + ff 3.5e-4 / 4.6e-5; + qkv 3.5e-4 / 5.3e-5; + proj 4.8e-4 / 6.5e-5."""
+                    ("attn",) 2.5e-4 / 3.8e-5; + attn_out + ff 3.5e-4 / 4.6e-5; + qkv 3.5e-4 / 5.3e-5 (the default); + conv1 5.0e-4 / 6.7e-5
+                    on the reduced-depth goldens but 1.2e-3 / 1.7e-3 (cache off / 0.3) at FULL depth against the fp32 family
+                    (tests/test_gpu_fulldepth.py): outside the bar, rejected; qkv + conv2 6.6e-4 / 9.7e-5; qkv + conv1 + conv2 6.9e-4 / 9.3e-5;
+                    qkv + proj 4.8e-4 / 6.5e-5."""
 
     __slots__ = ("impl", "f16_inputs")
-    GROUPS = ("attn", "attn_out", "ff", "qkv", "proj", "conv")
+    GROUPS = ("attn", "attn_out", "ff", "qkv", "proj", "conv1", "conv2")
 
     def __init__(self, impl="planes", f16_inputs=("attn", "attn_out", "ff", "qkv")):
         if impl not in ("planes", "f32"):

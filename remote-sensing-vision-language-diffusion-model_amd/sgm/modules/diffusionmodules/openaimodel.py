@@ -93,13 +93,13 @@ class ResBlock(TimestepBlock):
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
         gn2, conv2 = self.out_layers[0], self.out_layers[3]
         h = ops.conv2d(x, rt.pk(conv1), pad=conv1.padding[0], rowvec=emb_rows[id(self)], stats=True,
-                       norm=(gn1.weight, gn1.bias, gn1.num_groups, gn1.eps, True), norm_group="conv")
+                       norm=(gn1.weight, gn1.bias, gn1.num_groups, gn1.eps, True), norm_group="conv1")
         if isinstance(self.skip_connection, nn.Conv2d):
             skip = ops.conv2d(x, rt.pk(self.skip_connection), pad=self.skip_connection.padding[0])
         else:
             skip = x
         return ops.conv2d(h, rt.pk(conv2), pad=conv2.padding[0], residual=skip,
-                          norm=(gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, True), norm_group="conv")
+                          norm=(gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, True), norm_group="conv2")
 
 
 class UNetModel(HipNet):

@@ -85,7 +85,9 @@ if __name__ == "__main__":
              "split_s1w2": ("w2", "split", "split", None, None),                            # Stage 1: fp16 tensors x weight pairs
              "split_r04": ("split", "split", "split", P(f16_inputs=("attn",)), P(f16_inputs=("attn",))),   # round 4's composition
              "split_noqkv": ("split", "split", "split", P(f16_inputs=("attn", "attn_out", "ff")), None),
-             "split_conv": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "conv")), None),
+             "split_noconv": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv")), None),
+             "split_conv": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "conv1", "conv2")), None),
+             "split_conv2": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "conv2")), None),
              "split_proj": ("split", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "proj")), None),
              "split_full": ("split", "split", "split", ops.ALL_SPLIT, ops.ALL_SPLIT)}
     if "--only" in sys.argv:
