@@ -506,7 +506,7 @@ def bench_headline(args, dev, rank, world):
             main_s = torch.cuda.current_stream()
             side_stream.wait_stream(main_s)
             with torch.cuda.stream(side_stream):
-                fronts = [m.vae_front(lq[i0:i0 + c2]) for i0 in range(0, BPG, c2)]
+                fronts = [m.vae_front(lq[i0:i0 + c2], restoration_scale=S2_KW["restoration_scale"]) for i0 in range(0, BPG, c2)]
         captions = [captioner(u8[i:i + 1], seed=42 + unit * BPG + i) if live else "" for i in range(BPG)]   # infer.py:145-166
         if fronts[0] is not None:
             main_s.wait_stream(side_stream)

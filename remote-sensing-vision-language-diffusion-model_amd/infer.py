@@ -154,7 +154,7 @@ class SuperResolutionPipeline:
         side = torch.cuda.Stream(device=lq.device)
         side.wait_stream(torch.cuda.current_stream(lq.device))
         with torch.cuda.stream(side):
-            front = self.refinement_model.vae_front(lq, self.cfg.num_samples)
+            front = self.refinement_model.vae_front(lq, self.cfg.num_samples, restoration_scale=self.cfg.s_stage1)
         return side, front, (lq, h0, w0)
 
     def run_stage3_refinement(self, sr_image, caption: str, front=None):

@@ -92,8 +92,18 @@ class SR_backbone(DiffusionEngine):
     def batchify_denoise(self, x, is_stage1=False):
         return self.decode_first_stage(self.encode_first_stage_with_denoise(x, use_sample=False, is_stage1=is_stage1))
 
+    def _encode_center(self, x_stage1, needed):
+        """``z_stage1 = encode_first_stage(x_stage1)`` (:246) is read by the sampler only while the restoration pull is on
+        (``restore_cfg > 0``: sampling.py:614-616); with it off (infer.py's default ``s_stage1 = -1``) the encoder pass is dead work.
+        Skipped then -- but its posterior noise is still drawn, so that every later random draw is the one the reference makes."""
+        if needed:
+            return self.encode_first_stage(x_stage1)
+        B, _, H, W = x_stage1.shape
+        self._posterior_noise((B, self.first_stage_model.embed_dim, H // 8, W // 8))
+        return None
+
     @torch.no_grad()
-    def vae_front(self, x, num_samples=1):
+    def vae_front(self, x, num_samples=1, restoration_scale=4.0):
         """The three VAE passes that open ``just_sampling`` (:236-246: denoise-encode, decode, re-encode) -> ``(_z, x_stage1, z_stage1)``
         for ``just_sampling(..., vae_front=...)``.  They depend on the image only, not on the caption: a caller may issue them on a
         second HIP stream while the caption pass (a weight-streaming token loop that leaves the matrix pipes idle) runs on the first.
@@ -105,7 +115,7 @@ class SR_backbone(DiffusionEngine):
         with ops.plan_units(len(x)):
             _z = self.encode_first_stage_with_denoise(x, use_sample=False)
             x_stage1 = self.decode_first_stage(_z)
-            z_stage1 = self.encode_first_stage(x_stage1)
+            z_stage1 = self._encode_center(x_stage1, restoration_scale > 0)
         return _z, x_stage1, z_stage1
 
     def init_tile_vae(self, encoder_tile_size=512, decoder_tile_size=64):
@@ -193,7 +203,7 @@ class SR_backbone(DiffusionEngine):
             stamp("vae_denoise_encode")
             x_stage1 = self.decode_first_stage(_z)
             stamp("vae_decode_stage1")
-            z_stage1 = self.encode_first_stage(x_stage1)
+            z_stage1 = self._encode_center(x_stage1, restoration_scale > 0)
             stamp("vae_encode_stage1")
         else:       # computed ahead of the call (``vae_front``), e.g. on a second stream beside the caption pass
             _z, x_stage1, z_stage1 = front
