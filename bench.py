@@ -512,7 +512,8 @@ def bench_headline(args, dev, rank, world):
             main_s.wait_stream(side_stream)
             for f in fronts:
                 for t in f:
-                    t.record_stream(main_s)
+                    if t is not None:      # (z_stage1 is None while the restoration pull is off)
+                        t.record_stream(main_s)
         ph("caption")
         outs, traces = [], []
         for j, i0 in enumerate(range(0, BPG, c2)):

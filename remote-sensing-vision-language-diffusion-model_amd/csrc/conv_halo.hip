@@ -266,10 +266,16 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     const T* __restrict__ Wp = (const T*)p.w;
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
+    // PAIRED (round 5, the weight-pair form): the two 64-channel K chunks of one channel block are ADJACENT -- chunk 2 c = channels 64 c
+    // against W_lo, chunk 2 c + 1 = the same channels against W_hi -- so the second runs on the patch its partner left in LDS: no global
+    // load, no normalisation, no LDS write.  (The per-tap weight row is [W_lo(C) | W_hi(C)].)
+    constexpr bool PAIRED = SEG == 2;
+    auto chan0 = [&](int kc) { return PAIRED ? (kc >> 1) * 64 : kc * 64; };                                   // first logical channel of the chunk's patch
+    auto wchan0 = [&](int kc) { return PAIRED ? (kc & 1) * p.Cseg + (kc >> 1) * 64 : kc * 64; };              // ... of its weight slice
     u32x4 rp[PLOADS];
     auto load_patch = [&](int kc) {
         int which, Cs, coff;
-        halo_src_of<SEG>(p, kc * 64, which, Cs, coff);
+        halo_src_of<PAIRED ? 1 : SEG>(p, chan0(kc), which, Cs, coff);
         const T* src = which ? X2 : X1;
         coff += c * 8;
 #pragma unroll
@@ -282,8 +288,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     auto store_patch = [&](int kc) {
         float sa[8], sb[8];
         if (p.ab != nullptr) {
-            const int kch = kc * 64 - ((SEG == 2 && kc * 64 >= p.Cseg) ? p.Cseg : 0);   // the channels this logical chunk holds
-            const float* ab = p.ab + ((int64_t)img * p.Cseg + kch + c * 8) * 2;
+            const float* ab = p.ab + ((int64_t)img * p.Cseg + chan0(kc) + c * 8) * 2;   // (PAIRED: SEG == 2 is always paired here)
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sa[e] = ab[2 * e]; sb[e] = ab[2 * e + 1]; }
         }
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
             const int tap = step * TPS + j;
             if (tap >= 9) break;
             char* dst = wbuf + buf * W_BYTES + j * (BN * 128);
-            const int64_t koff = (int64_t)tap * p.Ctot + kc * 64 + wc * 8;
+            const int64_t koff = (int64_t)tap * p.Ctot + wchan0(kc) + wc * 8;
 #pragma unroll
             for (int i = 0; i < W_LOADS; ++i) {
                 // rows past Cout re-read the last row: their accumulators are never stored
@@ -350,8 +355,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(HaloArgs p) {
     int s = 0;
     dma_w(0, 0, 0);
     for (int kc = 0; kc < p.nchunks; ++kc) {
-        load_patch(kc);
-        store_patch(kc);
+        if (!PAIRED || !(kc & 1)) {
+            load_patch(kc);
+            store_patch(kc);
+        }
         __syncthreads();   // patch visible; weights of (kc, step 0) landed (vmcnt(0) + barrier)
 #pragma unroll
         for (int st = 0; st < SPC; ++st, ++s) {   // unrolled: the tap of every read is a compile-time constant

@@ -165,7 +165,8 @@ class SuperResolutionPipeline:
             side, vae_front, (lq, h0, w0) = front
             torch.cuda.current_stream(lq.device).wait_stream(side)
             for t in vae_front:
-                t.record_stream(torch.cuda.current_stream(lq.device))
+                if t is not None:      # (z_stage1 is None while the restoration pull is off)
+                    t.record_stream(torch.cuda.current_stream(lq.device))
         c = self.cfg
         samples = self.refinement_model.just_sampling(
             lq, [caption], num_steps=c.edm_steps, restoration_scale=c.s_stage1, s_churn=c.s_churn, s_noise=c.s_noise,
