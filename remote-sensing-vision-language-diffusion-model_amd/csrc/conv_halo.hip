@@ -445,9 +445,18 @@ template <int N> __device__ __forceinline__ void halo_wait_barrier() {
 // the halo overhead of the patch drops (612 instead of 680 patch pixels per 512 outputs).  Ablation builds
 // (tools/ablate_halo.sh) put the issue cost of the weight LDS-DMAs at 25 % of the 4-wave kernel's time and the patch
 // pipeline at 22-36 %, the fragment reads at ~1 %: per-wave DMA / staging instructions are what to cut.
+// PAIRED (round 5, the weight-pair form SEG == 2; H32_PAIRED = 0 restores the linear K' order): a body is ONE 32-channel chunk of the
+// activation under both weight halves -- step st = tap st with the [BN x 32] slices of W_lo and W_hi -- instead of two consecutive chunks
+// of the concatenated K' = [X | X].  The patch of a chunk is loaded, normalised and written to LDS once instead of twice (the patch
+// pipeline is 13-22 % of this form's time by the -DHALO_ABL=2 builds, tools/bench_halo_seg.py), its fragments are read once per tap for both
+// halves, and the two patch buffers alternate by body.  Same products, another summation order (lo, hi per tap instead of all lo, all hi).
+#ifndef H32_PAIRED
+#define H32_PAIRED 1
+#endif
 template <typename T, int BN, int NORM, int NW, int SEG = 1>
 __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     constexpr bool SPLIT = SEG == 3;
+    constexpr bool PAIRED = SEG == 2 && H32_PAIRED;
     constexpr int NT = 64 * NW;
     constexpr int WAVES_N = 2, WAVES_M = NW / 2;
     constexpr int TM = 4;                            // 32-pixel rows per wave
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     u32x4 rp[PL];
     auto issue_patch = [&](int k32, u32x4 (&r)[PL]) {
         int which, Cs, coff;
-        halo_src_of<SEG>(p, k32 * 32, which, Cs, coff);
+        halo_src_of<PAIRED ? 1 : SEG>(p, k32 * 32, which, Cs, coff);   // (PAIRED: k32 counts the activation's own chunks)
         const T* src = which ? X2 : X1;
         coff += c4 * 8;
 #pragma unroll
@@ -566,9 +575,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int g = 2 * st + j;
-            const int k32 = 2 * b + (g >= 9 ? 1 : 0), tap = g >= 9 ? g - 9 : g;
+            const int tap = PAIRED ? st : (g >= 9 ? g - 9 : g);
+            const int col = PAIRED ? j * p.Cseg + b * 32 : (2 * b + (g >= 9 ? 1 : 0)) * 32;   // PAIRED: W_lo | W_hi columns of chunk b
             char* dst = wbuf + buf * W_BYTES + j * TAP_BYTES;
-            const char* base = (const char*)(Wp + (int64_t)tap * p.Ctot + k32 * 32);   // wave-uniform
+            const char* base = (const char*)(Wp + (int64_t)tap * p.Ctot + col);   // wave-uniform
 #pragma unroll
             for (int i = 0; i < W_LOADS; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(base + wvoff[i]), (lptr_t)(dst + (wave * 16 + 16 * NW * i) * 64), 16, 0, 0);
@@ -576,8 +586,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     };
     auto dma_ab = [&](int b, int buf) {   // (scale, shift) of the 64 channels of body b: 512 B, lanes 32..63 duplicate it
         if (NORM != 0) {   // every wave issues the same piece (identical bytes): no branch in the step, uniform vmcnt
-            const int bch = b * 64 - ((SEG == 2 && b * 64 >= p.Cseg) ? p.Cseg : 0);   // the channels body b holds (wave-uniform)
-            const float* src = p.ab + ((int64_t)img * p.Cseg + bch) * 2 + (lane & 31) * 4;
+            const int bch = PAIRED ? b * 32 : b * 64 - ((SEG == 2 && b * 64 >= p.Cseg) ? p.Cseg : 0);   // the channels body b holds (wave-uniform)
+            const float* src = p.ab + ((int64_t)img * p.Cseg + bch) * 2 + (lane & (PAIRED ? 15 : 31)) * 4;   // (PAIRED: 32 channels, written twice)
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abuf + buf * AB32_BYTES), 16, 0, 0);
         }
     };
@@ -606,7 +616,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     {
         u32x4 ra[PL];
         issue_patch(0, ra);
-        issue_patch(1, rp);
+        if (!PAIRED) issue_patch(1, rp);
+        else {
+#pragma unroll
+            for (int i = 0; i < PL; ++i) rp[i] = (u32x4){0u, 0u, 0u, 0u};
+        }
         float ab16[16];
         if (NORM != 0) {
             const float* ab = p.ab + ((int64_t)img * p.Cseg + c4 * 8) * 2;
@@ -646,22 +660,46 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
             }
             if constexpr (st == 4 && NEXT && !(HALO_ABL & 2)) {
                 dma_ab(b + 1, (b + 1) & 1);
-                issue_patch(2 * b + 2, rp);
+                issue_patch(PAIRED ? b + 1 : 2 * b + 2, rp);
             }
-            if constexpr (st >= 1 && st <= 3 && !(HALO_ABL & 2)) {          // B of this body -> buffer 1
+            if constexpr (st >= 1 && st <= 3 && !(HALO_ABL & 2) && !PAIRED) {          // B of this body -> buffer 1
                 float ab16[16];
                 lds_ab(abuf + (b & 1) * AB32_BYTES + 256 + c4 * 64, ab16);
                 norm_write(rp[2 * (st - 1)], 2 * (st - 1), ab16, patch + PB);
                 if constexpr (2 * (st - 1) + 1 < PL) norm_write(rp[2 * (st - 1) + 1], 2 * (st - 1) + 1, ab16, patch + PB);
             }
-            if constexpr (st >= 6 && NEXT && !(HALO_ABL & 2)) {             // A' of the next body -> buffer 0
+            if constexpr (st >= 6 && NEXT && !(HALO_ABL & 2)) {             // A' of the next body -> buffer 0 (PAIRED: the next chunk -> the buffer this body does not read)
                 float ab16[16];
                 lds_ab(abuf + ((b + 1) & 1) * AB32_BYTES + c4 * 64, ab16);
-                norm_write(rp[2 * (st - 6)], 2 * (st - 6), ab16, patch);
-                if constexpr (2 * (st - 6) + 1 < PL) norm_write(rp[2 * (st - 6) + 1], 2 * (st - 6) + 1, ab16, patch);
+                char* const Pn = PAIRED ? patch + ((b + 1) & 1) * PB : patch;
+                norm_write(rp[2 * (st - 6)], 2 * (st - 6), ab16, Pn);
+                if constexpr (2 * (st - 6) + 1 < PL) norm_write(rp[2 * (st - 6) + 1], 2 * (st - 6) + 1, ab16, Pn);
             }
-            if constexpr (st == 8 && NEXT && !(HALO_ABL & 2)) issue_patch(2 * b + 3, rp);
+            if constexpr (st == 8 && NEXT && !(HALO_ABL & 2) && !PAIRED) issue_patch(2 * b + 3, rp);
             const char* w_st = wbuf + (s % WST) * W_BYTES;
+            if constexpr (PAIRED) {   // tap st of this body's chunk under W_lo (j = 0) and W_hi (j = 1): one set of patch fragments per k-step
+                constexpr int ky = st / 3, kx = st - ky * 3;
+                const char* P = patch + (b & 1) * PB;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    v8 fb[TM];
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        if ((HALO_ABL & 4) && (mi & 1)) fb[mi] = fb[mi - 1];
+                        else fb[mi] = *(const v8*)(P + fb_off[kx][ks] + (mi + ky) * (PW * 64));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        v8 fa[TN];
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const v8*)(w_st + j * TAP_BYTES + fa_off[ks] + ni * (32 * 64));
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                            for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = Mfma<T>::mma(fa[ni], fb[mi], acc[ni][mi]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int g = 2 * st + j;
@@ -690,9 +728,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
             // flight, those requested in the previous step (st 5, st 0) are waited for here
             constexpr int n_w = (w_issue && !(HALO_ABL & 1)) ? 2 * W_LOADS : 0;
             constexpr int n_ab = (st == 4 && NEXT && NORM != 0 && !(HALO_ABL & 2)) ? 1 : 0;
-            constexpr int n_p = ((st == 4 || st == 8) && NEXT && !(HALO_ABL & 2)) ? PL : 0;
+            constexpr int n_p = ((st == 4 || (st == 8 && !PAIRED)) && NEXT && !(HALO_ABL & 2)) ? PL : 0;
             constexpr int keep = (AHEAD == 2 ? n_w + n_ab : 0) + n_p;
-            if constexpr (st == 5 || st == 0) wait_patch(rp, std::integral_constant<int, (AHEAD == 2 ? n_w : 0)>{});
+            if constexpr (st == 5 || (st == 0 && !PAIRED)) wait_patch(rp, std::integral_constant<int, (AHEAD == 2 ? n_w : 0)>{});
             halo_wait_barrier<keep>();
             ++s;
         });
