@@ -445,18 +445,19 @@ template <int N> __device__ __forceinline__ void halo_wait_barrier() {
 // the halo overhead of the patch drops (612 instead of 680 patch pixels per 512 outputs).  Ablation builds
 // (tools/ablate_halo.sh) put the issue cost of the weight LDS-DMAs at 25 % of the 4-wave kernel's time and the patch
 // pipeline at 22-36 %, the fragment reads at ~1 %: per-wave DMA / staging instructions are what to cut.
-// PAIRED (round 5, the weight-pair form SEG == 2; H32_PAIRED = 0 restores the linear K' order): a body is ONE 32-channel chunk of the
-// activation under both weight halves -- step st = tap st with the [BN x 32] slices of W_lo and W_hi -- instead of two consecutive chunks
-// of the concatenated K' = [X | X].  The patch of a chunk is loaded, normalised and written to LDS once instead of twice (the patch
-// pipeline is 13-22 % of this form's time by the -DHALO_ABL=2 builds, tools/bench_halo_seg.py), its fragments are read once per tap for both
-// halves, and the two patch buffers alternate by body.  Same products, another summation order (lo, hi per tap instead of all lo, all hi).
+// PAIRED bodies (round 5, the multi-segment forms; H32_PAIRED = 0 restores the linear K' order): a body is ONE 32-channel chunk of the
+// activation under the two weight column blocks that multiply it -- step st = tap st with the [BN x 32] slices of both -- instead of two
+// consecutive chunks of the concatenated K'.  Weight pairs (K' = [X | X] against [W_lo | W_hi]): every body.  Split (K' = [X_lo | X_hi | X_hi]
+// against [W_hi | W_lo | W_hi]): the hi planes, after the lo planes have gone through in the linear order.  The patch of such a chunk is
+// loaded, normalised and written to LDS once instead of twice (the patch pipeline is 13-22 % of the weight-pair form's time by the
+// -DHALO_ABL=2 builds, tools/bench_halo_seg.py), its fragments are read once per tap for both blocks, and the two patch buffers alternate
+// by body.  Same products, another summation order (per tap instead of per segment).
 #ifndef H32_PAIRED
 #define H32_PAIRED 1
 #endif
 template <typename T, int BN, int NORM, int NW, int SEG = 1>
 __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     constexpr bool SPLIT = SEG == 3;
-    constexpr bool PAIRED = SEG == 2 && H32_PAIRED;
     constexpr int NT = 64 * NW;
     constexpr int WAVES_N = 2, WAVES_M = NW / 2;
     constexpr int TM = 4;                            // 32-pixel rows per wave
@@ -516,9 +517,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
     u32x4 rp[PL];
-    auto issue_patch = [&](int k32, u32x4 (&r)[PL]) {
+    auto issue_patch = [&](int ch0, u32x4 (&r)[PL]) {   // ch0: first K' channel of the 32-channel chunk
         int which, Cs, coff;
-        halo_src_of<PAIRED ? 1 : SEG>(p, k32 * 32, which, Cs, coff);   // (PAIRED: k32 counts the activation's own chunks)
+        halo_src_of<SEG>(p, ch0, which, Cs, coff);
         const T* src = which ? X2 : X1;
         coff += c4 * 8;
 #pragma unroll
@@ -571,12 +572,19 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i)   // rows past Cout re-read the last row; their accumulators are never stored
         wvoff[i] = (uint32_t)(((int64_t)min(n0 + wr0 + 16 * NW * i, p.Cout - 1) * Kel + wsl * 8) * (int64_t)sizeof(T));
-    auto dma_w = [&](int b, int st, int buf) {
+    // Body kinds (compile-time).  KIND 0: two consecutive 32-channel chunks of K' (chunk A -> patch buffer 0, B -> buffer 1; taps A0..A8, B0..B8,
+    // two per step).  KIND 1 (PAIRED): ONE chunk of the activation under two weight column blocks Cseg apart -- step st = tap st under both --
+    // patch buffers alternating by body.  idx = the body's index within its kind.  xch = K' channel of a body's chunk (for halo_src_of),
+    // wcol = its weight column.  PAIR_X0 / PAIR_W0: where the paired chunks start (the split form pairs its hi-plane segments 1 and 2).
+    const int PAIR_X0 = SEG == 3 ? p.Cseg : 0;
+    auto xch = [&](auto kind_c, int idx, int which) { return decltype(kind_c)::value ? PAIR_X0 + idx * 32 : (2 * idx + which) * 32; };
+    auto dma_w = [&](auto kind_c, int idx, int st, int buf) {
+        constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int g = 2 * st + j;
-            const int tap = PAIRED ? st : (g >= 9 ? g - 9 : g);
-            const int col = PAIRED ? j * p.Cseg + b * 32 : (2 * b + (g >= 9 ? 1 : 0)) * 32;   // PAIRED: W_lo | W_hi columns of chunk b
+            const int tap = KIND ? st : (g >= 9 ? g - 9 : g);
+            const int col = KIND ? PAIR_X0 + j * p.Cseg + idx * 32 : (2 * idx + (g >= 9 ? 1 : 0)) * 32;
             char* dst = wbuf + buf * W_BYTES + j * TAP_BYTES;
             const char* base = (const char*)(Wp + (int64_t)tap * p.Ctot + col);   // wave-uniform
 #pragma unroll
@@ -584,10 +592,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(base + wvoff[i]), (lptr_t)(dst + (wave * 16 + 16 * NW * i) * 64), 16, 0, 0);
         }
     };
-    auto dma_ab = [&](int b, int buf) {   // (scale, shift) of the 64 channels of body b: 512 B, lanes 32..63 duplicate it
+    auto dma_ab = [&](auto kind_c, int idx, int buf) {   // (scale, shift) of the body's 64 (KIND 1: 32, written twice) channels: 512 B, lanes 32..63 duplicate it
+        constexpr int KIND = decltype(kind_c)::value;
         if (NORM != 0) {   // every wave issues the same piece (identical bytes): no branch in the step, uniform vmcnt
-            const int bch = PAIRED ? b * 32 : b * 64 - ((SEG == 2 && b * 64 >= p.Cseg) ? p.Cseg : 0);   // the channels body b holds (wave-uniform)
-            const float* src = p.ab + ((int64_t)img * p.Cseg + bch) * 2 + (lane & (PAIRED ? 15 : 31)) * 4;   // (PAIRED: 32 channels, written twice)
+            const int bch = KIND ? idx * 32 : idx * 64 - ((SEG == 2 && idx * 64 >= p.Cseg) ? p.Cseg : 0);   // the channels the body holds (wave-uniform)
+            const float* src = p.ab + ((int64_t)img * p.Cseg + bch) * 2 + (lane & (KIND ? 15 : 31)) * 4;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abuf + buf * AB32_BYTES), 16, 0, 0);
         }
     };
@@ -608,15 +617,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
         fa_off[ks] = w32_off(wn * (TN * 32) + l31, 2 * ks + lh);
     }
 
-    // ---- prologue: chunk 0 is the one exposed load -> normalise -> write; chunk 1 is requested with it
-    const int nb = p.nchunks;   // bodies = 64-channel pairs of 32-channel chunks
+    // ---- the body sequence: U bodies of KIND 0, then Q of KIND 1.  Plain GEMM-K order: all KIND 0.  Weight pairs: all KIND 1.  Split: the lo
+    // planes (segment 0, against W_hi) as KIND 0, then every hi-plane chunk ONCE under W_lo and W_hi (segments 1 and 2) as KIND 1.
+    typedef std::integral_constant<int, 0> K0;
+    typedef std::integral_constant<int, 1> K1;
+    constexpr bool ALL_PAIRED = SEG == 2 && H32_PAIRED, PHASED = SEG == 3 && H32_PAIRED;
+    const int nb = p.nchunks;   // bodies = 64 channels of K' each
+    const int U = ALL_PAIRED ? 0 : PHASED ? p.Cseg / 64 : nb, Q = nb - U;
+    typedef std::integral_constant<int, ALL_PAIRED ? 1 : 0> KF;   // the first body's kind
+
+    // ---- prologue: chunk 0 is the one exposed load -> normalise -> write; chunk 1 (KIND 0) is requested with it
 #pragma unroll
-    for (int a = 0; a < ((HALO_ABL & 1) ? WST : AHEAD); ++a) dma_w(0, a, a);   // steps 0 .. AHEAD-1 of body 0 (every body has 9 steps); ablation 1: every stage once, so that the operands stay real data
-    dma_ab(0, 0);
+    for (int a = 0; a < ((HALO_ABL & 1) ? WST : AHEAD); ++a) dma_w(KF{}, 0, a, a);   // steps 0 .. AHEAD-1 of body 0 (every body has 9 steps); ablation 1: every stage once, so that the operands stay real data
+    dma_ab(KF{}, 0, 0);
     {
         u32x4 ra[PL];
-        issue_patch(0, ra);
-        if (!PAIRED) issue_patch(1, rp);
+        issue_patch(xch(KF{}, 0, 0), ra);
+        if (!KF::value) issue_patch(xch(K0{}, 0, 1), rp);
         else {
 #pragma unroll
             for (int i = 0; i < PL; ++i) rp[i] = (u32x4){0u, 0u, 0u, 0u};
@@ -648,38 +665,42 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     }
     halo_wait_barrier<0>();
 
-    int s = 0;   // global step: weight stage parity
-    auto body = [&](int b, auto next_c) {
-        constexpr bool NEXT = decltype(next_c)::value;
+    int s = 0;    // global step: weight stage parity
+    int gb = 0;   // global body: parity of the (scale, shift) buffers
+    // NEXT: 0 = the last body, 1 = a KIND 0 body follows, 2 = a KIND 1 body follows (behind a KIND 0 body: the first of its kind)
+    auto body = [&](auto kind_c, auto next_c, int idx) {
+        constexpr int KIND = decltype(kind_c)::value, NEXT = decltype(next_c)::value;
+        typedef std::integral_constant<int, NEXT == 2 ? 1 : 0> KN;   // the next body's kind
+        const int nidx = (NEXT == 2 && KIND == 0) ? 0 : idx + 1;
         halo_static_for<9>([&](auto st_c) {
             constexpr int st = decltype(st_c)::value;   // compile-time: taps, wait counts and piece indices depend on it
-            constexpr bool w_issue = (st + AHEAD < 9) || NEXT;   // the slice of step s + AHEAD exists
+            constexpr bool w_issue = (st + AHEAD < 9) || NEXT != 0;   // the slice of step s + AHEAD exists
             if constexpr (w_issue && !(HALO_ABL & 1)) {
-                if constexpr (st + AHEAD < 9) dma_w(b, st + AHEAD, (s + AHEAD) % WST);
-                else dma_w(b + 1, st + AHEAD - 9, (s + AHEAD) % WST);
+                if constexpr (st + AHEAD < 9) dma_w(kind_c, idx, st + AHEAD, (s + AHEAD) % WST);
+                else dma_w(KN{}, nidx, st + AHEAD - 9, (s + AHEAD) % WST);
             }
-            if constexpr (st == 4 && NEXT && !(HALO_ABL & 2)) {
-                dma_ab(b + 1, (b + 1) & 1);
-                issue_patch(PAIRED ? b + 1 : 2 * b + 2, rp);
+            if constexpr (st == 4 && NEXT != 0 && !(HALO_ABL & 2)) {
+                dma_ab(KN{}, nidx, (gb + 1) & 1);
+                issue_patch(xch(KN{}, nidx, 0), rp);
             }
-            if constexpr (st >= 1 && st <= 3 && !(HALO_ABL & 2) && !PAIRED) {          // B of this body -> buffer 1
+            if constexpr (st >= 1 && st <= 3 && !(HALO_ABL & 2) && KIND == 0) {          // B of this body -> buffer 1
                 float ab16[16];
-                lds_ab(abuf + (b & 1) * AB32_BYTES + 256 + c4 * 64, ab16);
+                lds_ab(abuf + (gb & 1) * AB32_BYTES + 256 + c4 * 64, ab16);
                 norm_write(rp[2 * (st - 1)], 2 * (st - 1), ab16, patch + PB);
                 if constexpr (2 * (st - 1) + 1 < PL) norm_write(rp[2 * (st - 1) + 1], 2 * (st - 1) + 1, ab16, patch + PB);
             }
-            if constexpr (st >= 6 && NEXT && !(HALO_ABL & 2)) {             // A' of the next body -> buffer 0 (PAIRED: the next chunk -> the buffer this body does not read)
+            if constexpr (st >= 6 && NEXT != 0 && !(HALO_ABL & 2)) {   // the next body's (first) chunk -> buffer 0; KIND 1 -> KIND 1: the buffer this body does not read
                 float ab16[16];
-                lds_ab(abuf + ((b + 1) & 1) * AB32_BYTES + c4 * 64, ab16);
-                char* const Pn = PAIRED ? patch + ((b + 1) & 1) * PB : patch;
+                lds_ab(abuf + ((gb + 1) & 1) * AB32_BYTES + c4 * 64, ab16);
+                char* const Pn = (KIND == 1 && NEXT == 2) ? patch + (nidx & 1) * PB : patch;
                 norm_write(rp[2 * (st - 6)], 2 * (st - 6), ab16, Pn);
                 if constexpr (2 * (st - 6) + 1 < PL) norm_write(rp[2 * (st - 6) + 1], 2 * (st - 6) + 1, ab16, Pn);
             }
-            if constexpr (st == 8 && NEXT && !(HALO_ABL & 2) && !PAIRED) issue_patch(2 * b + 3, rp);
+            if constexpr (st == 8 && NEXT == 1 && !(HALO_ABL & 2)) issue_patch(xch(K0{}, nidx, 1), rp);
             const char* w_st = wbuf + (s % WST) * W_BYTES;
-            if constexpr (PAIRED) {   // tap st of this body's chunk under W_lo (j = 0) and W_hi (j = 1): one set of patch fragments per k-step
+            if constexpr (KIND == 1) {   // tap st of this body's chunk under both weight blocks: one set of patch fragments per k-step
                 constexpr int ky = st / 3, kx = st - ky * 3;
-                const char* P = patch + (b & 1) * PB;
+                const char* P = patch + (idx & 1) * PB;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     v8 fb[TM];
@@ -727,16 +748,27 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
             // ago: everything issued in this step may stay in flight); patch loads requested in this step always stay in
             // flight, those requested in the previous step (st 5, st 0) are waited for here
             constexpr int n_w = (w_issue && !(HALO_ABL & 1)) ? 2 * W_LOADS : 0;
-            constexpr int n_ab = (st == 4 && NEXT && NORM != 0 && !(HALO_ABL & 2)) ? 1 : 0;
-            constexpr int n_p = ((st == 4 || (st == 8 && !PAIRED)) && NEXT && !(HALO_ABL & 2)) ? PL : 0;
+            constexpr int n_ab = (st == 4 && NEXT != 0 && NORM != 0 && !(HALO_ABL & 2)) ? 1 : 0;
+            constexpr int n_p = (((st == 4 && NEXT != 0) || (st == 8 && NEXT == 1)) && !(HALO_ABL & 2)) ? PL : 0;
             constexpr int keep = (AHEAD == 2 ? n_w + n_ab : 0) + n_p;
-            if constexpr (st == 5 || (st == 0 && !PAIRED)) wait_patch(rp, std::integral_constant<int, (AHEAD == 2 ? n_w : 0)>{});
+            if constexpr (st == 5 || (st == 0 && KIND == 0)) wait_patch(rp, std::integral_constant<int, (AHEAD == 2 ? n_w : 0)>{});
             halo_wait_barrier<keep>();
             ++s;
         });
+        ++gb;
     };
-    for (int b = 0; b + 1 < nb; ++b) body(b, std::true_type{});
-    body(nb - 1, std::false_type{});
+    typedef std::integral_constant<int, 0> N0;
+    typedef std::integral_constant<int, 1> N1;
+    typedef std::integral_constant<int, 2> N2;
+    if constexpr (!ALL_PAIRED) {
+        for (int u = 0; u + 1 < U; ++u) body(K0{}, N1{}, u);
+        if constexpr (PHASED) body(K0{}, N2{}, U - 1);
+        else body(K0{}, N0{}, U - 1);
+    }
+    if constexpr (ALL_PAIRED || PHASED) {
+        for (int q = 0; q + 1 < Q; ++q) body(K1{}, N2{}, q);
+        body(K1{}, N0{}, Q - 1);
+    }
 
     halo_epilogue<T, BN, TM, TN, NW, SEG>(p, smem, acc, tid, wm, wn, l31, lh, x0, y0, n0, img, tx, ty);
 }

@@ -90,6 +90,12 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
                           // fragments (<= 256 B/clk) and the pieces write 32 KiB (~64 B/clk): ~900 of the 1 024 cycles its 128 MFMAs take.
                           // profiles/r04_gemm_dma_issue.txt.  Off.
 #endif
+#ifndef G_PAIR_XREAD
+#define G_PAIR_XREAD 1    // PAIRED K loop (round 5): the two ACTIVATION pieces of an even K' tile are issued in the read slot of the odd tile three
+                          // tiles before it (four fragment reads instead of twelve: the one slot with issue time to spare) and only its two weight
+                          // pieces between the MFMAs, so that EVERY multiply slot carries two pieces (0: four / two alternating).  An LDS-DMA piece
+                          // costs its wave 60-180 issue cycles; 16 MFMAs + four pieces overran the 512 cycles the partner's slot takes.
+#endif
 #ifndef G_HALF_TILES
 #define G_HALF_TILES 1    // persistent form: the last partial round of an XCD's run as 128-row half tiles (see the tile enumeration); 0 = whole tiles
 #endif
@@ -707,8 +713,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     slot_end();
                     for (int kt = 1; kt < nk_main; kt += 2) {
                         rd_w(kt);
+                        if (G_PAIR_XREAD) {
+                            dma_piece(kt + 3, 0);
+                            dma_piece(kt + 3, 2);
+                        }
                         slot_end();
-                        mmp(kt + 3, std::false_type{}, std::false_type{});
+                        mmp(kt + 3, std::false_type{}, std::integral_constant<bool, G_PAIR_XREAD != 0>{});
                         g_wait_vm<6>();
                         slot_end();
                         read_tile(kt + 1);
@@ -734,9 +744,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                     slot_end();
                     for (int kt = 1; kt < nk_main; kt += 2) {
                         rd_w(kt);
-                        g_wait_vm<2>();                              // tile kt + 1 landed; tile kt + 2 (odd: two pieces) in flight
+                        if (G_PAIR_XREAD) {
+                            dma_piece(kt + 3, 0);
+                            dma_piece(kt + 3, 2);
+                            g_wait_vm<4>();                          // tile kt + 1 landed; tile kt + 2 (odd: two pieces) and these two in flight
+                        } else {
+                            g_wait_vm<2>();                          // tile kt + 1 landed; tile kt + 2 (odd: two pieces) in flight
+                        }
                         slot_end();
-                        mmp(kt + 3, std::false_type{}, std::false_type{});
+                        mmp(kt + 3, std::false_type{}, std::integral_constant<bool, G_PAIR_XREAD != 0>{});
                         slot_end();
                         read_tile(kt + 1);
                         g_wait_vm<4>();                              // tile kt + 2 landed; tile kt + 3 (even: four pieces) in flight
