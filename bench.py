@@ -962,6 +962,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="c2: launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--unet-f16-groups", default=None, help="experiment: the ops.SplitPolicy.f16_inputs of the Stage-2 UNets (comma list) "
                                                            "instead of ops.UNET_POLICY's")
+    ap.add_argument("--unet-f16-weights", default=None, help="experiment: the ops.SplitPolicy.f16_weights of the Stage-2 UNets (comma list; an empty "
+                                                            "string = every weight of the fp16-input GEMMs as a pair) instead of ops.UNET_POLICY's")
     ap.add_argument("--profile-detail", action="store_true", help="append every matrix layer's shape to its group in roofline.by_kernel")
     ap.add_argument("--dev-env", action="store_true", help="apply the developer A/B switches of the environment (rsvld_amd.devtools.apply_env)")
     ap.add_argument("--pmc-pass", action="store_true", help="c4: one iteration of each stage + the fixed part and nothing "
@@ -993,8 +995,10 @@ def main():
         devtools.apply_env()
     if args.profile_detail:
         ops.PROFILE_DETAIL = True
-    if args.unet_f16_groups is not None:     # (the default policy object is what set_precision takes when none is passed)
-        ops.UNET_POLICY = ops.SplitPolicy(f16_inputs=tuple(g for g in args.unet_f16_groups.split(",") if g))
+    if args.unet_f16_groups is not None or args.unet_f16_weights is not None:     # (the default policy object is what set_precision takes when none is passed)
+        gi = ops.UNET_POLICY.f16_inputs if args.unet_f16_groups is None else tuple(g for g in args.unet_f16_groups.split(",") if g)
+        gw = None if args.unet_f16_weights is None else tuple(g for g in args.unet_f16_weights.split(",") if g)
+        ops.UNET_POLICY = ops.SplitPolicy(f16_inputs=tuple(gi), f16_weights=gw)
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

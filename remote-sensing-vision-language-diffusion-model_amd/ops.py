@@ -89,12 +89,28 @@ class SplitPolicy:
                     ("attn",) 2.5e-4 / 3.8e-5; + attn_out + ff 3.5e-4 / 4.6e-5; + qkv 3.5e-4 / 5.3e-5 (the default); + conv1 5.0e-4 / 6.7e-5
                     on the reduced-depth goldens but 1.2e-3 / 1.7e-3 (cache off / 0.3) at FULL depth against the fp32 family
                     (tests/test_gpu_fulldepth.py): outside the bar, rejected; qkv + conv2 6.6e-4 / 9.7e-5; qkv + conv1 + conv2 6.9e-4 / 9.3e-5;
-                    qkv + proj 4.8e-4 / 6.5e-5."""
+                    qkv + proj 4.8e-4 / 6.5e-5.
+    ``f16_weights`` the GEMM groups whose WEIGHTS are rounded to fp16 as well -- fp16 activation x fp16 weight, ONE MFMA per product, the plain
+                    gemm256 / conv_igemm kernels -- where the input already is fp16 (default: "qkv" and "geglu" wherever ``f16_inputs`` allows):
+                      "qkv"       to_q / to_k / to_v (fp16 out: the attention operands)
+                      "geglu"     the GEGLU projection of a FeedForward (fp16 out)
+                      "attn_out", "ff_out"   to_out / ff.net.2 (fp32 out + fp32 residual): measured, no kernel form yet
+                    A rounded weight is the SAME perturbation at every step, so this was expected to cost more than a rounded activation; measured
+                    it does not: after 50 steps on the reduced-depth goldens 3.5e-4 / 5.3e-5 -> 5.3e-4 / 6.3e-5 (qkv + geglu), 5.5e-4 / 6.8e-5 with all
+                    four; at FULL depth against the fp32 family 2.9e-4 -> 4.5e-4 (cache off), 4.0e-4 -> 5.5e-4 (0.3), means 3.2e-5 / 4.0e-5, every
+                    cache decision equal (tools/fulldepth_check.py; the residual stream, the norms and every convolution stay fp32 / three-MFMA)."""
 
-    __slots__ = ("impl", "f16_inputs")
+    __slots__ = ("impl", "f16_inputs", "f16_weights")
     GROUPS = ("attn", "attn_out", "ff", "qkv", "proj", "conv1", "conv2")
+    WEIGHT_GROUPS = ("qkv", "geglu", "attn_out", "ff_out")
 
-    def __init__(self, impl="planes", f16_inputs=("attn", "attn_out", "ff", "qkv")):
+    def __init__(self, impl="planes", f16_inputs=("attn", "attn_out", "ff", "qkv"), f16_weights=None):
+        if f16_weights is None:     # the default: the two groups below, where their inputs are fp16
+            f16_weights = tuple(g for g, i in (("qkv", "qkv"), ("geglu", "ff")) if i in f16_inputs and impl == "planes")
+        bad = [g for g in f16_weights if g not in self.WEIGHT_GROUPS]
+        if bad:
+            raise ValueError(f"SplitPolicy.f16_weights {bad}: one of {self.WEIGHT_GROUPS}")
+        self.f16_weights = frozenset(f16_weights)
         if impl not in ("planes", "f32"):
             raise ValueError(f"SplitPolicy.impl {impl!r}: planes or f32")
         bad = [g for g in f16_inputs if g not in self.GROUPS]
@@ -105,12 +121,16 @@ class SplitPolicy:
             raise ValueError("SplitPolicy: fp16 layer inputs go with fp16 attention operands (\"attn\")")
         if self.f16_inputs and impl != "planes":
             raise ValueError("SplitPolicy: fp16 layer inputs exist in the product path (impl \"planes\") only")
+        need = {"qkv": "qkv", "geglu": "ff", "attn_out": "attn_out", "ff_out": "ff"}
+        bad = [g for g in self.f16_weights if need[g] not in self.f16_inputs]
+        if bad:
+            raise ValueError(f"SplitPolicy.f16_weights {bad}: a layer's weights are rounded to fp16 only where its input is (f16_inputs)")
 
     def key(self):
-        return (self.impl, tuple(sorted(self.f16_inputs)))
+        return (self.impl, tuple(sorted(self.f16_inputs)), tuple(sorted(self.f16_weights)))
 
     def describe(self):
-        return {"impl": self.impl, "f16_inputs": sorted(self.f16_inputs)}
+        return {"impl": self.impl, "f16_inputs": sorted(self.f16_inputs), "f16_weights": sorted(self.f16_weights)}
 
     def __eq__(self, o):
         return isinstance(o, SplitPolicy) and self.key() == o.key()
@@ -119,11 +139,11 @@ class SplitPolicy:
         return hash(self.key())
 
     def __repr__(self):
-        return f"SplitPolicy(impl={self.impl!r}, f16_inputs={sorted(self.f16_inputs)})"
+        return f"SplitPolicy(impl={self.impl!r}, f16_inputs={sorted(self.f16_inputs)}, f16_weights={sorted(self.f16_weights)})"
 
 
 UNET_POLICY = SplitPolicy()                                   # the UNets / ControlNet of Stage 2
-ALL_SPLIT = SplitPolicy(f16_inputs=())                        # every product in three MFMAs, attention in the split kernels
+ALL_SPLIT = SplitPolicy(f16_inputs=(), f16_weights=())                        # every product in three MFMAs, attention in the split kernels
 VAE_POLICY = ALL_SPLIT                                        # the VAE (its single-head attentions are a third of the Stage-2 distance in fp16)
 
 # Inside ``with f32_split(policy)`` the matrix products of fp32 tensors run in the split precision under that policy
@@ -308,11 +328,12 @@ def _launch(name, flops, nbytes, fn):
 class PackedConv:
     """K-major 16-bit weights of a Conv2d / Linear: ``w[Cout_p, KH*KW*Cin_p]``, bias fp32."""
 
-    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu", "w3", "w2")
+    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu", "w3", "w2", "w1")
 
     def __init__(self, w, bias, cin, cout, cin_p, cout_p, kh, kw, geglu=False):
         self.w, self.bias = w, bias
         self.w3 = None     # split product path: bf16 triples [Cout_p][KH*KW][W_hi | W_lo | W_hi], packed on first use from the fp32 ``w``
+        self.w1 = None     # the fp32 ``w`` rounded to fp16 (SplitPolicy.f16_weights: fp16 activation x fp16 weight, one MFMA), likewise
         self.w2 = None     # fp16 pairs [Cout_p][KH*KW][W_lo | W_hi] (dtype RSVLD_F16W2: fp16 activations), likewise
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.kh, self.kw, self.geglu = kh, kw, geglu
@@ -370,7 +391,8 @@ SPLIT_HALO_MIN_WGS = 64    # the split precision: its gather kernel runs at 190-
 
 
 def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, residual=None,
-           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False, out_planes=False, out_group=None, norm_group=None):
+           out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False, out_planes=False, out_group=None, norm_group=None,
+           group=None):
     """NHWC convolution.  ``pad`` = int or (top, left, bottom, right).
 
     ``norm=(gamma, beta, groups, eps, silu)``: a GroupNorm(+SiLU) over the input ([x | x2]) precedes the
@@ -402,7 +424,13 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
             raise L.RsvldError("conv2d: fp32-packed weights take fp16 activations (RSVLD_F16W2), fp32 tensors or planes")
         if _split_fast():
             out_f32 = not out_planes
-    wt = _w2(pc) if w2 else pc.w
+            # the layer's weight group (SplitPolicy.f16_weights): named by the caller, or implied by the consumer of an fp16 output
+            wg = group if group is not None else ({"attn": "qkv", "ff": "geglu"}.get(out_group) if not out_f32 else None)
+            if wg is not None and _POLICY is not None and wg in _POLICY.f16_weights:
+                if out_f32:
+                    raise L.RsvldError(f"conv2d: weights rounded to fp16 (SplitPolicy.f16_weights {wg!r}) exist for fp16 outputs only")
+                w2 = False        # the plain fp16 kernels: ONE MFMA per product
+    wt = _w2(pc) if w2 else (_w1(pc) if pc.w.dtype == torch.float32 else pc.w)
     B, H, W, Cin = x.shape
     Cin2 = 0 if x2 is None else x2.shape[-1]
     if Cin + Cin2 != pc.cin_p:
@@ -558,6 +586,13 @@ def _w3(pc):
         L.check(L.load().rsvld_split_pack_weights(_ptr(pc.w), _ptr(w3), pc.cout_p, taps, pc.cin_p, _stream()), "rsvld_split_pack_weights")
         pc.w3 = w3
     return pc.w3
+
+
+def _w1(pc):
+    """The fp32 K-major ``w`` of a PackedConv rounded to fp16 (SplitPolicy.f16_weights), once."""
+    if pc.w1 is None:
+        pc.w1 = pc.w.half()
+    return pc.w1
 
 
 def _w2(pc):
@@ -722,13 +757,14 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
     return out
 
 
-def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0, out_planes=False, out_group=None):
-    """``[..., Cin] -> [..., Cout]`` on token-major tensors (a 1x1 conv over rows)."""
+def linear(x, pc, *, residual=None, act=L.ACT_NONE, alpha=1.0, beta=1.0, out_planes=False, out_group=None, group=None):
+    """``[..., Cin] -> [..., Cout]`` on token-major tensors (a 1x1 conv over rows).  ``group``: the layer's weight group
+    (``SplitPolicy.f16_weights``) where the consumer of its output does not name it."""
     shp = x.shape
     rows = x.numel() // shp[-1]
     res = None if residual is None else residual.reshape(1, 1, rows, residual.shape[-1])
     y = conv2d(x.reshape(1, 1, rows, shp[-1]), pc, pad=0, residual=res, act=act, alpha=alpha, beta=beta, out_planes=out_planes,
-               out_group=out_group)
+               out_group=out_group, group=group)
     return y.reshape(*shp[:-1], y.shape[-1])
 
 

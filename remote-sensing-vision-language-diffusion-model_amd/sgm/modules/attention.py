@@ -49,7 +49,7 @@ class FeedForward(nn.Module):
         # (split precision: ``x_norm`` arrives as planes, or as fp16 when the policy's "ff" group is set -- then both layers run as
         #  fp16 activation x weight pair, the GEGLU product stays fp16 and only the residual stream is fp32)
         g = ops.linear(x_norm, rt.pk(self.net[0].proj, "geglu", geglu=True), act=ACT_GEGLU, out_planes=True, out_group="ff")   # feeds a linear only
-        return ops.linear(g, rt.pk(self.net[2]), residual=residual)
+        return ops.linear(g, rt.pk(self.net[2]), residual=residual, group="ff_out")
 
 
 class CrossAttention(nn.Module):
@@ -89,7 +89,7 @@ class CrossAttention(nn.Module):
                 kv = kv.index_select(0, rows)
             k, v = kv[..., :inner], kv[..., inner:]
         o = ops.attention(q, k, v, heads=self.heads, scale=self.scale)
-        return ops.linear(o, rt.pk(self.to_out[0]), residual=residual, alpha=alpha)
+        return ops.linear(o, rt.pk(self.to_out[0]), residual=residual, alpha=alpha, group="attn_out")
 
 
 MemoryEfficientCrossAttention = CrossAttention  # same parameters; the kernel IS the memory-efficient path

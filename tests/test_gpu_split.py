@@ -390,6 +390,12 @@ def test_attention_split_mode_f16_composition(cuda, B, heads, Nq, Nk, D, shared)
 # Round 5: the weight-pair form (dtype RSVLD_F16W2: fp16 activation x fp16 [W_lo | W_hi], two MFMAs per product) and the fp16 hand-over
 # of the split kernels.  Reference = fp64 on the host over the SAME fp16-rounded activation (the rounding of the input is the policy's
 # decision, measured end to end in DESIGN.md section 4; here the KERNEL must add nothing beyond the weights' ~2^-22).
+def PAIRS_ONLY():
+    """The UNets' policy with every weight of the fp16-input GEMMs kept as a pair (the default rounds to_q / to_k / to_v and the GEGLU projection to fp16)."""
+    from rsvld_amd import ops
+    return ops.SplitPolicy(f16_weights=())
+
+
 W2_LINEAR_CASES = [
     # rows, K, N, residual (fp32), geglu, f16 out
     (8192, 640, 5120, False, True, True),        # GEGLU feed-forward, fp16 out: the persistent gemm256 (SEG = 2)
@@ -419,7 +425,7 @@ def test_linear_weight_pairs(cuda, case):
     if use_res:
         y = y * 0.5 + res.double()
     pc = ops.pack_conv(w, b, torch.float32, cuda, geglu=geglu)
-    with ops.f32_split(ops.UNET_POLICY):      # inside a split-precision network: fp32 out unless the consumer takes fp16 (out_planes)
+    with ops.f32_split(PAIRS_ONLY()):         # inside a split-precision network: fp32 out unless the consumer takes fp16 (out_planes); every weight as a pair
         got = ops.linear(x16.to(cuda), pc, residual=None if res is None else res.to(cuda), act=L.ACT_GEGLU if geglu else L.ACT_NONE,
                          alpha=0.5 if use_res else 1.0, out_planes=f16_out, out_group="ff")
     assert got.dtype == (torch.float16 if f16_out else torch.float32) and got.shape == tuple(y.shape)
@@ -429,6 +435,32 @@ def test_linear_weight_pairs(cuda, case):
     w2 = ops._w2(pc).view(pc.cout_p, 2, pc.cin_p).float().cpu()
     wp = pc.w.cpu()
     assert torch.equal(w2[:, 1], wp.half().float()) and torch.equal(w2[:, 0], (wp - wp.half().float()).half().float())
+
+
+@pytest.mark.parametrize("rows,K,N,geglu", [(8192, 640, 1920, False), (4096 + 13, 1280, 5120, True), (300, 320, 960, False)])
+def test_linear_fp16_weights_route(cuda, rows, K, N, geglu):
+    """``SplitPolicy.f16_weights`` ("qkv": the consumer of the fp16 output is the attention; "geglu": a FeedForward): the fp32-packed weights are
+    rounded to fp16 once and the PLAIN fp16 kernels run -- one MFMA per product.  The route must be exactly that: bit for bit the result of the
+    same layer packed in fp16; a policy without the group keeps the pair (and differs)."""
+    from rsvld_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(rows + N)
+    x16 = torch.randn(rows, K, generator=g).half().to(cuda)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    act = L.ACT_GEGLU if geglu else L.ACT_NONE
+    pc32 = ops.pack_conv(w, b, torch.float32, cuda, geglu=geglu)
+    pc16 = ops.pack_conv(w, b, torch.float16, cuda, geglu=geglu)
+    want = ops.linear(x16, pc16, act=act)                                   # the reference's GPU policy for this layer
+    og = "ff" if geglu else "attn"
+    with ops.f32_split(ops.UNET_POLICY):
+        got = ops.linear(x16, pc32, act=act, out_planes=True, out_group=og)
+    with ops.f32_split(PAIRS_ONLY()):
+        pair = ops.linear(x16, pc32, act=act, out_planes=True, out_group=og)
+    assert got.dtype == torch.float16 and torch.equal(got, want)
+    assert pair.dtype == torch.float16 and not torch.equal(pair, want)
+    assert ("geglu" if geglu else "qkv") in ops.UNET_POLICY.f16_weights and ops.UNET_POLICY.key() != PAIRS_ONLY().key()
+    with pytest.raises(ValueError):
+        ops.SplitPolicy(f16_inputs=("attn",), f16_weights=("qkv",))       # a weight is rounded only where its input is
 
 
 @pytest.mark.parametrize("rows,K,N,geglu", [(8192, 640, 1920, False), (4096 + 13, 1280, 2560, True), (500, 320, 960, False)])

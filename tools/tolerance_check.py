@@ -84,11 +84,14 @@ if __name__ == "__main__":
              "split": ("split", "split", "split", None, None),
              "split_s1w2": ("w2", "split", "split", None, None),                            # Stage 1: fp16 tensors x weight pairs
              "split_r04": ("split", "split", "split", P(f16_inputs=("attn",)), P(f16_inputs=("attn",))),   # round 4's composition
-             "split_noqkv": ("split", "split", "split", P(f16_inputs=("attn", "attn_out", "ff")), None),
-             "split_noconv": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv")), None),
-             "split_conv": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "conv1", "conv2")), None),
-             "split_conv2": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "conv2")), None),
-             "split_proj": ("split", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "proj")), None),
+             "split_noqkv": ("split", "split", "split", P(f16_inputs=("attn", "attn_out", "ff"), f16_weights=()), None),
+             "split_noconv": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv"), f16_weights=()), None),
+             "split_conv": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "conv1", "conv2"), f16_weights=()), None),
+             "split_conv2": ("w2", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "conv2"), f16_weights=()), None),
+             "split_proj": ("split", "split", "split", P(f16_inputs=("attn", "attn_out", "ff", "qkv", "proj"), f16_weights=()), None),
+             "split_pairs": ("w2", "split", "split", P(f16_weights=()), None),                 # every weight of the fp16-input GEMMs as a pair (two MFMAs)
+             "split_w1_qkv": ("w2", "split", "split", P(f16_weights=("qkv",)), None),          # to_q / to_k / to_v weights rounded to fp16 (one MFMA)
+             "split_w1_geglu": ("w2", "split", "split", P(f16_weights=("geglu",)), None),      # the GEGLU projection's
              "split_full": ("split", "split", "split", ops.ALL_SPLIT, ops.ALL_SPLIT)}
     if "--only" in sys.argv:
         modes = {k: v for k, v in modes.items() if k in sys.argv[sys.argv.index("--only") + 1].split(",")}
