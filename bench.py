@@ -301,6 +301,7 @@ PMC_ALIAS = {"attention_d64": ("attn_d64c", "attn_d64"), "attention_d64_cross": 
              "conv_halo_64_split": ("conv_halo_64",), "conv_igemm_split": ("conv_igemm_64x128",), "groupnorm_apply_split": ("gn_apply_split",),
              "groupnorm_stats_split": ("gn_partial_f32",), "layernorm_split": ("layernorm_split",), "split_planes": ("split_planes",),
              # the weight-pair form (round 5): the RSVLD_F16W2 instantiations of the same kernels
+             "gemm_256x256_w1": ("gemm256_w1", "gemm256"),
              "gemm_256x256_w2": ("gemm256_w2", "gemm256"), "conv_halo_128_w2": ("conv_halo_128_w2", "conv_halo_128"),
              "conv_halo_64_w2": ("conv_halo_64_w2", "conv_halo_64"), "conv_igemm_64x128_w2": ("conv_igemm_64x128",),
              "conv_igemm_128x128_w2": ("conv_igemm_128x128",)}

@@ -41,6 +41,7 @@ extern "C" {
 #define RSVLD_F32 2   /* accepted ONLY by the *_f32 entry points at the end of this header */
 #define RSVLD_SPLIT 3 /* split-operand precision on the 16-bit tilings (rsvld_conv_desc.dtype; the *_split entry points below) */
 #define RSVLD_F16W2 4 /* fp16 activations x fp16 weight PAIRS [W_lo | W_hi] (rsvld_conv_desc.dtype; see below): two MFMAs per product */
+#define RSVLD_F16W1 5 /* fp16 activations x the SAME weights rounded to fp16, fp32 out (+ fp32 residual): one MFMA per product (see below) */
 
 /* epilogue activations for rsvld_conv2d_nhwc */
 #define RSVLD_ACT_NONE 0
@@ -114,6 +115,11 @@ typedef struct rsvld_conv_desc {
  * the activation: two MFMAs per product instead of RSVLD_SPLIT's three, half the activation bytes, and the fused GroupNorm prologue
  * of the halo kernel stays available.  residual: fp32.  out: fp32 when out_f32 = 1, fp16 when out_f32 = 0 (no residual then).
  * RSVLD_SPLIT with out_f32 = 2 writes fp16 as well (q | k | v on their way to the 16-bit attention kernels). */
+/* dtype = RSVLD_F16W1 (round 5; accepted by rsvld_conv2d_nhwc, 1x1 only): a Linear layer of a split-precision transformer block whose policy
+ * rounds its WEIGHTS to fp16 as well (SplitPolicy.f16_weights "attn_out" / "ff_out": to_out of sgm/modules/attention.py:288-373, ff.net.2
+ * of :250-285).  x : fp16; w : plain fp16 [Cout][Cin] (what RSVLD_F16 takes): ONE MFMA per product -- with the OUTPUT side of the
+ * multi-segment family: out fp32 (out_f32 must be 1), residual fp32, out = alpha * (x W + b) + beta * residual in fp32.  The same layer with
+ * a 16-bit output is plain RSVLD_F16. */
 int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
 
 /* 3x3 / stride-1 / pad-1 convolution with an LDS-resident input halo patch (each activation byte crosses

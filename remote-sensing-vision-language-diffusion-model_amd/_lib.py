@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("RSVLD_LIB") or os.path.join(_PKG_DIR, "librsvld_hip.s
 F16, BF16, F32 = 0, 1, 2   # F32: the *_f32 entry points only (fp32-operand VAE family)
 SPLIT = 3                   # rsvld_conv_desc.dtype: bf16 planes + weight triples (the split-operand product path)
 F16W2 = 4                   # rsvld_conv_desc.dtype: fp16 activations x fp16 weight pairs [W_lo | W_hi]
+F16W1 = 5                   # rsvld_conv_desc.dtype: fp16 activations x fp16 weights, fp32 out + fp32 residual (one MFMA per product)
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 # rsvld_conv_desc.tune (developer A/B overrides)
 TUNE_TILE = {"256x64": 1, "128x64": 2, "128x128": 3, "64x128": 4}

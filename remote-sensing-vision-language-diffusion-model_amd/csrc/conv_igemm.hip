@@ -569,9 +569,12 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     if (d->Cin <= 0 || d->Cin % 8 != 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
     if (d->Cin2 < 0 || d->Cin2 % 8 != 0 || ((d->Cin2 > 0) != (d->x2 != nullptr))) return RSVLD_EINVAL;
     if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0) return RSVLD_EINVAL;
-    const bool split = d->dtype == RSVLD_SPLIT, w2 = d->dtype == RSVLD_F16W2;
+    // RSVLD_F16W1: the weight-pair kernels (SEG = 2: fp16 in, fp32 out + fp32 residual) over ONE K segment -- their second-segment wrap of the
+    // channel index never triggers when Ctot = Cseg, and the weight rows are K long
+    const bool split = d->dtype == RSVLD_SPLIT, w1 = d->dtype == RSVLD_F16W1, w2 = d->dtype == RSVLD_F16W2 || w1;
     const int seg = split ? 3 : w2 ? 2 : 1;
     if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16 && seg == 1) return RSVLD_EINVAL;
+    if (w1 && (d->out_f32 != 1 || d->KH != 1 || d->KW != 1)) return RSVLD_EINVAL;
     if (d->out_f32 < 0 || d->out_f32 > 2 || (d->out_f32 == 2 && !split)) return RSVLD_EINVAL;
     if (seg == 1 && d->out_f32 && (d->Cout > 32 || d->act == RSVLD_ACT_GEGLU || d->residual != nullptr)) return RSVLD_EUNSUPPORTED;
     if (split && d->out_f32 != 1 && d->residual != nullptr) return RSVLD_EINVAL;   // planes / fp16 out of RSVLD_SPLIT: no residual (the stream stays fp32)
@@ -612,7 +615,7 @@ extern "C" int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream) {
     a.seg = seg;
     a.out_kind = d->out_f32 == 1 ? 1 : (split && d->out_f32 == 0) ? 2 : 0;
     a.Cseg8 = (d->Cin + d->Cin2) / 8;
-    a.Ctot8 = seg * a.Cseg8;
+    a.Ctot8 = (w1 ? 1 : seg) * a.Cseg8;
     a.KC = d->KH * d->KW * a.Ctot8;
     a.nk = (a.KC + 7) / 8;
     a.Cout_out = d->act == RSVLD_ACT_GEGLU ? d->Cout / 2 : d->Cout;

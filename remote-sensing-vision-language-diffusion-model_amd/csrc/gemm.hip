@@ -140,7 +140,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
     static_assert(WIDE == 0 || SEG > 1, "the fp32 / planes epilogues belong to the multi-segment kernels");
     static_assert(!(PERSIST && WIDE == 1), "persistent form: the 16-bit epilogue (WIDE 0) or fp32 out + fp32 residual (WIDE 2, PV 4 = none)");
     static_assert(!(PERSIST && WIDE == 2) || PV == 0, "the persistent fp32 epilogue has one variant: no activation, alpha, + beta * residual");
-    static_assert(SEG >= 1 && SEG <= 3, "1 plain, 2 fp16 x weight pairs, 3 bf16 planes x weight triples");
+    static_assert(SEG >= 1 && SEG <= 4, "1 plain, 2 fp16 x weight pairs, 3 bf16 planes x weight triples, 4 fp16 x fp16 with the multi-segment outputs");
+    // SEG 4 (RSVLD_F16W1): ONE K segment -- a plain fp16 GEMM -- with the output side of the multi-segment family (fp32 out + fp32 residual)
+    constexpr int NSEG = SEG == 4 ? 1 : SEG;
     static_assert(SEG == 1 || !(PV & 8), "the persistent residual variants are 16-bit residuals (plain GEMM only)");
     static_assert(PERSIST || PV == 0, "PV is the persistent epilogue's variant");
     constexpr bool SPLIT = SEG == 3;
@@ -211,9 +213,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
         }
     }
     const int nk0 = p.K >> 5;
-    const int nk = (G_ABL & 4) ? 3 : SEG * nk0;   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
+    const int nk = (G_ABL & 4) ? 3 : NSEG * nk0;   // diagnostic build 4: three K steps only (workgroup turnover + ring fill)
     const int64_t rowb = (int64_t)p.K * (int64_t)sizeof(T) * (SPLIT ? 2 : 1);    // activation row: K values, or the planes lo | hi
-    const int64_t rowb_w = (int64_t)p.K * (int64_t)sizeof(T) * SEG;              // weight row: K values, the pair lo | hi, or the triple hi | lo | hi
+    const int64_t rowb_w = (int64_t)p.K * (int64_t)sizeof(T) * NSEG;             // weight row: K values, the pair lo | hi, or the triple hi | lo | hi
     // K tile kt of the concatenated K' -> the activation's K tile: SPLIT reads the planes lo, hi, hi (tiles >= 2 nk0 alias the hi
     // plane), the pair form reads the one row twice; the weight row is linear
     // PAIRED (round 5; the persistent weight-pair GEMMs): the two K' tiles of one activation K tile are ADJACENT -- tile 2 p = [X(p) | W_lo(p)],
@@ -1415,11 +1417,12 @@ int gemm_go(dim3 grid, hipStream_t s, const GemmArgs& a) {
 }  // namespace
 
 int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
-    const bool split = d->dtype == RSVLD_SPLIT, w2 = d->dtype == RSVLD_F16W2;
-    const int seg = split ? 3 : w2 ? 2 : 1;
+    const bool split = d->dtype == RSVLD_SPLIT, w2 = d->dtype == RSVLD_F16W2, w1 = d->dtype == RSVLD_F16W1;
+    const int seg = split ? 3 : w2 ? 2 : 1;          // K segments (RSVLD_F16W1: one, in the SEG = 4 kernels: the multi-segment family's outputs)
     if (d->tune & RSVLD_TUNE_NO_GEMM256) return RSVLD_EUNSUPPORTED;   // A/B switch
+    if (w1 && d->out_f32 != 1) return RSVLD_EINVAL;
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad_t != 0 || d->pad_l != 0 || d->upsample) return RSVLD_EUNSUPPORTED;
-    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || (d->out_f32 && seg == 1)) return RSVLD_EUNSUPPORTED;
+    if (d->x2 != nullptr || d->Cin2 != 0 || d->rowvec != nullptr || (d->out_f32 && seg == 1 && !w1)) return RSVLD_EUNSUPPORTED;
     if (d->Cin % 32 != 0 || d->Cout % 8 != 0) return RSVLD_EUNSUPPORTED;
     const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
     if (d->H != d->Ho || d->W != d->Wo) return RSVLD_EUNSUPPORTED;
@@ -1440,12 +1443,12 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     a.N_out = d->act == RSVLD_ACT_GEGLU ? d->Cout / 2 : d->Cout;
     a.act = d->act; a.alpha = d->alpha; a.beta = d->beta;
     // out_kind: 0 = 16-bit (T, or fp16 from the multi-segment forms), 1 = fp32, 2 = bf16 planes (RSVLD_SPLIT's native output)
-    a.out_kind = seg == 1 ? 0 : d->out_f32 == 1 ? 1 : (split && d->out_f32 == 0) ? 2 : 0;
+    a.out_kind = w1 ? 1 : seg == 1 ? 0 : d->out_f32 == 1 ? 1 : (split && d->out_f32 == 0) ? 2 : 0;
     hipStream_t s = (hipStream_t)stream;
     const unsigned nmt = (unsigned)((M + 255) / 256), nnt = (unsigned)((d->Cout + 255) / 256);
     const dim3 grid1(nmt, nnt);
     // the persistent form: 16-bit output, at least four K tiles (its K loop peels tile 0 and requests three tiles ahead)
-    const bool wide_res = seg > 1 && a.out_kind == 1 && a.residual != nullptr && a.act == RSVLD_ACT_NONE;   // fp32 out + fp32 residual
+    const bool wide_res = (seg > 1 || w1) && a.out_kind == 1 && a.residual != nullptr && a.act == RSVLD_ACT_NONE;   // fp32 out + fp32 residual
     if (!(d->tune & RSVLD_TUNE_GEMM_ONE_TILE) && (a.out_kind == 0 || wide_res) && seg * d->Cin >= 128) {
         static const int n_cu = [] {
             int dev = 0, n = 0;
@@ -1458,7 +1461,10 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
             const bool h = d->dtype == RSVLD_F16;
             if (wide_res) {
                 return split ? gemm_go<gemm256_kernel<bf16, 3, true, 0, 2>, G_SMEM_P>(pgrid, s, a)
+                       : w1  ? gemm_go<gemm256_kernel<f16, 4, true, 0, 2>, G_SMEM_P>(pgrid, s, a)
                              : gemm_go<gemm256_kernel<f16, 2, true, 0, 2>, G_SMEM_P>(pgrid, s, a);
+            } else if (w1) {
+                // (fp32 out without a residual, or with an activation: the one-tile form below)
             } else if (seg == 1) {
 #define G_PV_CASE(V) case V: return h ? gemm_go<gemm256_kernel<f16, 1, true, V>, G_SMEM_P>(pgrid, s, a) : gemm_go<gemm256_kernel<bf16, 1, true, V>, G_SMEM_P>(pgrid, s, a);
                 switch (pv) {
@@ -1482,6 +1488,8 @@ int rsvld_gemm256_try(const rsvld_conv_desc* d, void* stream) {
     if (split) return wide == 2 ? gemm_go<gemm256_kernel<bf16, 3, false, 0, 2>, G_SMEM>(grid1, s, a)
                     : wide == 1 ? gemm_go<gemm256_kernel<bf16, 3, false, 0, 1>, G_SMEM>(grid1, s, a)
                                 : gemm_go<gemm256_kernel<bf16, 3, false, 0, 0>, G_SMEM>(grid1, s, a);
+    if (w1) return wide == 2 ? gemm_go<gemm256_kernel<f16, 4, false, 0, 2>, G_SMEM>(grid1, s, a)
+                             : gemm_go<gemm256_kernel<f16, 4, false, 0, 1>, G_SMEM>(grid1, s, a);
     if (w2) return wide == 2 ? gemm_go<gemm256_kernel<f16, 2, false, 0, 2>, G_SMEM>(grid1, s, a)
                  : wide == 1 ? gemm_go<gemm256_kernel<f16, 2, false, 0, 1>, G_SMEM>(grid1, s, a)
                              : gemm_go<gemm256_kernel<f16, 2, false, 0, 0>, G_SMEM>(grid1, s, a);

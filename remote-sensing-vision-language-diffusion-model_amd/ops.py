@@ -91,22 +91,24 @@ class SplitPolicy:
                     (tests/test_gpu_fulldepth.py): outside the bar, rejected; qkv + conv2 6.6e-4 / 9.7e-5; qkv + conv1 + conv2 6.9e-4 / 9.3e-5;
                     qkv + proj 4.8e-4 / 6.5e-5.
     ``f16_weights`` the GEMM groups whose WEIGHTS are rounded to fp16 as well -- fp16 activation x fp16 weight, ONE MFMA per product, the plain
-                    gemm256 / conv_igemm kernels -- where the input already is fp16 (default: "qkv" and "geglu" wherever ``f16_inputs`` allows):
+                    gemm256 / conv_igemm kernels -- where the input already is fp16 (default: all four wherever ``f16_inputs`` allows):
                       "qkv"       to_q / to_k / to_v (fp16 out: the attention operands)
                       "geglu"     the GEGLU projection of a FeedForward (fp16 out)
-                      "attn_out", "ff_out"   to_out / ff.net.2 (fp32 out + fp32 residual): measured, no kernel form yet
+                      "attn_out", "ff_out"   to_out / ff.net.2 (fp32 out + fp32 residual: dtype RSVLD_F16W1)
                     A rounded weight is the SAME perturbation at every step, so this was expected to cost more than a rounded activation; measured
-                    it does not: after 50 steps on the reduced-depth goldens 3.5e-4 / 5.3e-5 -> 5.3e-4 / 6.3e-5 (qkv + geglu), 5.5e-4 / 6.8e-5 with all
-                    four; at FULL depth against the fp32 family 2.9e-4 -> 4.5e-4 (cache off), 4.0e-4 -> 5.5e-4 (0.3), means 3.2e-5 / 4.0e-5, every
-                    cache decision equal (tools/fulldepth_check.py; the residual stream, the norms and every convolution stay fp32 / three-MFMA)."""
+                    it does not: after 50 steps on the reduced-depth goldens 3.5e-4 / 5.3e-5 (every weight a pair) -> 5.3e-4 / 6.3e-5 (qkv + geglu) ->
+                    4.5e-4 / 7.0e-5 (all four: the default; single groups scatter between 4.5e-4 and 7.8e-4 in the maximum, 6.3-7.5e-5 in the
+                    mean); at FULL depth against the fp32 family 2.9e-4 -> 5.4e-4 (cache off), 4.0e-4 -> 4.9e-4 (0.3), means 3.9e-5 / 4.6e-5, every
+                    cache decision equal (tools/tolerance_check.py, tools/fulldepth_check.py; the residual stream, the norms, proj_in / proj_out and
+                    every convolution stay fp32 / three-MFMA).  16.7 -> 10.5 s of GEMM time per 4096^2 image."""
 
     __slots__ = ("impl", "f16_inputs", "f16_weights")
     GROUPS = ("attn", "attn_out", "ff", "qkv", "proj", "conv1", "conv2")
     WEIGHT_GROUPS = ("qkv", "geglu", "attn_out", "ff_out")
 
     def __init__(self, impl="planes", f16_inputs=("attn", "attn_out", "ff", "qkv"), f16_weights=None):
-        if f16_weights is None:     # the default: the two groups below, where their inputs are fp16
-            f16_weights = tuple(g for g, i in (("qkv", "qkv"), ("geglu", "ff")) if i in f16_inputs and impl == "planes")
+        if f16_weights is None:     # the default: every transformer GEMM whose input is fp16
+            f16_weights = tuple(g for g, i in (("qkv", "qkv"), ("geglu", "ff"), ("attn_out", "attn_out"), ("ff_out", "ff")) if i in f16_inputs and impl == "planes")
         bad = [g for g in f16_weights if g not in self.WEIGHT_GROUPS]
         if bad:
             raise ValueError(f"SplitPolicy.f16_weights {bad}: one of {self.WEIGHT_GROUPS}")
@@ -419,6 +421,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         return _conv2d_f32(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
                            act=act, alpha=alpha, beta=beta, norm=norm)
     w2 = pc.w.dtype == torch.float32         # fp32 masters under a 16-bit activation: the weight-pair form
+    w1res = False
     if w2:
         if x.dtype != torch.float16:
             raise L.RsvldError("conv2d: fp32-packed weights take fp16 activations (RSVLD_F16W2), fp32 tensors or planes")
@@ -428,9 +431,12 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
             wg = group if group is not None else ({"attn": "qkv", "ff": "geglu"}.get(out_group) if not out_f32 else None)
             if wg is not None and _POLICY is not None and wg in _POLICY.f16_weights:
                 if out_f32:
-                    raise L.RsvldError(f"conv2d: weights rounded to fp16 (SplitPolicy.f16_weights {wg!r}) exist for fp16 outputs only")
-                w2 = False        # the plain fp16 kernels: ONE MFMA per product
-    wt = _w2(pc) if w2 else (_w1(pc) if pc.w.dtype == torch.float32 else pc.w)
+                    if pc.kh != 1 or pc.kw != 1 or x2 is not None:
+                        raise L.RsvldError(f"conv2d: SplitPolicy.f16_weights {wg!r} with an fp32 output is a Linear layer's form (RSVLD_F16W1)")
+                    w1res = True  # fp16 x fp16, ONE MFMA per product, fp32 out + fp32 residual (dtype RSVLD_F16W1)
+                else:
+                    w2 = False    # the plain fp16 kernels
+    wt = _w1(pc) if w1res else _w2(pc) if w2 else (_w1(pc) if pc.w.dtype == torch.float32 else pc.w)
     B, H, W, Cin = x.shape
     Cin2 = 0 if x2 is None else x2.shape[-1]
     if Cin + Cin2 != pc.cin_p:
@@ -463,9 +469,9 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         rowvec=None if rowvec is None else rowvec.data_ptr(),
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride,
-        pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=L.F16W2 if w2 else _dt(x), out_f32=int(out_f32),
+        pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=L.F16W1 if w1res else L.F16W2 if w2 else _dt(x), out_f32=int(out_f32),
         act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=_PLAN_DIV, tune=TUNE)
-    sfx = "_w2" if w2 else ""
+    sfx = "_w1" if w1res else "_w2" if w2 else ""
     lib = L.load()
     halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
     Bp = -(-B // _PLAN_DIV)            # batch rows of one planning unit: every plan decision below uses Bp / Mp

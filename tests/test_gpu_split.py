@@ -391,7 +391,7 @@ def test_attention_split_mode_f16_composition(cuda, B, heads, Nq, Nk, D, shared)
 # of the split kernels.  Reference = fp64 on the host over the SAME fp16-rounded activation (the rounding of the input is the policy's
 # decision, measured end to end in DESIGN.md section 4; here the KERNEL must add nothing beyond the weights' ~2^-22).
 def PAIRS_ONLY():
-    """The UNets' policy with every weight of the fp16-input GEMMs kept as a pair (the default rounds to_q / to_k / to_v and the GEGLU projection to fp16)."""
+    """The UNets' policy with every weight of the fp16-input GEMMs kept as a pair (the default rounds the transformer GEMMs' weights to fp16)."""
     from rsvld_amd import ops
     return ops.SplitPolicy(f16_weights=())
 
@@ -461,6 +461,33 @@ def test_linear_fp16_weights_route(cuda, rows, K, N, geglu):
     assert ("geglu" if geglu else "qkv") in ops.UNET_POLICY.f16_weights and ops.UNET_POLICY.key() != PAIRS_ONLY().key()
     with pytest.raises(ValueError):
         ops.SplitPolicy(f16_inputs=("attn",), f16_weights=("qkv",))       # a weight is rounded only where its input is
+
+
+@pytest.mark.parametrize("rows,K,N", [(16384, 1280, 1280), (8192 + 77, 2560, 640), (20000, 640, 640), (66000, 320, 256), (300, 640, 640), (4096, 128, 320)])
+def test_linear_fp16_weights_fp32_residual(cuda, rows, K, N):
+    """dtype RSVLD_F16W1 (``SplitPolicy.f16_weights`` "attn_out" / "ff_out"): fp16 activation x the weights rounded to fp16, ONE MFMA per
+    product, fp32 accumulation, fp32 out + fp32 residual -- through the persistent gemm256 (SEG = 4), its one-tile form and the implicit-GEMM
+    kernel.  Against fp64 over the SAME rounded operands: the kernel adds nothing but the fp32 summation."""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x16 = torch.randn(rows, K, generator=g).half()
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(rows, N, generator=g)
+    y = (x16.double() @ w.half().double().t() + b.double()) * 0.5 + res.double()
+    pc = ops.pack_conv(w, b, torch.float32, cuda)
+    assert {"attn_out", "ff_out"} <= ops.UNET_POLICY.f16_weights
+    with ops.f32_split(ops.UNET_POLICY):
+        got = ops.linear(x16.to(cuda), pc, residual=res.to(cuda), alpha=0.5, group="ff_out")
+        none = ops.linear(x16.to(cuda), pc, alpha=0.5, group="attn_out")             # fp32 out without a residual: the one-tile / implicit-GEMM forms
+    with ops.f32_split(PAIRS_ONLY()):
+        pair = ops.linear(x16.to(cuda), pc, residual=res.to(cuda), alpha=0.5, group="ff_out")
+    assert got.dtype == torch.float32 and none.dtype == torch.float32
+    _cmp(got, y, 3e-6, f"linear, fp16 weights, fp32 out + residual ({rows}, {K}, {N})")
+    _cmp(none, y - res.double(), 3e-6, "  without a residual")
+    assert not torch.equal(pair, got)      # (a policy without the groups keeps these layers' weights as pairs)
+    with pytest.raises(ValueError):
+        ops.SplitPolicy(f16_weights=("conv",))
 
 
 @pytest.mark.parametrize("rows,K,N,geglu", [(8192, 640, 1920, False), (4096 + 13, 1280, 2560, True), (500, 320, 960, False)])

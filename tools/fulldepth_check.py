@@ -9,7 +9,9 @@ from rsvld_amd import ops
 
 dev = torch.device("cuda:0")
 P = ops.SplitPolicy
-POLICIES = {"default": ops.UNET_POLICY, "pairs": P(f16_weights=()), "w1_qkv": P(f16_weights=("qkv",)), "w1_geglu": P(f16_weights=("geglu",))}
+POLICIES = {"default": ops.UNET_POLICY, "pairs": P(f16_weights=()), "w1_qkv": P(f16_weights=("qkv",)), "w1_geglu": P(f16_weights=("geglu",)),
+            "w1_all": P(f16_weights=("qkv", "geglu", "attn_out", "ff_out")), "w1_ao": P(f16_weights=("qkv", "geglu", "attn_out")),
+            "w1_fo": P(f16_weights=("qkv", "geglu", "ff_out"))}
 if "--only" in sys.argv:
     keep = sys.argv[sys.argv.index("--only") + 1].split(",")
     POLICIES = {k: v for k, v in POLICIES.items() if k in keep}

@@ -92,6 +92,9 @@ if __name__ == "__main__":
              "split_pairs": ("w2", "split", "split", P(f16_weights=()), None),                 # every weight of the fp16-input GEMMs as a pair (two MFMAs)
              "split_w1_qkv": ("w2", "split", "split", P(f16_weights=("qkv",)), None),          # to_q / to_k / to_v weights rounded to fp16 (one MFMA)
              "split_w1_geglu": ("w2", "split", "split", P(f16_weights=("geglu",)), None),      # the GEGLU projection's
+             "split_w1_all": ("w2", "split", "split", P(f16_weights=("qkv", "geglu", "attn_out", "ff_out")), None),   # + to_out and ff.net.2 (RSVLD_F16W1)
+             "split_w1_ao": ("w2", "split", "split", P(f16_weights=("qkv", "geglu", "attn_out")), None),
+             "split_w1_fo": ("w2", "split", "split", P(f16_weights=("qkv", "geglu", "ff_out")), None),
              "split_full": ("split", "split", "split", ops.ALL_SPLIT, ops.ALL_SPLIT)}
     if "--only" in sys.argv:
         modes = {k: v for k, v in modes.items() if k in sys.argv[sys.argv.index("--only") + 1].split(",")}
