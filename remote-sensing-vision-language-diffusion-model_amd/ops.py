@@ -100,7 +100,9 @@ class SplitPolicy:
                     4.5e-4 / 7.0e-5 (all four: the default; single groups scatter between 4.5e-4 and 7.8e-4 in the maximum, 6.3-7.5e-5 in the
                     mean); at FULL depth against the fp32 family 2.9e-4 -> 5.4e-4 (cache off), 4.0e-4 -> 4.9e-4 (0.3), means 3.9e-5 / 4.6e-5, every
                     cache decision equal (tools/tolerance_check.py, tools/fulldepth_check.py; the residual stream, the norms, proj_in / proj_out and
-                    every convolution stay fp32 / three-MFMA).  16.7 -> 10.5 s of GEMM time per 4096^2 image."""
+                    every convolution stay fp32 / three-MFMA).  16.7 -> 10.5 s of GEMM time per 4096^2 image.
+                    The convolutions are different: their weights rounded to fp16 (emulated through the triples of fp16(W), round 5) end at
+                    1.8e-3 on the goldens and 2.6e-3 / 2.3e-3 at full depth -- no two-MFMA form of the 3x3 layers on fp16 planes x fp16 weights."""
 
     __slots__ = ("impl", "f16_inputs", "f16_weights")
     GROUPS = ("attn", "attn_out", "ff", "qkv", "proj", "conv1", "conv2")
