@@ -364,6 +364,21 @@ int rsvld_nchw_f32_to_nhwc_f32(const float* src, float* dst, int B, int C, int H
  * Replaces torch.nn.functional.linear with ONE activation row in the Llama decode step behind models/util.py:17-66
  * (llava/model/language_model/llava_llama.py:118-137): q|k|v, o, gate|up, down projections and lm_head. */
 int rsvld_gemv(const void* w, const void* x, const void* bias, void* y, int N, int K, int dtype, void* stream);
+/* rsvld_gemv with the element-wise neighbours of a Llama decoder layer's decode step folded in (the same reference call sites; the unfused
+ * sequence is ~26 launches per layer, the token loop is launch-bound): norm_w != NULL: x <- RMSNorm(x) * norm_w (LlamaRMSNorm in front of
+ * q|k|v, gate|up and lm_head; norm_eps); glu: x holds 2 K elements [gate | up] and the product runs on silu(gate) * up (SwiGLU in front of
+ * down_proj); residual != NULL [N]: y <- residual + (w x + bias) (the layer's two residual additions).  Roundings to the 16-bit type where
+ * the unfused sequence has them. */
+int rsvld_gemv_fused(const void* w, const void* x, const void* bias, const void* norm_w, float norm_eps, const void* residual, int glu,
+                     void* y, int N, int K, int dtype, void* stream);
+/* One decode step of grouped-query attention over a static cache (LlamaAttention.forward with ONE new token, llava_llama.py:118-137 ->
+ * transformers' Llama decode): qkv [ (n_q + 2 n_kv) x head_dim ] = the new token's q | k | v rows; cos, sin [head_dim] (half-split rotary
+ * embedding, 16-bit); *pos (DEVICE int64: the step is replayed from a hipGraph) = the token's position; kcache / vcache
+ * [n_kv][max_len][head_dim] are UPDATED at *pos; out [n_q x head_dim] = softmax(q K^T scale) V over positions <= *pos.  head_dim = 128,
+ * n_q / n_kv <= 8.  ws: rsvld_llama_decode_attention_ws_bytes(n_q, n_kv, max_len) bytes. */
+size_t rsvld_llama_decode_attention_ws_bytes(int n_q, int n_kv, int max_len);
+int rsvld_llama_decode_attention(const void* qkv, const void* cos, const void* sin, const int64_t* pos, void* kcache, void* vcache, void* out,
+                                 float* ws, int n_q, int n_kv, int head_dim, int max_len, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Split-operand product path (round 4): the producers / consumers of bf16 PLANES around the RSVLD_SPLIT convolutions.

@@ -89,6 +89,9 @@ SIGNATURES = {
     "rsvld_groupnorm_stats_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rsvld_groupnorm_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "rsvld_gemv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rsvld_gemv_fused": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "rsvld_llama_decode_attention_ws_bytes": (_i64, [_i, _i, _i]),
+    "rsvld_llama_decode_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "rsvld_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "rsvld_concat_c_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "rsvld_axpby_f32": (_i, [_vp, _vp, _vp, _i64, _f, _f, _vp]),

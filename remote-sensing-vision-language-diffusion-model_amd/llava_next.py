@@ -319,6 +319,8 @@ class FastDecoder:
         self.v = [torch.zeros(shape, device=self.dev, dtype=self.dt) for _ in self.layers]
         self.cols = torch.arange(self.max_len, device=self.dev)
         self._graph = None
+        self._ws = None
+        self.fused = True        # the decode step through the fused kernels where their conditions hold (``_fused_ok``); False = the torch-op sequence
         self.profile = None      # a dict: generate() fills in device-synchronised seconds of its prefill and its token loop
         # One weight-streaming GEMV for q | k | v and one for gate | up: the three (two) weight matrices of a layer become views
         # of one concatenated tensor (no copy is kept, ``state_dict`` is unchanged), so a decode step launches 4 GEMVs per layer
@@ -377,6 +379,8 @@ class FastDecoder:
         T = embeds.shape[1]
         nq, nkv, hd = self.n_q, self.n_kv, self.hd
         g = nq // nkv
+        if T == 1 and self._fused_ok(embeds):
+            return self._forward_fused(embeds, pos)
         cos, sin = m.rotary_emb(embeds, pos[None])                                 # [1, T, hd]
         cos, sin = cos[0][:, None], sin[0][:, None]                                # [T, 1, hd]
         bias = torch.zeros((T, self.max_len), device=self.dev, dtype=torch.float32)
@@ -401,6 +405,38 @@ class FastDecoder:
             inter = gu.shape[-1] // 2
             h = h + self._lin(torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:], layer.mlp.down_proj.weight)
         return self._lin(self._rms(h[-1:], m.norm), self.model.lm_head.weight, self.model.lm_head.bias)
+
+    def _fused_ok(self, embeds):
+        """The decode step as the library's fused kernels (rsvld_gemv_fused, rsvld_llama_decode_attention): 16-bit tensors on the GPU, head_dim
+        128, at most eight query heads per kv head, unbiased MLP, 16-byte aligned rows."""
+        return (self.fused and embeds.is_cuda and embeds.dtype in (torch.float16, torch.bfloat16) and self.hd == 128
+                and self.n_q % self.n_kv == 0 and self.n_q // self.n_kv <= 8 and embeds.shape[-1] % 8 == 0)
+
+    def _forward_fused(self, embeds, pos):
+        """ONE new token through the decoder in 7 launches per layer instead of ~26: RMSNorm folded into the q|k|v and gate|up products, rotary
+        embedding + cache write + grouped-query attention in one operator, the residual additions in the o_proj / down_proj epilogues, SwiGLU in
+        down_proj's prologue.  Same arithmetic and the same roundings as ``forward`` up to the order of two fp32 sums (the RMSNorm's mean, the
+        softmax over key chunks) and the 16-bit rounding of P, which this path skips."""
+        from . import ops
+        m = self.model.model
+        cos, sin = m.rotary_emb(embeds, pos[None])                                 # [1, 1, hd]
+        cos, sin = cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous()
+        h = embeds.reshape(-1).contiguous()
+        scale = self.hd ** -0.5
+        if self._ws is None:
+            lib = ops.L.load()
+            self._ws = torch.zeros(int(lib.rsvld_llama_decode_attention_ws_bytes(self.n_q, self.n_kv, self.max_len)) // 4, device=self.dev,
+                                   dtype=torch.float32)          # (its first 256 bytes are the operator's tickets: zero once)
+        for i, layer in enumerate(self.layers):
+            n1, n2 = layer.input_layernorm, layer.post_attention_layernorm
+            qkv = ops.gemv_fused(self.wqkv[i], h, self.bqkv[i], norm=(n1.weight, n1.variance_epsilon))
+            o = ops.llama_decode_attention(qkv, cos, sin, pos, self.k[i][0], self.v[i][0], self.n_q, self.n_kv, scale, ws=self._ws)
+            op = layer.self_attn.o_proj
+            h = ops.gemv_fused(op.weight, o, op.bias, residual=h)
+            gu = ops.gemv_fused(self.wgu[i], h, None, norm=(n2.weight, n2.variance_epsilon))
+            h = ops.gemv_fused(layer.mlp.down_proj.weight, gu, None, glu=True, residual=h)
+        head = self.model.lm_head
+        return ops.gemv_fused(head.weight, h, head.bias, norm=(m.norm.weight, m.norm.variance_epsilon))[None]
 
     def _pick(self, logits, do_sample, temperature, top_k=0, top_p=1.0):
         """``generate``'s sampling chain (transformers' TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> multinomial).

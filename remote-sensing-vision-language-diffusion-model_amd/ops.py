@@ -1096,6 +1096,46 @@ def gemv(w, x, bias=None):
     return y
 
 
+def gemv_fused(w, x, bias=None, *, norm=None, residual=None, glu=False):
+    """``gemv`` with the element-wise neighbours of a Llama decode step folded in (rsvld_gemv_fused): ``norm=(weight, eps)``: the product runs
+    on RMSNorm(x) * weight; ``glu``: x holds ``[gate | up]`` (2 K elements) and the product runs on silu(gate) * up; ``residual [N]``: the
+    result is residual + (w x + bias)."""
+    _need_gpu(w, x, bias, residual)
+    N, K = w.shape
+    if x.numel() != (2 * K if glu else K) or w.stride(1) != 1 or w.stride(0) != K or not x.is_contiguous():
+        raise L.RsvldError("gemv_fused: w must be a contiguous [N, K] matrix and x a contiguous row of K (glu: 2 K) elements")
+    nw, eps = (None, 0.0) if norm is None else norm
+    for t in (x, bias, nw, residual):
+        if t is not None and t.dtype != w.dtype:
+            raise L.RsvldError("gemv_fused: every operand shares the weights' 16-bit dtype")
+    if residual is not None and (residual.numel() != N or not residual.is_contiguous()):
+        raise L.RsvldError("gemv_fused: residual must be a contiguous row of N elements")
+    y = torch.empty(N, device=w.device, dtype=w.dtype)
+    lib = L.load()
+    _launch("gemv", 2.0 * N * K, (N * K + K + N) * 2, lambda: L.check(
+        lib.rsvld_gemv_fused(_ptr(w), _ptr(x), _ptr(bias), _ptr(nw), float(eps), _ptr(residual), int(glu), _ptr(y), N, K, _dt(w), _stream()),
+        "rsvld_gemv_fused"))
+    return y
+
+
+def llama_decode_attention(qkv, cos, sin, pos, kcache, vcache, n_q, n_kv, scale, ws=None):
+    """One decode step of grouped-query attention over a static cache (rsvld_llama_decode_attention): ``qkv`` = the new token's q | k | v rows,
+    ``pos`` a DEVICE int64 scalar; the caches ``[n_kv, max_len, 128]`` are updated at ``pos``; ``ws`` (optional, re-usable): a ZEROED fp32
+    tensor of rsvld_llama_decode_attention_ws_bytes.  -> ``[n_q * 128]``."""
+    _need_gpu(qkv, cos, sin, pos, kcache, vcache)
+    hd, max_len = kcache.shape[-1], kcache.shape[-2]
+    if pos.dtype != torch.int64 or not (kcache.is_contiguous() and vcache.is_contiguous() and qkv.is_contiguous()):
+        raise L.RsvldError("llama_decode_attention: contiguous caches / qkv and an int64 position on the device")
+    lib = L.load()
+    if ws is None:
+        ws = torch.zeros(int(lib.rsvld_llama_decode_attention_ws_bytes(n_q, n_kv, max_len)) // 4, device=qkv.device, dtype=torch.float32)
+    out = torch.empty(n_q * hd, device=qkv.device, dtype=qkv.dtype)
+    _launch("llama_decode_attention", 0.0, 0.0, lambda: L.check(
+        lib.rsvld_llama_decode_attention(_ptr(qkv), _ptr(cos), _ptr(sin), _ptr(pos), _ptr(kcache), _ptr(vcache), _ptr(out), _ptr(ws), n_q, n_kv,
+                                         hd, max_len, float(scale), _dt(qkv), _stream()), "rsvld_llama_decode_attention"))
+    return out
+
+
 # ----------------------------------------------------------------------------- small fp32 layers
 def linear_small(x, w, b, act_in=0, act_out=0):
     """fp32 ``[rows, in] -> [rows, out]`` with torch nn.Linear weight layout."""

@@ -127,6 +127,40 @@ def test_llava_next_on_device_vs_reference_golden(cuda, tmp_path, golden_dir, n)
     assert fast.cpu().tolist() == z[f"i{n}.greedy"].tolist() == again.cpu().tolist()
 
 
+def test_fast_decoder_fused_decode_step_equals_the_torch_sequence(cuda):
+    """The token loop's decode step through the fused kernels (rsvld_gemv_fused, rsvld_llama_decode_attention: 7 launches per layer) against
+    the torch-op sequence it replaces (FastDecoder.fused = False), on a seeded Llama of the 8 B decoder's head geometry (head_dim 128, four
+    query heads per kv head) in fp16: the same greedy tokens over 24 steps behind a 300-token prompt -- i.e. across a 256-key chunk boundary --
+    next-token logits within the 16-bit kernels' tolerance, and both replayed from a hipGraph."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from rsvld_amd import llava_next as LN
+    cfg = LlamaConfig(vocab_size=2000, hidden_size=1024, intermediate_size=2048, num_hidden_layers=3, num_attention_heads=8,
+                      num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-5, rope_theta=500000.0, attention_bias=False)
+    torch.manual_seed(11)
+    model = LlamaForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p_ in model.parameters():                    # a spread of magnitudes instead of the uniform init
+            p_.mul_(2.0)
+    model.to(device=cuda, dtype=torch.float16)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, cfg.vocab_size, (1, 300), generator=g).to(cuda)
+    emb = model.model.embed_tokens(ids)
+    outs, logits = {}, {}
+    for fused in (True, False):
+        dec = LN.FastDecoder(model, 400)
+        dec.fused = fused
+        with torch.no_grad():
+            outs[fused] = dec.generate(emb, 24, do_sample=False).cpu().tolist()
+            assert dec._graph is not None
+            logits[fused] = dec._logits.float().cpu()
+        assert (dec._ws is not None) == fused            # the fused operators ran (and only then)
+    d = float((logits[True] - logits[False]).abs().max())
+    rng = float(logits[False].abs().max())
+    print(f"FastDecoder, fused decode step vs the torch sequence: last-step logits max|d| = {d:.3e} (range {rng:.2f})")
+    assert outs[True] == outs[False] and len(outs[True]) == 24
+    assert d < 2e-2 * rng
+
+
 def test_pipeline_with_live_caption_end_to_end(cuda, tmp_path):
     """BASELINE configs[3] in miniature: Stage 1 -> uint8 hand-off -> LIVE LLaVA-NeXT caption (tiny seeded model on the device)
     -> Stage 2 with that caption -> PNG, through SuperResolutionPipeline.process() exactly as the CLI runs it."""

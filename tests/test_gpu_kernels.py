@@ -584,6 +584,62 @@ def test_gemv_weight_streaming(cuda, dtype, shape):
     _close(got, want + b, dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(6144, 4096), (4096, 14336), (1003, 520)])
+def test_gemv_fused_decode_step_neighbours(cuda, dtype, shape):
+    """rsvld_gemv_fused: the RMSNorm prologue, the SwiGLU prologue and the residual epilogue of a Llama decode step, each against the unfused
+    torch sequence on the SAME 16-bit operands (F.rms_norm -> linear; silu(g) * u -> linear; h + linear): equal up to the order of one fp32 sum."""
+    from rsvld_amd import ops
+    N, K = shape
+    g = torch.Generator().manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda, dtype)
+    x = (torch.randn(K, generator=g) * 2).to(cuda, dtype)
+    nw = (torch.randn(K, generator=g) * 0.2 + 1).to(cuda, dtype)
+    res = torch.randn(N, generator=g).to(cuda, dtype)
+    gu = torch.randn(2 * K, generator=g).to(cuda, dtype)
+    lin = lambda v: (w.double() @ v.double()).to(dtype)        # the product's fp32 accumulation, rounded once
+    want_n = lin(F.rms_norm(x, (K,), nw, 1e-5))
+    want_r = (res + lin(x))
+    want_g = (res + lin(F.silu(gu[:K]) * gu[K:]))
+    _close(ops.gemv_fused(w, x, None, norm=(nw, 1e-5)), want_n.float().cpu(), dtype)
+    _close(ops.gemv_fused(w, x, None, residual=res), want_r.float().cpu(), dtype)
+    _close(ops.gemv_fused(w, gu, None, glu=True, residual=res), want_g.float().cpu(), dtype)
+    assert torch.equal(ops.gemv_fused(w, x, None), ops.gemv(w, x))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("pos", [0, 5, 255, 256, 700])
+def test_llama_decode_attention_vs_torch_sequence(cuda, dtype, pos):
+    """rsvld_llama_decode_attention (rotary embedding of the new q / k, cache write at a DEVICE position, grouped-query attention over the
+    filled prefix) against the torch-op sequence of FastDecoder.forward for ONE new token: 8 query heads on 2 kv heads, head_dim 128,
+    positions on both sides of the 256-key chunk boundary."""
+    from rsvld_amd import ops
+    nq, nkv, hd, max_len = 8, 2, 128, 777
+    g = torch.Generator().manual_seed(pos + 1)
+    qkv = torch.randn(nq + 2 * nkv, hd, generator=g).to(cuda, dtype)
+    kc = torch.randn(nkv, max_len, hd, generator=g).to(cuda, dtype)
+    vc = torch.randn(nkv, max_len, hd, generator=g).to(cuda, dtype)
+    ang = torch.rand(hd // 2, generator=g) * 6
+    cos, sin = torch.cat([ang.cos(), ang.cos()]).to(cuda, dtype), torch.cat([ang.sin(), ang.sin()]).to(cuda, dtype)
+    p = torch.tensor([pos], device=cuda)
+    # the unfused sequence (llava_next.FastDecoder.forward, T = 1)
+    k_ref, v_ref = kc.clone(), vc.clone()
+    qk = qkv[:nq + nkv]
+    half = hd // 2
+    qk = qk * cos + torch.cat((-qk[..., half:], qk[..., :half]), dim=-1) * sin
+    k_ref[:, pos] = qk[nq:]
+    v_ref[:, pos] = qkv[nq + nkv:]
+    gq = nq // nkv
+    q = qk[:nq].reshape(nkv, gq, hd)
+    sc = torch.matmul(q, k_ref.transpose(1, 2)).float() * hd ** -0.5
+    sc[..., pos + 1:] = float("-inf")
+    want = torch.matmul(torch.softmax(sc, dim=-1).to(dtype), v_ref).reshape(nq * hd)
+    got = ops.llama_decode_attention(qkv.reshape(-1), cos, sin, p, kc, vc, nq, nkv, hd ** -0.5)
+    assert torch.equal(kc[:, pos], k_ref[:, pos]) and torch.equal(vc[:, pos], v_ref[:, pos])      # the cache rows as the sequence writes them
+    assert torch.equal(kc[:, :pos], k_ref[:, :pos]) and torch.equal(kc[:, pos + 1:], k_ref[:, pos + 1:])
+    _close(got, want.float().cpu(), dtype)
+
+
 def test_small_layers_and_embeddings(cuda):
     from rsvld_amd import ops
     g = torch.Generator().manual_seed(2)
