@@ -9,6 +9,7 @@
 // of 16 rows, ONE per CU with 32 KiB of weight loads in flight where ~64 KiB per CU are needed to keep HBM busy) run with the four waves
 // of a workgroup SPLITTING K for the same GV_RPW rows: four times the workgroups, partial sums through LDS.
 #include "rsvld_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -167,6 +168,19 @@ constexpr int DA_CH = 128, DA_HD = 128, DA_GMAX = 8;   // keys per workgroup: 8 
 constexpr int DA_ROW = DA_HD * 2 + 16;                 // LDS row stride in bytes: four rows read by one wave instruction fall into different banks
 constexpr int DA_PIECES = DA_CH * 16 / 256;            // 16-byte pieces of the K (and of the V) chunk per thread
 
+// sum over the 16 lanes of a DPP row, in every lane: four cross-lane VALU steps (quad swaps, half-row and row mirrors) where
+// __shfl_xor would be four dependent ds_bpermute round trips -- 16 of them per key group and wave made the score phase the kernel's longest
+__device__ __forceinline__ float da_row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1, 0, 3, 2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2, 3, 0, 1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});    // row_mirror
+    return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void da_kernel(const T* __restrict__ qkv, const T* __restrict__ cosv, const T* __restrict__ sinv,
                                                  const long long* __restrict__ pos_p, T* __restrict__ kc, T* __restrict__ vc,
@@ -225,8 +239,7 @@ __global__ __launch_bounds__(256) void da_kernel(const T* __restrict__ qkv, cons
                 float d = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) d = __builtin_fmaf(kf[e], qs[g][l16 * 8 + e], d);
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+                d = da_row16_sum(d);
                 if (l16 == 0) sc[g][j] = j < nkeys ? (float)(T)d * scale : -INFINITY;    // (the unfused path holds the scores in T)
             }
         }
