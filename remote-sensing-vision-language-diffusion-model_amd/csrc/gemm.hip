@@ -96,6 +96,12 @@ constexpr int G_STAGE = 32 * 1024;   // X: 256 rows x 64 B | W: 256 rows x 64 B
                           // pieces between the MFMAs, so that EVERY multiply slot carries two pieces (0: four / two alternating).  An LDS-DMA piece
                           // costs its wave 60-180 issue cycles; 16 MFMAs + four pieces overran the 512 cycles the partner's slot takes.
 #endif
+#ifndef G_RES_AHEAD
+#define G_RES_AHEAD 1     // persistent fp32 + residual epilogue: the residual pieces of this many 32 x 32 half-blocks are in flight ahead of the one being
+                          // stored.  2 and 3 measured (round 5, tools/bench_linear_w2.py, A-B-A-B): no change on any of the four to_out / ff.net.2 shapes
+                          // (157.9 / 157.7 / 157.8 us at 32 768 x 1 280 -> 1 280) -- with fp16 weights these GEMMs move 8 bytes per output element beside
+                          // 2 K FLOP and run at 3.8-4.3 TB/s of HBM traffic: bound by the bytes, not by the latency of the request rounds
+#endif
 #ifndef G_HALF_TILES
 #define G_HALF_TILES 1    // persistent form: the last partial round of an XCD's run as 128-row half tiles (see the tile enumeration); 0 = whole tiles
 #endif
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                 const int rb32 = rrow * 128 + ((rchunk ^ (rrow & 7)) << 4);        // + i * 1024: rows rrow + 8 i (same row & 7)
                 const int ncol = n0e + wn * 64 + 4 * rchunk;                        // + 32 ni
                 const int mrow = m0e + grp * (32 * MI) + rrow;                      // + 32 mi + 8 i
-                f32x4 rvp[2][4];
+                f32x4 rvp[G_RES_AHEAD + 1][4];
                 auto load_res = [&](int hb, f32x4 (&r)[4]) {
                     const int n = ncol + (hb & 1) * 32;
 #pragma unroll
@@ -853,7 +859,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                         r[i] = *(const f32x4*)((const float*)p.residual + (int64_t)min(m, p.M - 1) * p.N_out + (n < p.N_out ? n : 0));
                     }
                 };
-                load_res(0, rvp[0]);
+#pragma unroll
+                for (int a = 0; a < G_RES_AHEAD; ++a) load_res(a, rvp[a]);
 #pragma unroll
                 for (int hb = 0; hb < 2 * MI; ++hb) {
                     const int mi = hb >> 1, ni = hb & 1;
@@ -864,14 +871,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p) {
                         for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e] * p.alpha;
                         *(f32x4*)(P + wb32 + (((2 * g + lh) ^ x7w) << 4)) = v;
                     }
-                    if (hb + 1 < 2 * MI) load_res(hb + 1, rvp[(hb + 1) & 1]);
+                    if (hb + G_RES_AHEAD < 2 * MI) load_res(hb + G_RES_AHEAD, rvp[(hb + G_RES_AHEAD) % (G_RES_AHEAD + 1)]);
                     const int n = ncol + ni * 32;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         f32x4 o = *(const f32x4*)(P + rb32 + i * 1024);
                         const int m = mrow + mi * 32 + 8 * i;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += p.beta * rvp[hb & 1][i][e];
+                        for (int e = 0; e < 4; ++e) o[e] += p.beta * rvp[hb % (G_RES_AHEAD + 1)][i][e];
                         if (m < p.M && n < p.N_out && !((G_ABL & 1) && p.M > 0)) *(f32x4*)((float*)p.out + (int64_t)m * p.N_out + n) = o;
                     }
                 }
