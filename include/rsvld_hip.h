@@ -113,7 +113,8 @@ typedef struct rsvld_conv_desc {
  *     w : fp16 [Cout][KH*KW][ W_lo(Cin+Cin2) | W_hi(Cin+Cin2) ]   W_hi = fp16(W), W_lo = fp16(W - W_hi)   (rsvld_pack_weight_pairs)
  * so that x W = x W_lo + x W_hi is ONE fp16 contraction over 2 (Cin+Cin2) logical channels per tap whose second segment re-reads
  * the activation: two MFMAs per product instead of RSVLD_SPLIT's three, half the activation bytes, and the fused GroupNorm prologue
- * of the halo kernel stays available.  residual: fp32.  out: fp32 when out_f32 = 1, fp16 when out_f32 = 0 (no residual then).
+ * of the halo kernel stays available.  residual: of the OUTPUT's type (fp32 with out_f32 = 1: a split-precision network's residual
+ * stream; fp16 with out_f32 = 0: SR3's compute dtype "w2", fp16 tensors throughout).  out: fp32 when out_f32 = 1, fp16 when out_f32 = 0.
  * RSVLD_SPLIT with out_f32 = 2 writes fp16 as well (q | k | v on their way to the 16-bit attention kernels). */
 /* dtype = RSVLD_F16W1 (round 5; accepted by rsvld_conv2d_nhwc, 1x1 only): a Linear layer of a split-precision transformer block whose policy
  * rounds its WEIGHTS to fp16 as well (SplitPolicy.f16_weights "attn_out" / "ff_out": to_out of sgm/modules/attention.py:288-373, ff.net.2
@@ -375,7 +376,8 @@ int rsvld_gemv_fused(const void* w, const void* x, const void* bias, const void*
  * transformers' Llama decode): qkv [ (n_q + 2 n_kv) x head_dim ] = the new token's q | k | v rows; cos, sin [head_dim] (half-split rotary
  * embedding, 16-bit); *pos (DEVICE int64: the step is replayed from a hipGraph) = the token's position; kcache / vcache
  * [n_kv][max_len][head_dim] are UPDATED at *pos; out [n_q x head_dim] = softmax(q K^T scale) V over positions <= *pos.  head_dim = 128,
- * n_q / n_kv <= 8.  ws: rsvld_llama_decode_attention_ws_bytes(n_q, n_kv, max_len) bytes. */
+ * n_q / n_kv <= 8.  ws: rsvld_llama_decode_attention_ws_bytes(n_q, n_kv, max_len) bytes of scratch (no initial state).  *pos outside
+ * [0, max_len) is clamped into it by the kernel (the host cannot see a device scalar): nothing is written past the cache. */
 size_t rsvld_llama_decode_attention_ws_bytes(int n_q, int n_kv, int max_len);
 int rsvld_llama_decode_attention(const void* qkv, const void* cos, const void* sin, const int64_t* pos, void* kcache, void* vcache, void* out,
                                  float* ws, int n_q, int n_kv, int head_dim, int max_len, float scale, int dtype, void* stream);

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void da_kernel(const T* __restrict__ qkv, cons
     __shared__ float ml[DA_GMAX][2];
     const int kvh = blockIdx.x, c = blockIdx.y, nchunk = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int G = n_q / n_kv, p = (int)*pos_p, half = DA_HD / 2;
+    const int G = n_q / n_kv, p = (int)min(max(*pos_p, 0ll), (long long)max_len - 1), half = DA_HD / 2;   // (a position outside the cache is clamped, never written past it)
     float* out = ws + ((size_t)(kvh * nchunk + c) * G) * (DA_HD + 2);
     const int j0 = c * DA_CH, nkeys = min(DA_CH, p + 1 - j0);
     const bool owner = p >= j0 && p < j0 + DA_CH;
@@ -333,7 +333,7 @@ static int gemv_launch(const void* w, const void* x, const void* bias, const voi
                        int N, int K, int dtype, void* stream) {
     if (!w || !x || !y || N <= 0 || K <= 0) return RSVLD_EINVAL;
     if (dtype != RSVLD_F16 && dtype != RSVLD_BF16) return RSVLD_EINVAL;
-    if (K % 8 != 0 || K > 32768) return RSVLD_EUNSUPPORTED;      // 16-byte pieces; x (<= 64 KiB) in LDS
+    if (K % 8 != 0 || (size_t)K * 2 + 4 * GV_RPW * sizeof(float) + 16 * sizeof(float) > 65536) return RSVLD_EUNSUPPORTED;   // 16-byte pieces; x + scratch within the 64 KiB of dynamic LDS a launch gets without an opt-in
     if (((uintptr_t)w | (uintptr_t)x | (uintptr_t)norm_w) & 15) return RSVLD_EINVAL;
     if (glu && (norm_w != nullptr || (((uintptr_t)x + (uintptr_t)K * 2) & 15))) return RSVLD_EINVAL;
     hipStream_t s = (hipStream_t)stream;

@@ -59,6 +59,12 @@ __global__ __launch_bounds__(256) void merge_planes_kernel(const bf16* __restric
     }
 }
 
+// clamp to the finite fp16 range WITHOUT swallowing NaN: fminf / fmaxf lower to minnum / maxnum, which return the non-NaN operand
+// (fmaxf(NaN, -65504) = -65504), so the clamp is a compare + select on |s| and NaN (all compares false) falls through unchanged
+__device__ __forceinline__ float sat_f16_keep_nan(float s) {
+    return fabsf(s) > 65504.f ? copysignf(65504.f, s) : s;
+}
+
 // planes (rows of lo | hi, the two planes `ps` elements apart, rows `ld` elements apart: a channel slice of a wider planes tensor
 // is fine) -> fp16 [rows][C] (row stride old): the operands of the 16-bit attention kernels in the "split, attention in fp16" mode
 __global__ __launch_bounds__(256) void planes_to_f16_kernel(const bf16* __restrict__ y, f16* __restrict__ o, int64_t items, int C8, int64_t ld,
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void planes_to_f16_kernel(const bf16* __restri
         unpack8<bf16>(*(const u32x4*)(y + row * ld + c), l);
         unpack8<bf16>(*(const u32x4*)(y + row * ld + ps + c), h);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = fminf(fmaxf(h[e] + l[e], -65504.f), 65504.f);   // saturate: a finite fp32 value stays finite (NaN passes)
+        for (int e = 0; e < 8; ++e) h[e] = sat_f16_keep_nan(h[e] + l[e]);   // saturate: a finite fp32 value stays finite, NaN stays NaN
         *(u32x4*)(o + row * old + c) = pack8<f16>(h);
     }
 }
@@ -1107,7 +1113,7 @@ __global__ __launch_bounds__(256) void pack_weight_pairs_kernel(const float* __r
         f16x8 h;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            h[e] = (f16)fminf(fmaxf(f[e], -65504.f), 65504.f);
+            h[e] = (f16)sat_f16_keep_nan(f[e]);
             l[e] = f[e] - (float)h[e];
         }
         f16* d = o + row * (2 * (int64_t)C) + c;

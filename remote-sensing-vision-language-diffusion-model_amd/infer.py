@@ -78,6 +78,8 @@ class PipelineConfig:
 
 
 class SuperResolutionPipeline:
+    _side_stream = None     # ONE second HIP stream for every image's VAE front (the caching allocator keys its free blocks by stream)
+
     def __init__(self, cfg: PipelineConfig):
         self.cfg = cfg
         if cfg.seed >= 0:
@@ -151,7 +153,9 @@ class SuperResolutionPipeline:
         the caption pass -- a weight-streaming token loop that leaves the matrix pipes idle -- instead of after it.  -> a handle for
         ``run_stage3_refinement(..., front=...)``; same kernels and the same random draws as the serial order."""
         lq, h0, w0 = self._stage2_input(sr_image)
-        side = torch.cuda.Stream(device=lq.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=lq.device)
+        side = self._side_stream
         side.wait_stream(torch.cuda.current_stream(lq.device))
         with torch.cuda.stream(side):
             front = self.refinement_model.vae_front(lq, self.cfg.num_samples, restoration_scale=self.cfg.s_stage1)

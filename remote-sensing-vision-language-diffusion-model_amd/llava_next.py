@@ -425,8 +425,8 @@ class FastDecoder:
         scale = self.hd ** -0.5
         if self._ws is None:
             lib = ops.L.load()
-            self._ws = torch.zeros(int(lib.rsvld_llama_decode_attention_ws_bytes(self.n_q, self.n_kv, self.max_len)) // 4, device=self.dev,
-                                   dtype=torch.float32)          # (its first 256 bytes are the operator's tickets: zero once)
+            self._ws = torch.empty(int(lib.rsvld_llama_decode_attention_ws_bytes(self.n_q, self.n_kv, self.max_len)) // 4, device=self.dev,
+                                   dtype=torch.float32)          # (per-chunk partial results: written before they are read, no initial state)
         for i, layer in enumerate(self.layers):
             n1, n2 = layer.input_layernorm, layer.post_attention_layernorm
             qkv = ops.gemv_fused(self.wqkv[i], h, self.bqkv[i], norm=(n1.weight, n1.variance_epsilon))

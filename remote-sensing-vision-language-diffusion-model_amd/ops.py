@@ -418,7 +418,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     if isinstance(x, Planes) or (x.dtype == torch.float32 and _split_fast()):
         return _conv2d_split(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
                              act=act, alpha=alpha, beta=beta, norm=norm, stats=stats, out_planes=out_planes, out_group=out_group,
-                             norm_group=norm_group)
+                             norm_group=norm_group, group=group)
     if x.dtype == torch.float32:
         return _conv2d_f32(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
                            act=act, alpha=alpha, beta=beta, norm=norm)
@@ -484,7 +484,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         gamma, nbeta, groups, eps, silu = norm
         xn = group_norm(x, gamma, nbeta, groups, eps, x2=x2, silu=silu)
         return conv2d(xn, pc, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
-                      out_f32=out_f32, act=act, alpha=alpha, beta=beta, stats=stats, out_planes=out_planes)
+                      out_f32=out_f32, act=act, alpha=alpha, beta=beta, stats=stats, out_planes=out_planes, out_group=out_group, group=group)
     esz = x.element_size()
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
     nbytes = (x.numel() + (0 if x2 is None else x2.numel()) + wt.numel()) * esz + out.numel() * out.element_size() \
@@ -673,7 +673,7 @@ def _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample):
 
 
 def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alpha, beta, norm, stats, out_planes, out_group=None,
-                  norm_group=None):
+                  norm_group=None, group=None):
     """The split-operand product path of conv2d / linear: bf16 planes in (split here when the caller hands fp32), weight triples,
     the 16-bit kernels with dtype RSVLD_SPLIT; fp32 (or Planes, or -- a 1x1 layer whose consumer group takes fp16 -- fp16) out,
     fp32 residual."""
@@ -686,7 +686,7 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
         if f16_group(norm_group):     # the policy hands this convolution's input over in fp16: the weight-pair form (fp32 out, fp32 residual)
             x16 = _gn_apply_split(x, x2, ab, silu, planes=True, f16=True)
             return conv2d(x16, pc, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual, act=act, alpha=alpha,
-                          beta=beta, stats=stats, out_planes=out_planes)
+                          beta=beta, stats=stats, out_planes=out_planes, out_group=out_group, group=group)
         x, x2 = _gn_apply_split(x, x2, ab, silu, planes=True), None
     x = to_planes(x)
     x2 = None if x2 is None else to_planes(x2)
@@ -1120,15 +1120,15 @@ def gemv_fused(w, x, bias=None, *, norm=None, residual=None, glu=False):
 
 def llama_decode_attention(qkv, cos, sin, pos, kcache, vcache, n_q, n_kv, scale, ws=None):
     """One decode step of grouped-query attention over a static cache (rsvld_llama_decode_attention): ``qkv`` = the new token's q | k | v rows,
-    ``pos`` a DEVICE int64 scalar; the caches ``[n_kv, max_len, 128]`` are updated at ``pos``; ``ws`` (optional, re-usable): a ZEROED fp32
-    tensor of rsvld_llama_decode_attention_ws_bytes.  -> ``[n_q * 128]``."""
+    ``pos`` a DEVICE int64 scalar; the caches ``[n_kv, max_len, 128]`` are updated at ``pos``; ``ws`` (optional, re-usable): an fp32
+    tensor of rsvld_llama_decode_attention_ws_bytes (scratch: no initial state).  A position outside ``[0, max_len)`` is clamped by the kernel.  -> ``[n_q * 128]``."""
     _need_gpu(qkv, cos, sin, pos, kcache, vcache)
     hd, max_len = kcache.shape[-1], kcache.shape[-2]
     if pos.dtype != torch.int64 or not (kcache.is_contiguous() and vcache.is_contiguous() and qkv.is_contiguous()):
         raise L.RsvldError("llama_decode_attention: contiguous caches / qkv and an int64 position on the device")
     lib = L.load()
     if ws is None:
-        ws = torch.zeros(int(lib.rsvld_llama_decode_attention_ws_bytes(n_q, n_kv, max_len)) // 4, device=qkv.device, dtype=torch.float32)
+        ws = torch.empty(int(lib.rsvld_llama_decode_attention_ws_bytes(n_q, n_kv, max_len)) // 4, device=qkv.device, dtype=torch.float32)
     out = torch.empty(n_q * hd, device=qkv.device, dtype=qkv.dtype)
     _launch("llama_decode_attention", 0.0, 0.0, lambda: L.check(
         lib.rsvld_llama_decode_attention(_ptr(qkv), _ptr(cos), _ptr(sin), _ptr(pos), _ptr(kcache), _ptr(vcache), _ptr(out), _ptr(ws), n_q, n_kv,

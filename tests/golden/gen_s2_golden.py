@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 import ref_shims
 
-AttrDict = ref_shims.install()
+AttrDict = ref_shims.install(xformers=not getattr(ref_shims, "NO_XFORMERS", False))   # (check_s2_no_xformers.py imports this module without the stand-in)
 
 import numpy as np
 import torch

@@ -20,7 +20,10 @@ def _mod(name, **attrs):
     return m
 
 
-def install():
+def install(xformers=True):
+    """``xformers=False``: no xformers stand-in at all -- ``import xformers`` fails as on a box without the wheel and the reference takes its
+    own torch-SDPA branch (sgm/modules/attention.py:397-402, SR_modules.py:121); tests/golden/check_s2_no_xformers.py uses it to show that
+    the Stage-2 goldens do not depend on the stand-in."""
     import torch
     import torch.nn as nn
     import transformers  # noqa: F401  (must be imported BEFORE the torchvision stub)
@@ -99,8 +102,9 @@ def install():
     def mea(q, k, v, attn_bias=None, op=None):  # [B,N,C] single head
         return torch.nn.functional.scaled_dot_product_attention(q.unsqueeze(1), k.unsqueeze(1), v.unsqueeze(1)).squeeze(1)
 
-    xf = _mod("xformers")
-    xf.ops = _mod("xformers.ops", memory_efficient_attention=mea)
+    if xformers:
+        xf = _mod("xformers")
+        xf.ops = _mod("xformers.ops", memory_efficient_attention=mea)
     df = _mod("diffusers")
     df.utils = _mod("diffusers.utils")
     df.utils.import_utils = _mod("diffusers.utils.import_utils", is_xformers_available=lambda: True)

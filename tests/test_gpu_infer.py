@@ -14,11 +14,12 @@ import s2_common as S
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("prec", ["default", "fp32", "split", "vae_split"])
+@pytest.mark.parametrize("prec", ["default", "fp32", "split", "vae_split", "tolerance"])
 def test_pipeline_cli_flow(cuda, tmp_path, prec):
     """``fp32``: PipelineConfig(ae_dtype / diff_dtype / sr3_dtype = "fp32") = the CLI's --fp32: both stages on the fp32-operand
     kernel family; ``split`` = --split (both stages through the split-operand product path), ``vae_split`` = --vae_split (the VAE
-    passes only); same files, same sizes."""
+    passes only); ``tolerance`` = --tolerance, the composition bench.py times (Stage 1 fp16 x weight pairs, Stage 2 + VAE split);
+    same files, same sizes."""
     from PIL import Image
     from rsvld_amd import infer
     cfg = yaml.safe_load(open(S.YAML.replace("juggernautXL.yaml", "juggernautXL_cached.yaml")))
@@ -38,13 +39,21 @@ def test_pipeline_cli_flow(cuda, tmp_path, prec):
                               allow_random_init=True, no_llava=True,
                               upscale_factor=2, min_size=128, edm_steps=3, sr3_steps=3, seed=1, img_threshold=0.3,
                               **(dict(ae_dtype=prec, diff_dtype=prec, sr3_dtype=prec) if prec in ("fp32", "split") else
+                                 dict(ae_dtype="split", diff_dtype="split", sr3_dtype="w2") if prec == "tolerance" else
                                  dict(ae_dtype="split") if prec == "vae_split" else {}))
     pipe = infer.SuperResolutionPipeline(pc)
     want_dt = torch.float32 if prec in ("fp32", "split") else torch.float16
-    assert pipe.sr3_model.netG.denoise_fn.compute_dtype == want_dt and pipe.refinement_model.model.dtype == want_dt
+    unet1 = pipe.sr3_model.netG.denoise_fn
+    assert unet1.compute_dtype == want_dt
+    assert unet1.pack_dtype == (torch.float32 if prec == "tolerance" else want_dt)        # w2: fp16 tensors, weights packed as pairs from fp32
+    assert pipe.refinement_model.model.dtype == (torch.float32 if prec == "tolerance" else want_dt)
     assert pipe.refinement_model.first_stage_model.compute_dtype == (torch.bfloat16 if prec == "default" else torch.float32)
-    assert (pipe.sr3_model.netG.denoise_fn.split is not None) == (prec == "split") and (pipe.refinement_model.model.split is not None) == (prec == "split")
-    assert (pipe.refinement_model.first_stage_model.split is not None) == (prec in ("split", "vae_split"))
+    assert (unet1.split is not None) == (prec == "split")
+    assert (pipe.refinement_model.model.split is not None) == (prec in ("split", "tolerance"))
+    assert (pipe.refinement_model.first_stage_model.split is not None) == (prec in ("split", "vae_split", "tolerance"))
+    if prec == "tolerance":     # what main(["--tolerance"]) builds is this composition
+        from rsvld_amd import ops
+        assert pipe.refinement_model.precision_key() == ("split", "split", ops.VAE_POLICY.key(), ops.UNET_POLICY.key())
     # zero-initialised output convs would make Stage 2 a no-op: give them small seeded weights
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():

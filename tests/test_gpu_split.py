@@ -386,6 +386,33 @@ def test_attention_split_mode_f16_composition(cuda, B, heads, Nq, Nk, D, shared)
     assert torch.equal(back.f32().cpu(), x16.float())
 
 
+def test_planes_to_f16_saturates_finite_and_keeps_nan(cuda):
+    """The fp16 hand-over of the split precision saturates finite values at +-65504 and must NOT turn NaN into a finite number
+    (fminf / fmaxf are minnum / maxnum on this target: fmaxf(NaN, -65504) = -65504 -- the clamp is a compare + select): a NaN operand
+    has to reach the attention output as NaN so that the isfinite() guards of the tests and of bench.py can see it.  Same for the
+    weight-pair packer's hi half."""
+    from rsvld_amd import ops
+    x = torch.zeros(1, 64, 64)
+    x[0, 0, :8] = torch.tensor([1.0, 1e6, -1e6, float("inf"), float("-inf"), float("nan"), 65504.0, -70000.0])
+    h = ops._planes_to_f16(ops.to_planes(x.to(cuda))).float().cpu()[0, 0, :8]
+    assert h[:3].tolist() == [1.0, 65504.0, -65504.0] and h[6:].tolist() == [65504.0, -65504.0]
+    # (an infinity has no planes form: lo = bf16(inf - inf) = NaN, so it arrives as NaN -- non-finite either way, never a finite number)
+    assert not bool(torch.isfinite(h[3:6]).any()) and bool(torch.isnan(h[5])), f"non-finite inputs became {h[3:6].tolist()}"
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(1, 256, 64, generator=g) for _ in range(3))
+    k[0, 17, 3] = float("nan")                                     # one poisoned key: every query row's softmax sees it
+    with ops.f32_split(ops.UNET_POLICY):
+        out = ops.attention(ops.to_planes(q.to(cuda)), ops.to_planes(k.to(cuda)), ops.to_planes(v.to(cuda)), heads=1, scale=0.125)
+    assert bool(torch.isnan(out.float()).any()), "a NaN key vanished on the way through the fp16 hand-over"
+    w = torch.randn(16, 64, generator=g)
+    w[3, 5], w[4, 6] = float("nan"), 1e6
+    pc = ops.pack_conv(w, None, torch.float32, cuda)
+    with ops.f32_split(PAIRS_ONLY()):
+        y = ops.linear(torch.ones(8, 64, device=cuda, dtype=torch.float16), pc)
+    y = y.float().cpu()
+    assert bool(torch.isnan(y[:, 3]).all()) and bool(torch.isfinite(y[:, [0, 1, 2, 5]]).all())
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Round 5: the weight-pair form (dtype RSVLD_F16W2: fp16 activation x fp16 [W_lo | W_hi], two MFMAs per product) and the fp16 hand-over
 # of the split kernels.  Reference = fp64 on the host over the SAME fp16-rounded activation (the rounding of the input is the policy's

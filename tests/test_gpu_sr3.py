@@ -118,12 +118,13 @@ def test_p_sample_vs_reference_golden(sr3, cuda, golden_dir, t):
     assert e < 3e-4
 
 
-@pytest.mark.parametrize("prec", ["fp16", "fp32", "split"])
+@pytest.mark.parametrize("prec", ["fp16", "fp32", "split", "w2"])
 def test_pipeline_config1_vs_reference_golden(sr3, cuda, golden_dir, prec):
     """BASELINE config 1: 64 -> 256 (x4), 1 image, 10 DDPM steps, torch seed 0, CPU noise order.
     The reference hands Stage 1's result to Stage 2 as uint8 (utils/tensor2img.py); report both the
     fp32 per-pixel error and the 8-bit agreement.  fp16 = the default 16-bit kernels; fp32 = ``compute_dtype: fp32``, the
-    fp32-operand kernel family (the reference's own Stage 1 runs in fp32)."""
+    fp32-operand kernel family (the reference's own Stage 1 runs in fp32); w2 = fp16 tensors x fp16 weight pairs, the Stage-1
+    precision of the benchmarked (tolerance) composition: north_star's 1e-3 is its bound."""
     net, _ = sr3
     net.denoise_fn.set_compute_dtype(prec)
     try:
@@ -151,13 +152,16 @@ def _pipeline_config1(net, cuda, golden_dir, prec):
     if prec == "fp32":
         assert float(d.max()) < 5e-5 and float(d.mean()) < 5e-6 and float((lsb == 0).mean()) >= 0.9995 and int(lsb.max()) <= 1
         return
+    if prec == "w2":     # the benchmarked Stage-1 dtype: the bound is north_star's own (|d| < 1e-3 per pixel)
+        assert float(d.max()) < 1e-3 and float(d.mean()) < 1e-4 and float((lsb == 0).mean()) >= 0.99 and int(lsb.max()) <= 1
+        return
     # fp16 operands sit AT north_star's 1e-3 after 10 steps (8.3e-4 .. 9.9e-4 across boxes), not inside it with margin: the mode
     # that holds the criterion with margin is compute_dtype fp32 above (9.5e-7).  Bound = 1.5 x measured.
     assert float(d.max()) < 1.5e-3 and float(d.mean()) < 2e-4
     assert float((lsb == 0).mean()) >= 0.98 and int(lsb.max()) <= 1
 
 
-@pytest.mark.parametrize("prec", ["fp16", "fp32", "split"])
+@pytest.mark.parametrize("prec", ["fp16", "fp32", "split", "w2"])
 def test_pipeline_t50_vs_reference_golden(sr3, cuda, golden_dir, prec):
     """The step count the metric is quoted on: the config-1 image through T = 50 ancestral steps (torch seed 0, CPU noise
     order) against the reference's own 50-step run (tests/golden/gen_steps50_golden.py): the final frame, the 11 kept
@@ -199,6 +203,9 @@ def test_pipeline_t50_vs_reference_golden(sr3, cuda, golden_dir, prec):
         return
     if prec == "split":
         assert float(d.max()) < 3e-4 and float(d.mean()) < 3e-5 and int(lsb.max()) <= 1
+        return
+    if prec == "w2":     # the benchmarked Stage-1 dtype at the metric's step count: north_star's 1e-3 (bench.py measured 5.9e-4 / 5.5e-5)
+        assert float(d.max()) < 1e-3 and float(d.mean()) < 1.1e-4 and int(lsb.max()) <= 1
         return
     assert float(d.max()) < S1_T50_MAX and float(d.mean()) < S1_T50_MEAN and int(lsb.max()) <= S1_T50_LSB
     assert float((lsb == 0).mean()) >= 0.95
