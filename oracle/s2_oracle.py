@@ -311,15 +311,17 @@ def sliding_windows(h, w, tile_size, tile_stride):  # :850-863
 
 
 def gaussian_weights(tile_width, tile_height):  # :830-847 -> float64 [tile_height, tile_width] (the reference tiles it to [nb,4,h,w])
-    import math
+    # numpy's SCALAR exp / sqrt, one element at a time, as the reference evaluates them (math.exp differs from it in the last bit for some
+    # arguments: found by the bit-exact pin against the reference's own plane, tests/golden/tiled_sampler_mask.npz)
+    import numpy as np
     var = 0.01
     midpoint = (tile_width - 1) / 2
-    x_probs = [math.exp(-(x - midpoint) * (x - midpoint) / (tile_width * tile_width) / (2 * var)) / math.sqrt(2 * math.pi * var)
+    x_probs = [np.exp(-(x - midpoint) * (x - midpoint) / (tile_width * tile_width) / (2 * var)) / np.sqrt(2 * np.pi * var)
                for x in range(tile_width)]
     midpoint = tile_height / 2          # sic: no "- 1" for the rows
-    y_probs = [math.exp(-(y - midpoint) * (y - midpoint) / (tile_height * tile_height) / (2 * var)) / math.sqrt(2 * math.pi * var)
+    y_probs = [np.exp(-(y - midpoint) * (y - midpoint) / (tile_height * tile_height) / (2 * var)) / np.sqrt(2 * np.pi * var)
                for y in range(tile_height)]
-    return torch.tensor(y_probs, dtype=torch.float64)[:, None] * torch.tensor(x_probs, dtype=torch.float64)[None, :]
+    return torch.tensor(np.outer(y_probs, x_probs))
 
 
 def tiled_restore_edm(sd, table, x, sigmas, c, uc, x_center, opt, randn, tile_size, tile_stride):

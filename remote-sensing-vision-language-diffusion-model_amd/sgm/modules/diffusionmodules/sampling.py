@@ -177,13 +177,13 @@ class RestoreEDMSampler(BaseDiffusionSampler):
 def gaussian_weights(tile_width, tile_height, nbatches, device=None):
     """sampling.py:830-847 -> float64 ``[nbatches, 4, tile_height, tile_width]``.  var = 0.01; note the reference's
     asymmetry: the x midpoint is (w-1)/2, the y midpoint h/2."""
-    var = 0.01
+    var, norm = 0.01, np.sqrt(2 * np.pi * 0.01)
     mx, my = (tile_width - 1) / 2, tile_height / 2
-    xs = np.arange(tile_width, dtype=np.float64)
-    ys = np.arange(tile_height, dtype=np.float64)
-    x_probs = np.exp(-(xs - mx) * (xs - mx) / (tile_width * tile_width) / (2 * var)) / np.sqrt(2 * np.pi * var)
-    y_probs = np.exp(-(ys - my) * (ys - my) / (tile_height * tile_height) / (2 * var)) / np.sqrt(2 * np.pi * var)
-    w = torch.tensor(np.outer(y_probs, x_probs), device=device)
+
+    def bell(n, mid):      # element by element through numpy's SCALAR exp: the array form differs from it in the last bit of some entries,
+        return [np.exp(-(i - mid) * (i - mid) / (n * n) / (2 * var)) / norm for i in range(n)]   # and the reference's plane is pinned bit for bit
+
+    w = torch.tensor(np.outer(bell(tile_height, my), bell(tile_width, mx)), device=device)
     return torch.tile(w, (nbatches, 4, 1, 1))
 
 

@@ -218,8 +218,9 @@ def test_create_sr_model_loads_both_checkpoints_in_reference_order(model, tmp_pa
 
 
 def test_tiled_sampler_windows_and_weights(golden_dir):
-    """sampling.py:830-863: window lists against the reference's own `_sliding_windows` (golden), the Gaussian tile mask
-    of the product against the line-by-line restatement (the reference builds it on device='cuda': not runnable here)."""
+    """sampling.py:830-863: window lists against the reference's own `_sliding_windows` (golden); the Gaussian tile mask of the
+    product AND of the oracle bit for bit against the plane the reference's own `gaussian_weights` returned
+    (tests/golden/tiled_sampler_mask.npz, float64; gen_tiled_golden.py calls it with only the device keyword dropped)."""
     from rsvld_amd.sgm.modules.diffusionmodules.sampling import _sliding_windows, gaussian_weights
     for case in json.load(open(os.path.join(golden_dir, "tiled_sampler_windows.json"))):
         want = [tuple(t) for t in case["windows"]]
@@ -231,11 +232,15 @@ def test_tiled_sampler_windows_and_weights(golden_dir):
             assert he - hi == ts and we - wi == ts and 0 <= hi and he <= h and 0 <= wi and we <= w
             cover[hi:he, wi:we] += 1
         assert float(cover.min()) >= 1          # every latent pixel is inside some tile
+    masks = np.load(os.path.join(golden_dir, "tiled_sampler_mask.npz"))
     for tw, th in ((16, 16), (128, 128), (9, 16)):
         got = gaussian_weights(tw, th, 2)
         want = O.gaussian_weights(tw, th)
+        ref = torch.tensor(masks[f"mask_{tw}x{th}"])
+        assert ref.dtype == torch.float64 and ref.shape == (th, tw)
         assert got.dtype == torch.float64 and got.shape == (2, 4, th, tw)
-        assert torch.allclose(got[1, 3], want, rtol=1e-14, atol=0)
+        assert torch.equal(want, ref), f"oracle mask {tw}x{th}: max|d| = {float((want - ref).abs().max()):.3e}"
+        assert torch.equal(got[1, 3].cpu(), ref), f"product mask {tw}x{th}: max|d| = {float((got[1, 3].cpu() - ref).abs().max()):.3e}"
         assert torch.equal(got[0, 0], got[1, 2])
         assert torch.allclose(want[:, 0], want[:, -1], rtol=1e-14)        # columns: symmetric about (w-1)/2
         assert torch.allclose(want[1], want[-1], rtol=1e-14)              # rows: about h/2 (the reference's asymmetry)
