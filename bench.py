@@ -89,6 +89,7 @@ def stage1_input(image_ids, lr_side, scale):
 PRECISIONS = {"tolerance": ("w2", "split", "split"), "reference-gpu": ("fp16", "bf16", "fp16"), "default": ("fp16", "bf16", "fp16"),
               "split": ("split", "split", "split"), "fp32": ("fp32", "fp32", "fp32"), "vae-split": ("fp16", "split", "fp16")}
 PRECISION = "default"     # --precision (module default = what importing tests get: the reference's GPU policy)
+UNET_POLICY = None        # --unet-f16-groups / --unet-f16-weights (experiments): the ops.SplitPolicy handed to set_precision (None = its default)
 
 
 def apply_precision(net, m, name):
@@ -97,7 +98,7 @@ def apply_precision(net, m, name):
     if net is not None:
         net.denoise_fn.set_compute_dtype(s1)
     if m is not None:
-        m.set_precision(ae, df)
+        m.set_precision(ae, df, policy=UNET_POLICY if df == "split" else None)
 
 
 def precision_report(net, m):
@@ -270,6 +271,17 @@ def dist_max(vals, dev, world):
     t = torch.tensor(vals, device="cpu" if on_host else dev, dtype=torch.float64)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     return [float(v) for v in t.tolist()]
+
+
+def dist_gather_rows(vals, dev, world):
+    """Every rank's row of figures on every rank (one small all-gather outside the timed region) -> [world][len(vals)]."""
+    if world == 1:
+        return [[float(v) for v in vals]]
+    on_host = torch.distributed.get_backend() == "gloo"
+    t = torch.tensor(vals, device="cpu" if on_host else dev, dtype=torch.float64)
+    out = torch.empty((world, len(vals)), device=t.device, dtype=torch.float64)
+    torch.distributed.all_gather_into_tensor(out, t)
+    return [[float(v) for v in row] for row in out.tolist()]
 
 
 def barrier(world):
@@ -578,6 +590,8 @@ def bench_headline(args, dev, rank, world):
     a = ph.acc
     s1_loop, s2_loop = a["s1_loop"], a["edm_sampler_loop"]
     fixed = sum(v for k, v in a.items() if k not in ("s1_loop", "edm_sampler_loop"))
+    per_rank = dist_gather_rows([s1_loop / K * 1e3 / (T if full else 1), s2_loop / K * 1e3 / (T if full else 1), fixed * 1e3 / (K if full else 1),
+                                 a.get("caption", 0.0) * 1e3 / (K if full else 1), a.get("handoff", 0.0) * 1e3 / (K if full else 1)], dev, world)
     dt, s1_loop, s2_loop, fixed = dist_max([dt, s1_loop, s2_loop, fixed], dev, world)
     if full:
         value = world * BPG * K / dt
@@ -678,7 +692,7 @@ def bench_headline(args, dev, rank, world):
         tolerance = guarded(run_tolerance)
 
     # ---- beside it: the reference's own GPU policy (fp16 UNets under autocast, bf16 VAE -- what rounds 1-4 quoted as `value`), timed at
-    # the same shapes in the same process over 3 iterations per stage, with ITS distance from the reference's CPU path
+    # the same shapes in the same process over 2 iterations per stage, with ITS distance from the reference's CPU path
     ref_gpu = None
     if extras and headline_prec == "tolerance":
         def run_ref_gpu():
@@ -687,20 +701,41 @@ def bench_headline(args, dev, rank, world):
             try:
                 one_image(rank, cond, 1, Phases(), gather=False)       # packs the 16-bit weights (one time)
                 pht = Phases()
-                one_image(rank, cond, 3, pht, gather=False)
+                one_image(rank, cond, 2, pht, gather=False)
                 ta = pht.acc
                 tfx = sum(v for k, v in ta.items() if k not in ("s1_loop", "edm_sampler_loop"))
-                t1, t2 = ta["s1_loop"] / 3, ta["edm_sampler_loop"] / 3
+                t1, t2 = ta["s1_loop"] / 2, ta["edm_sampler_loop"] / 2
                 s1, ae, df = PRECISIONS["reference-gpu"]
                 return {"dtype": "f16 (UNets, fp32 accumulate), bf16 (VAE): SR_model.py:28-33, wrappers.py:90",
                         "t_s1_iter_ms": round(t1 * 1e3, 1), "t_s2_iter_ms": round(t2 * 1e3, 1), "t_fixed_ms": round(tfx * 1e3, 1),
                         "seconds_per_image": round(T * t1 + T * t2 + tfx, 2), "img_per_s": round(1.0 / (T * t1 + T * t2 + tfx), 6),
-                        "iterations_timed_per_stage": 3,
+                        "iterations_timed_per_stage": 2,
                         "headline_time_over_this": round((T * it1 + T * it2 + fx) / (T * t1 + T * t2 + tfx), 3),
                         "max_abs_err_50_steps": TC.errors_after_50_steps(dev, s1, ae, df)}
             finally:
                 apply_precision(net, m, headline_prec)
         ref_gpu = guarded(run_ref_gpu)
+
+    # ---- an EXECUTED image beside the projection: all 50 + 50 iterations of this unit, warm, after everything else of the line was
+    # measured (models/SR_model.py:265-296 and sr3_modules/diffusion.py:177-201 run to the end; the same unit, seeds and shapes as `value`)
+    whole = None
+    if extras and not args.no_whole_image:
+        def run_whole():
+            phw = Phases()
+            barrier(world)
+            tw = time.perf_counter()
+            res = one_image(rank, cond, None, phw, gather=False)
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - tw
+            aw = phw.acc
+            proj = T * it1 + T * it2 + fx
+            return {"seconds": round(secs, 2), "projected_seconds": round(proj, 2), "executed_over_projected": round(secs / proj, 4),
+                    "s1_loop_s": round(aw["s1_loop"], 2), "s2_loop_s": round(aw["edm_sampler_loop"], 2),
+                    "fixed_s": round(sum(v for k, v in aw.items() if k not in ("s1_loop", "edm_sampler_loop")), 2),
+                    "iterations_executed": [T, T], "finite": bool(torch.isfinite(res.float()).all()),
+                    "what": f"one whole unit ({BPG} image) executed warm in this process after the timed region: Stage 1 all {T} ancestral steps, "
+                            f"hand-off, caption, Stage 2 all {T} EDM steps (feature cache as in `value`), tiled VAE, colour fix, uint8"}
+        whole = guarded(run_whole)
 
     line = None
     if rank == 0:
@@ -747,6 +782,9 @@ def bench_headline(args, dev, rank, world):
                 "caption_new_tokens": getattr(captioner, "last_tokens", None) if live else None,
                 "caption_breakdown": getattr(captioner, "breakdown", None) if live else None,
                 "seconds_per_image": round((T * it1 + T * it2 + fx) / BPG, 2),
+                "whole_image_executed_s": None if not isinstance(whole, dict) else whole.get("seconds"), "whole_image_executed": whole,
+                "per_rank_ms": [{"rank": r, "first_image": r * BPG, "t_s1_iter": round(row[0], 1), "t_s2_iter": round(row[1], 1), "t_fixed": round(row[2], 1),
+                                 "caption": round(row[3], 1), "handoff": round(row[4], 1)} for r, row in enumerate(per_rank)],
                 "phases_ms": {k: round(v * 1e3, 1) for k, v in a.items()},
                 "timed_region_s": round(dt, 2), "model_build_s": round(build_s, 1), "finite": finite,
                 "algorithmic_tflops_whole_image": round(tf_img * BPG / (T * it1 + T * it2 + fx), 1),
@@ -951,6 +989,7 @@ def main():
     ap.add_argument("--tile-vae", action="store_true", help="s2: VAEHook tiling (needed from 2048x2048 up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="c4: skip the cache-on pass, the 50-step tolerance check and the reference-GPU-policy pass")
+    ap.add_argument("--no-whole-image", action="store_true", help="c4: skip the executed whole image (all 50 + 50 iterations, ~76 s) printed beside the projection")
     ap.add_argument("--cached-cond", action="store_true", help="c4 / c4full: cached text embeddings (PreparedConditioner) and no "
                                                                 "caption pass, as rounds 1-2 measured (default: live LLaVA-NeXT "
                                                                 "caption + live text towers, BASELINE configs[3])")
@@ -995,11 +1034,12 @@ def main():
     if args.dev_env:
         devtools.apply_env()
     if args.profile_detail:
-        ops.PROFILE_DETAIL = True
-    if args.unet_f16_groups is not None or args.unet_f16_weights is not None:     # (the default policy object is what set_precision takes when none is passed)
+        ops.set_defaults(profile_detail=True)
+    if args.unet_f16_groups is not None or args.unet_f16_weights is not None:     # an explicit policy ARGUMENT of set_precision (apply_precision)
+        global UNET_POLICY
         gi = ops.UNET_POLICY.f16_inputs if args.unet_f16_groups is None else tuple(g for g in args.unet_f16_groups.split(",") if g)
         gw = None if args.unet_f16_weights is None else tuple(g for g in args.unet_f16_weights.split(",") if g)
-        ops.UNET_POLICY = ops.SplitPolicy(f16_inputs=tuple(gi), f16_weights=gw)
+        UNET_POLICY = ops.SplitPolicy(f16_inputs=tuple(gi), f16_weights=gw)
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

@@ -11,6 +11,7 @@ dispatch on the tensor's dtype (the VAE under ``ae_dtype: fp32``, the UNet / Con
 """
 import contextlib
 import ctypes as C
+import contextvars
 import math
 
 import torch
@@ -45,21 +46,82 @@ def pad8(c):
     return (c + 7) // 8 * 8
 
 
-# ----------------------------------------------------------------------------- launch plans
-# Batch-invariant plans (include/rsvld_hip.h, conventions): inside ``with plan_units(n)`` every launch is planned --
-# kernel family, tile shape, split-K / split-KV -- for ONE of the ``n`` independent work units (images) stacked along its
-# batch, so an image's result is bit-identical however many images share the launch.  Default 1 = plan on the whole call.
-_PLAN_DIV = 1
+# ----------------------------------------------------------------------------- launch context
+# Everything a launch reads BESIDES its arguments lives in ONE immutable ``LaunchContext`` held in a ``contextvars.ContextVar``:
+# the launch-plan divisor, the precision policy of the network that is running, the developer A/B overrides and the profiler.
+# The context managers below (``plan_units``, ``f32_split``, ``tuning``) install a modified COPY for the duration of a ``with``
+# block and restore the previous object on exit; nothing in this module is a mutable global.  A ContextVar is per thread (and per
+# asyncio task): two threads driving two HIP streams can run two precisions at once; nested blocks on one thread compose.
+class LaunchContext:
+    """``plan_div``  batch-invariant plans (include/rsvld_hip.h, conventions): every launch is planned -- kernel family, tile shape,
+                  split-K / split-KV -- for ONE of ``plan_div`` independent work units (images) stacked along its batch, so an
+                  image's result is bit-identical however many images share the launch.  1 = plan on the whole call.
+    ``policy``    the ``SplitPolicy`` of the split-precision network whose forward is running (None: not in one).
+    ``tune``      developer A/B overrides -> rsvld_conv_desc.tune (every combination computes the same function); 0 = the library's choice.
+    ``use_halo`` / ``halo_min_wgs`` / ``split_halo_min_wgs``   routing of eligible 3x3 convolutions through conv_halo.hip (below).
+    ``split_d512_fused_min`` / ``split_attn_s_bytes``          form of the split-precision d != 64 attention (below).
+    ``d64_kernel``                                             developer A/B of the d = 64 attention's three bit-identical forms.
+    ``profiler`` / ``profile_detail``   per-launch HIP-event bracketing (``LaunchProfiler``) and layer shapes in its group names."""
+
+    __slots__ = ("plan_div", "policy", "tune", "use_halo", "halo_min_wgs", "split_halo_min_wgs", "split_d512_fused_min",
+                 "split_attn_s_bytes", "profiler", "profile_detail", "d64_kernel")
+
+    def __init__(self, plan_div=1, policy=None, tune=0, use_halo=True, halo_min_wgs=256, split_halo_min_wgs=64,
+                 split_d512_fused_min=2048, split_attn_s_bytes=32 << 30, profiler=None, profile_detail=False, d64_kernel=0):
+        # d64_kernel: developer A/B (devtools.d64_kernel): 1 / 2 / 3 = force attn_d64b / attn_d64c / attn_d64p (bit-identical forms)
+        # use_halo: route eligible 3x3 convs through conv_halo.hip (False: A/B against the gather kernel)
+        # halo_min_wgs 256: below one workgroup per CU the 8x32-pixel halo tile under-fills the chip (measured 130 vs 334 TFLOP/s on
+        #   32x32 maps): such layers use the 64x128 gather kernel with the 3-stage ring
+        # split_halo_min_wgs 64: the split precision's gather kernel runs at 190-200 effective TFLOP/s where the halo kernel does
+        #   385-400, and the small maps of this precision are the tiles of the tiled VAE, stacked 7-49 per launch (86 x 86 x 512:
+        #   132 workgroups per planning unit, 72 x 72: 108, 86 x 64: 88): the halo tile from a quarter of a chip per unit
+        # split_d512_fused_min 2048: query rows from which the fused split d = 512 kernel runs (64 per workgroup)
+        # split_attn_s_bytes 32 GiB: fp32 score block of the GEMM form (P planes: as much again)
+        object.__setattr__(self, "plan_div", max(1, int(plan_div)))
+        for k, v in (("policy", policy), ("tune", int(tune)), ("use_halo", bool(use_halo)), ("halo_min_wgs", int(halo_min_wgs)),
+                     ("split_halo_min_wgs", int(split_halo_min_wgs)), ("split_d512_fused_min", int(split_d512_fused_min)),
+                     ("split_attn_s_bytes", int(split_attn_s_bytes)), ("profiler", profiler), ("profile_detail", bool(profile_detail)),
+                     ("d64_kernel", int(d64_kernel))):
+            object.__setattr__(self, k, v)
+
+    def __setattr__(self, k, v):
+        raise AttributeError("LaunchContext is immutable: use ops.tuning(...) / ops.plan_units(n) / ops.f32_split(policy) around the calls")
+
+    def replace(self, **changes):
+        kw = {k: getattr(self, k) for k in self.__slots__}
+        bad = [k for k in changes if k not in kw]
+        if bad:
+            raise TypeError(f"LaunchContext has no field {bad}")
+        kw.update(changes)
+        return LaunchContext(**kw)
+
+
+_CTX = contextvars.ContextVar("rsvld_launch_context", default=LaunchContext())
+
+
+def context():
+    """The LaunchContext the next launch of this thread will read."""
+    return _CTX.get()
 
 
 @contextlib.contextmanager
-def plan_units(n):
-    global _PLAN_DIV
-    old, _PLAN_DIV = _PLAN_DIV, max(1, int(n))
+def tuning(**changes):
+    """``with ops.tuning(use_halo=False, halo_min_wgs=0, tune=..., profiler=...):`` -- a modified copy of the current context for the block."""
+    token = _CTX.set(_CTX.get().replace(**changes))
     try:
-        yield
+        yield _CTX.get()
     finally:
-        _PLAN_DIV = old
+        _CTX.reset(token)
+
+
+def set_defaults(**changes):
+    """Process start-up only (rsvld_amd.devtools.apply_env, bench.py's flags): change this thread's BASE context for good."""
+    _CTX.set(_CTX.get().replace(**changes))
+
+
+def plan_units(n):
+    """Inside ``with plan_units(n)`` every launch is planned for ONE of the ``n`` independent work units stacked along its batch."""
+    return tuning(plan_div=max(1, int(n)))
 
 
 # ----------------------------------------------------------------------------- split-operand precision mode
@@ -151,37 +213,33 @@ ALL_SPLIT = SplitPolicy(f16_inputs=(), f16_weights=())                        # 
 VAE_POLICY = ALL_SPLIT                                        # the VAE (its single-head attentions are a third of the Stage-2 distance in fp16)
 
 # Inside ``with f32_split(policy)`` the matrix products of fp32 tensors run in the split precision under that policy
-# (``True`` = UNET_POLICY, ``False`` / ``None`` = off).  Set by the owning network around its forward.
-_POLICY = None
-_F32_SPLIT = False
-
-
-@contextlib.contextmanager
+# (``True`` = UNET_POLICY, ``False`` / ``None`` = off).  Entered by the owning network around its forward.
 def f32_split(on):
-    global _POLICY, _F32_SPLIT
-    old = _POLICY
-    _POLICY = UNET_POLICY if on is True else (on if isinstance(on, SplitPolicy) else None)
-    _F32_SPLIT = _POLICY is not None
-    try:
-        yield
-    finally:
-        _POLICY = old
-        _F32_SPLIT = _POLICY is not None
+    return tuning(policy=UNET_POLICY if on is True else (on if isinstance(on, SplitPolicy) else None))
+
+
+def _policy():
+    return _CTX.get().policy
 
 
 def _split_fast():
-    return _POLICY is not None and _POLICY.impl == "planes"
+    pol = _CTX.get().policy
+    return pol is not None and pol.impl == "planes"
 
 
 def precision_token():
     """Hashable name of the precision the current call runs in (None outside a split-precision network): cached intermediate tensors
     (the text context's K | V) are keyed on it."""
-    return None if _POLICY is None else _POLICY.key()
+    pol = _CTX.get().policy
+    return None if pol is None else pol.key()
 
 
 def f16_group(group):
     """Does the current policy hand the inputs of layer group ``group`` over as fp16?"""
-    return group is not None and _split_fast() and group in _POLICY.f16_inputs
+    if group is None:
+        return False
+    pol = _CTX.get().policy
+    return pol is not None and pol.impl == "planes" and group in pol.f16_inputs
 
 
 class Planes:
@@ -280,11 +338,6 @@ def maybe_planes(x):
     return x
 
 
-# Developer A/B overrides -> rsvld_conv_desc.tune (every combination computes the same function).  0 = the library's own choice.
-# Set by the tools layer (rsvld_amd.devtools.apply_env); neither this module nor the C ABI reads the environment.
-TUNE = 0
-
-
 # ----------------------------------------------------------------------------- launch profiling
 class LaunchProfiler:
     """Brackets every C-ABI launch with HIP events on the launch stream (torch's current stream is
@@ -313,19 +366,16 @@ class LaunchProfiler:
         return agg
 
 
-_PROFILER = None
-PROFILE_DETAIL = False   # tools (devtools.apply_env / bench.py --profile-detail): append the layer shape to the profiler group name
-
-
 def set_profiler(p):
-    global _PROFILER
-    _PROFILER = p
+    """Bracket every launch of this thread from now on (``None``: stop).  Scoped form: ``with ops.tuning(profiler=p):``."""
+    set_defaults(profiler=p)
 
 
 def _launch(name, flops, nbytes, fn):
-    if _PROFILER is None:
+    prof = _CTX.get().profiler
+    if prof is None:
         return fn()
-    return _PROFILER.run(name, flops, nbytes, fn)
+    return prof.run(name, flops, nbytes, fn)
 
 
 # ----------------------------------------------------------------------------- weights
@@ -386,14 +436,6 @@ def pack_conv(weight, bias, dtype, device, cin_split=None, geglu=False):
 
 
 # ----------------------------------------------------------------------------- conv / linear
-USE_HALO = True      # route eligible 3x3 convs through conv_halo.hip (set False to A/B against the gather kernel)
-HALO_MIN_WGS = 256   # below one workgroup per CU the 8x32-pixel halo tile under-fills the chip (measured 130 vs
-                     # 334 TFLOP/s on 32x32 maps): such layers use the 64x128 gather kernel with the 3-stage ring
-SPLIT_HALO_MIN_WGS = 64    # the split precision: its gather kernel runs at 190-200 effective TFLOP/s where the halo kernel does 385-400, and
-                     # the small maps of this precision are the tiles of the tiled VAE, stacked 7-49 per launch (86 x 86 x 512: 132 workgroups
-                     # per planning unit, 72 x 72: 108, 86 x 64: 88): the halo tile from a quarter of a chip per unit
-
-
 def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, residual=None,
            out_f32=False, act=L.ACT_NONE, alpha=1.0, beta=1.0, norm=None, stats=False, out_planes=False, out_group=None, norm_group=None,
            group=None):
@@ -415,6 +457,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
     compute dtype "w2"): dtype RSVLD_F16W2, fp16 activation x fp16 weight pair [W_lo | W_hi], two MFMAs per product; in a
     split-precision network the output is fp32 (+ fp32 residual) unless ``out_planes`` asks for the fp16 hand-over."""
     _need_gpu(x, x2, pc.w, rowvec, residual)
+    ctx = _CTX.get()
     if isinstance(x, Planes) or (x.dtype == torch.float32 and _split_fast()):
         return _conv2d_split(x, pc, x2=x2, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual,
                              act=act, alpha=alpha, beta=beta, norm=norm, stats=stats, out_planes=out_planes, out_group=out_group,
@@ -431,7 +474,7 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
             out_f32 = not out_planes
             # the layer's weight group (SplitPolicy.f16_weights): named by the caller, or implied by the consumer of an fp16 output
             wg = group if group is not None else ({"attn": "qkv", "ff": "geglu"}.get(out_group) if not out_f32 else None)
-            if wg is not None and _POLICY is not None and wg in _POLICY.f16_weights:
+            if wg is not None and ctx.policy is not None and wg in ctx.policy.f16_weights:
                 if out_f32:
                     if pc.kh != 1 or pc.kw != 1 or x2 is not None:
                         raise L.RsvldError(f"conv2d: SplitPolicy.f16_weights {wg!r} with an fp32 output is a Linear layer's form (RSVLD_F16W1)")
@@ -472,14 +515,14 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride,
         pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, upsample=int(upsample), dtype=L.F16W1 if w1res else L.F16W2 if w2 else _dt(x), out_f32=int(out_f32),
-        act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=_PLAN_DIV, tune=TUNE)
+        act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=ctx.plan_div, tune=ctx.tune)
     sfx = "_w1" if w1res else "_w2" if w2 else ""
     lib = L.load()
-    halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
-    Bp = -(-B // _PLAN_DIV)            # batch rows of one planning unit: every plan decision below uses Bp / Mp
+    halo = ctx.use_halo and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
+    Bp = -(-B // ctx.plan_div)            # batch rows of one planning unit: every plan decision below uses Bp / Mp
     if halo:
         bn = 64 if pc.cout_p <= 64 else 128
-        halo = Bp * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= HALO_MIN_WGS and not (upsample and norm is not None)
+        halo = Bp * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= ctx.halo_min_wgs and not (upsample and norm is not None)
     if norm is not None and not halo:   # unfused: normalise into a (single) tensor, then convolve it
         gamma, nbeta, groups, eps, silu = norm
         xn = group_norm(x, gamma, nbeta, groups, eps, x2=x2, silu=silu)
@@ -519,11 +562,11 @@ def conv2d(x, pc, *, x2=None, stride=1, pad=None, upsample=False, rowvec=None, r
             out._gn_part = (part_out, ntiles)
         return out
     M = B * Ho * Wo
-    Mp = -(-M // _PLAN_DIV)
+    Mp = -(-M // ctx.plan_div)
     if (pc.kh == 1 and pc.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not upsample and x2 is None and rowvec is None
             and (w2 or not out_f32) and Cin % 32 == 0 and pc.cout_p >= 256 and Mp >= 4096
             and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128 and 256 * Cin * (4 if w2 else 2) < 2 ** 32
-            and not (TUNE & L.TUNE_NO_GEMM256)):   # mirrors rsvld_gemm256_try in csrc/gemm.hip (profiler label only)
+            and not (ctx.tune & L.TUNE_NO_GEMM256)):   # mirrors rsvld_gemm256_try in csrc/gemm.hip (profiler label only)
         variant = "gemm_256x256"
     elif pc.cout_p <= 32:
         variant = "conv_igemm_256x32"
@@ -574,10 +617,10 @@ def _conv2d_f32(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, alph
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo,
         upsample=int(upsample), dtype=L.F32, out_f32=1, act=act, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=1,
-        tune=L.TUNE_F32_SPLIT if _F32_SPLIT else 0)
+        tune=L.TUNE_F32_SPLIT if _policy() is not None else 0)
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
     nbytes = 4.0 * (x.numel() + pc.w.numel() + out.numel() + (0 if residual is None else residual.numel()))
-    _launch("conv_f32_split" if _F32_SPLIT else "conv_f32", flops, nbytes, lambda: L.check(L.load().rsvld_conv2d_nhwc_f32(C.byref(d), _stream()),
+    _launch("conv_f32_split" if _policy() is not None else "conv_f32", flops, nbytes, lambda: L.check(L.load().rsvld_conv2d_nhwc_f32(C.byref(d), _stream()),
                                                        "rsvld_conv2d_nhwc_f32"))
     out._nhwc = True     # an fp32 4-d tensor is otherwise taken for NCHW by the VAE's input adapter
     return out
@@ -667,7 +710,7 @@ def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None, f
 
 
 def _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample):
-    if not PROFILE_DETAIL:
+    if not _CTX.get().profile_detail:
         return ""
     return f" [{B}x{Ho}x{Wo} {Cin}+{Cin2}->{pc.cout_p} k{pc.kh} s{stride}{' up' if upsample else ''}]"
 
@@ -688,6 +731,7 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
             return conv2d(x16, pc, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual, act=act, alpha=alpha,
                           beta=beta, stats=stats, out_planes=out_planes, out_group=out_group, group=group)
         x, x2 = _gn_apply_split(x, x2, ab, silu, planes=True), None
+    ctx = _CTX.get()
     x = to_planes(x)
     x2 = None if x2 is None else to_planes(x2)
     B, H, W, Cin = x.shape
@@ -730,16 +774,16 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
         residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
         B=B, H=H, W=W, Cin=Cin, Cin2=Cin2, Cout=pc.cout_p, KH=pc.kh, KW=pc.kw, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo,
         upsample=int(upsample), dtype=L.SPLIT, out_f32=2 if out_f16 else int(not out_planes), act=act, alpha=alpha, beta=beta,
-        rowvec_stride=rv_stride, plan_div=_PLAN_DIV, tune=TUNE)
+        rowvec_stride=rv_stride, plan_div=ctx.plan_div, tune=ctx.tune)
     lib = L.load()
     flops = 2.0 * B * Ho * Wo * pc.cout * pc.cin * pc.kh * pc.kw
     nbytes = 4.0 * (x.numel() + (0 if x2 is None else x2.numel()) + out.numel() / (2 if (out_planes or out_f16) else 1)
                     + (0 if residual is None else residual.numel())) + 6.0 * pc.w.numel()
-    Bp = -(-B // _PLAN_DIV)
-    halo = USE_HALO and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
+    Bp = -(-B // ctx.plan_div)
+    halo = ctx.use_halo and bool(lib.rsvld_conv3x3_halo_supported(C.byref(d)))
     if halo:
         bn = 64 if pc.cout_p <= 64 else 128
-        halo = Bp * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= SPLIT_HALO_MIN_WGS
+        halo = Bp * ((Ho + 7) // 8) * ((Wo + 31) // 32) * ((pc.cout_p + bn - 1) // bn) >= ctx.split_halo_min_wgs
     if halo:
         part_out = None
         if stats and not out_planes:
@@ -751,10 +795,10 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
             out._gn_part = (part_out, ntiles)
     else:
         M = B * Ho * Wo
-        Mp = -(-M // _PLAN_DIV)
+        Mp = -(-M // ctx.plan_div)
         g256 = (pc.kh == 1 and pc.kw == 1 and stride == 1 and (pt, pl) == (0, 0) and not upsample and x2 is None and rowvec is None
                 and Cin % 32 == 0 and pc.cout_p >= 256 and Mp >= 4096 and ((Mp + 255) // 256) * ((pc.cout_p + 255) // 256) >= 128
-                and 256 * Cin * 6 < 2 ** 32 and not (TUNE & L.TUNE_NO_GEMM256))   # mirrors rsvld_gemm256_try
+                and 256 * Cin * 6 < 2 ** 32 and not (ctx.tune & L.TUNE_NO_GEMM256))   # mirrors rsvld_gemm256_try
         _launch(("gemm_256x256_split" if g256 else "conv_igemm_split") + _detail(B, Ho, Wo, Cin, Cin2, pc, stride, upsample), flops, nbytes,
                 lambda: L.check(lib.rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
     if out_f16:
@@ -935,30 +979,25 @@ def attention(q, k, v, heads, scale=None):
     if q.dtype == torch.float32:
         if k.dtype != torch.float32 or v.dtype != torch.float32:
             raise L.RsvldError("attention (fp32): q, k, v must all be fp32")
-        fn = lib.rsvld_attention_f32_split if _F32_SPLIT else lib.rsvld_attention_f32
-        _launch(f"attention_f32{'_split' if _F32_SPLIT else ''}_d{D}", flops, nbytes, lambda: L.check(
+        fn = lib.rsvld_attention_f32_split if _policy() is not None else lib.rsvld_attention_f32
+        _launch(f"attention_f32{'_split' if _policy() is not None else ''}_d{D}", flops, nbytes, lambda: L.check(
             fn(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
                q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                out.stride(0), out.stride(1), scale, _stream()), "rsvld_attention_f32"))
         return out
-    ws_bytes = lib.rsvld_attention_ws_bytes(B, heads, Nq, Nk, D, _PLAN_DIV)   # split-KV partials (D = 512, small grids)
+    ws_bytes = lib.rsvld_attention_ws_bytes(B, heads, Nq, Nk, D, _CTX.get().plan_div)   # split-KV partials (D = 512, small grids)
     ws = torch.empty(ws_bytes, device=q.device, dtype=torch.uint8) if ws_bytes > 0 else None
-    tune = D64_KERNEL_TUNE
+    tune = _CTX.get().d64_kernel
     # (profiler group: the short cross-attention launches -- 77 text keys -- are a different kernel and a different regime than
     #  the self-attention of the same layer: kept apart so that the roofline of the dominant group describes ONE kind of launch)
     _launch(f"attention_d{D}" + ("_cross" if (D == 64 and Nk != Nq) else ""), flops, nbytes, lambda: L.check(
         lib.rsvld_attention_tuned(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, heads, Nq, Nk, D,
                                   q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                  out.stride(0), out.stride(1), scale, _dt(q), _PLAN_DIV, _ptr(ws), _stream(), tune),
+                                  out.stride(0), out.stride(1), scale, _dt(q), _CTX.get().plan_div, _ptr(ws), _stream(), tune),
         "rsvld_attention"))
     if _split_fast() and not f16_group("attn_out"):   # a split-precision network whose to_out wants planes (exact: 11 bits fit hi + lo)
         return _f16_to_planes(out)
     return out
-
-
-D64_KERNEL_TUNE = 0              # developer A/B (devtools.d64_kernel): 1 / 2 / 3 = force attn_d64b / attn_d64c / attn_d64p (bit-identical forms)
-SPLIT_D512_FUSED_MIN = 2048      # query rows from which the fused split d = 512 kernel runs (64 per workgroup)
-SPLIT_ATTN_S_BYTES = 32 << 30    # fp32 score block of the GEMM form (P planes: as much again)
 
 
 def _split_gemm(xt, w3, out, M, K, N, out_f32, name):
@@ -966,7 +1005,7 @@ def _split_gemm(xt, w3, out, M, K, N, out_f32, name):
     ``out`` fp32 ``[M, N]`` or planes ``[M, 2, N]`` (rsvld_conv2d_nhwc as a 1x1 layer; plans on the whole call)."""
     d = L.ConvDesc(x=xt.data_ptr(), x2=None, w=w3.data_ptr(), bias=None, rowvec=None, residual=None, out=out.data_ptr(),
                    B=1, H=1, W=M, Cin=K, Cin2=0, Cout=N, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, Ho=1, Wo=M, upsample=0,
-                   dtype=L.SPLIT, out_f32=int(out_f32), act=L.ACT_NONE, alpha=1.0, beta=1.0, rowvec_stride=0, plan_div=1, tune=TUNE)
+                   dtype=L.SPLIT, out_f32=int(out_f32), act=L.ACT_NONE, alpha=1.0, beta=1.0, rowvec_stride=0, plan_div=1, tune=_CTX.get().tune)
     _launch(name, 2.0 * M * K * N, 4.0 * M * K + 6.0 * N * K + 4.0 * M * N,
             lambda: L.check(L.load().rsvld_conv2d_nhwc(C.byref(d), _stream()), "rsvld_conv2d_nhwc"))
 
@@ -1040,7 +1079,7 @@ def _attention_split_kernels(q, k, v, heads, scale):
             v.t.stride(0), v.t.stride(1), v.t.stride(2), out.stride(0), out.stride(1), out.stride(2), scale, 0, _stream()),
             "rsvld_attention_split_d64"))
         return Planes(out)
-    if D == 512 and heads == 1 and shared and Nq >= SPLIT_D512_FUSED_MIN:
+    if D == 512 and heads == 1 and shared and Nq >= _CTX.get().split_d512_fused_min:
         # keys and values are ONE planes tensor (SR3's re-associated SelfAttention): the fused kernel, two waves per 32 query rows
         nbytes = 4.0 * (2 * B * Nq * HD + B * Nk * HD)
         _launch("attention_split_d512", flops, nbytes, lambda: L.check(lib.rsvld_attention_split_d512_shared(
@@ -1051,7 +1090,7 @@ def _attention_split_kernels(q, k, v, heads, scale):
     if D % 8:
         raise L.RsvldError("attention (split): head dim must be a multiple of 8")
     Nk_p = (Nk + 7) // 8 * 8
-    rows_blk = max(256, min(Nq, (SPLIT_ATTN_S_BYTES // (4 * Nk_p)) // 256 * 256))
+    rows_blk = max(256, min(Nq, (_CTX.get().split_attn_s_bytes // (4 * Nk_p)) // 256 * 256))
     dev = q.t.device
     for b in range(B):
         for h in range(heads):

@@ -147,7 +147,7 @@ class GaussianDiffusion(nn.Module):
         # the graph holds raw pointers into the packed weights: key it on their version and drop stale captures
         # ... and on everything else a capture bakes in: the split-operand flag and the batch-invariant plan divisor are global state
         # read at launch time (fp32 <-> split toggles left pack_version alone and replayed the other mode's kernels)
-        key = (tuple(xin.shape), xin.dtype, xin.device.index, unet.pack_version, unet.precision_key(), ops._PLAN_DIV)
+        key = (tuple(xin.shape), xin.dtype, xin.device.index, unet.pack_version, unet.precision_key(), ops.context().plan_div)
         ent = self._graphs.get(key)
         if ent is None:
             self._graphs = {k: v for k, v in self._graphs.items() if k[3] == unet.pack_version}

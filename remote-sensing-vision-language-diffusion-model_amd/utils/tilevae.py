@@ -154,7 +154,7 @@ class VAEHook:
             key = (b[3] - b[2], b[1] - b[0]) if self.stack_tiles else i
             classes.setdefault(key, []).append(i)
         groups = list(classes.values())
-        unit = ops._PLAN_DIV                             # independent units the caller has already stacked along B
+        unit = ops.context().plan_div                             # independent units the caller has already stacked along B
         gens, pending = [], []
         for idx in groups:
             x = torch.cat([z[:, in_bboxes[i][2]:in_bboxes[i][3], in_bboxes[i][0]:in_bboxes[i][1], :] for i in idx], 0)

@@ -108,18 +108,14 @@ def test_conv3x3_halo_fused_groupnorm(cuda, dtype, case):
     resp = torch.zeros(B, H, W, pad8, dtype=dtype)
     resp[..., :Cout] = res.permute(0, 2, 3, 1)
     norm = (gamma.to(cuda), beta.to(cuda), 32, 1e-5, True) if fuse else None
-    ops.HALO_MIN_WGS = 0   # force the halo kernel at test sizes
-    got = ops.conv2d(_nhwc(x1, dtype, cuda), pc, x2=None if x2 is None else _nhwc(x2, dtype, cuda), pad=1,
-                     rowvec=rv.to(cuda), residual=resp.to(cuda), norm=norm)
+    with ops.tuning(halo_min_wgs=0):   # force the halo kernel at test sizes
+        got = ops.conv2d(_nhwc(x1, dtype, cuda), pc, x2=None if x2 is None else _nhwc(x2, dtype, cuda), pad=1,
+                         rowvec=rv.to(cuda), residual=resp.to(cuda), norm=norm)
     _close(got[..., :Cout].permute(0, 3, 1, 2), want, dtype)
     # the same call through the gather kernel (unfused norm) must agree with the fused path
-    ops.USE_HALO = False
-    try:
+    with ops.tuning(use_halo=False):
         ref = ops.conv2d(_nhwc(x1, dtype, cuda), pc, x2=None if x2 is None else _nhwc(x2, dtype, cuda), pad=1,
                          rowvec=rv.to(cuda), residual=resp.to(cuda), norm=norm)
-    finally:
-        ops.USE_HALO = True
-        ops.HALO_MIN_WGS = 256
     _close(got.float(), ref.float().cpu(), dtype, scale=float(want.abs().max()))
 
 
@@ -137,8 +133,7 @@ def test_groupnorm_statistics_from_conv_epilogue(cuda, dtype):
     wc = _rt(torch.randn(128, 192, 3, 3, generator=g) / 41, dtype)
     res = _rt(torch.randn(B, 128, H, W, generator=g), dtype)
     gamma, beta = 1 + 0.1 * torch.randn(192, generator=g), 0.1 * torch.randn(192, generator=g)
-    ops.HALO_MIN_WGS = 0
-    try:
+    with ops.tuning(halo_min_wgs=0):
         ya = ops.conv2d(_nhwc(xa, dtype, cuda), ops.pack_conv(wa, None, dtype, cuda), pad=1, residual=_nhwc(res, dtype, cuda), stats=True)
         yb = ops.conv2d(_nhwc(xb, dtype, cuda), ops.pack_conv(wb, None, dtype, cuda), pad=1, stats=True)
         assert hasattr(ya, "_gn_part") and hasattr(yb, "_gn_part")
@@ -147,8 +142,6 @@ def test_groupnorm_statistics_from_conv_epilogue(cuda, dtype):
         got = ops.conv2d(ya, pcc, x2=yb, pad=1, norm=norm)                       # statistics from the epilogues
         ya2, yb2 = ya.clone(), yb.clone()                                          # clones carry no partials
         ref = ops.conv2d(ya2, pcc, x2=yb2, pad=1, norm=norm)                     # statistics pass over the tensors
-    finally:
-        ops.HALO_MIN_WGS = 256
     cat = torch.cat([ya.float().cpu().permute(0, 3, 1, 2), yb.float().cpu().permute(0, 3, 1, 2)], 1)
     want = F.conv2d(F.silu(F.group_norm(cat, 32, gamma, beta, eps=1e-5)), wc, None, padding=1)
     _close(got.permute(0, 3, 1, 2), want, dtype)
@@ -167,16 +160,13 @@ def test_groupnorm_statistics_from_8wave_conv_epilogue(cuda):
     wa = _rt(torch.randn(512, 64, 3, 3, generator=g) / 24, dtype)      # 192 workgroups of 16x32 -> 8-wave kernel
     wc = _rt(torch.randn(128, 512, 3, 3, generator=g) / 68, dtype)
     gamma, beta = 1 + 0.1 * torch.randn(512, generator=g), 0.1 * torch.randn(512, generator=g)
-    ops.HALO_MIN_WGS = 0
-    try:
+    with ops.tuning(halo_min_wgs=0):
         ya = ops.conv2d(_nhwc(xa, dtype, cuda), ops.pack_conv(wa, None, dtype, cuda), pad=1, stats=True)
         assert hasattr(ya, "_gn_part")
         norm = (gamma.to(cuda), beta.to(cuda), 32, 1e-5, True)
         pcc = ops.pack_conv(wc, None, dtype, cuda)
         got = ops.conv2d(ya, pcc, pad=1, norm=norm)            # statistics from the producer's epilogue
         ref = ops.conv2d(ya.clone(), pcc, pad=1, norm=norm)    # statistics pass over the tensor
-    finally:
-        ops.HALO_MIN_WGS = 256
     want = F.conv2d(F.silu(F.group_norm(ya.float().cpu().permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-5)), wc, None, padding=1)
     _close(got.permute(0, 3, 1, 2), want, dtype)
     _close(got.float(), ref.float().cpu(), dtype, scale=float(want.abs().max()))
@@ -191,11 +181,8 @@ def test_conv3x3_halo_fused_upsample(cuda, dtype):
     w = _rt(torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(128 * 9), dtype)
     b = torch.randn(128, generator=g) * 0.1
     want = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
-    ops.HALO_MIN_WGS = 0
-    try:
+    with ops.tuning(halo_min_wgs=0):
         got = ops.conv2d(_nhwc(x, dtype, cuda), ops.pack_conv(w, b, dtype, cuda), pad=1, upsample=True)
-    finally:
-        ops.HALO_MIN_WGS = 256
     assert got.shape == (2, 18, 42, 128)
     _close(got.permute(0, 3, 1, 2), want, dtype)
 
@@ -267,12 +254,8 @@ def test_gemm256_persistent_vs_one_tile(cuda, dtype):
         pc = ops.pack_conv(w, b, dtype, cuda, geglu=(act == 2))
         kw = dict(residual=None if res is None else res.to(cuda, dtype), act={0: L.ACT_NONE, 2: L.ACT_GEGLU}[act], alpha=alpha, beta=beta)
         got = ops.linear(x.to(cuda, dtype), pc, **kw)
-        keep = ops.TUNE
-        ops.TUNE = keep | L.TUNE_GEMM_ONE_TILE
-        try:
+        with ops.tuning(tune=ops.context().tune | L.TUNE_GEMM_ONE_TILE):
             one = ops.linear(x.to(cuda, dtype), pc, **kw)
-        finally:
-            ops.TUNE = keep
         _close(got, y, dtype)
         _close(one, y, dtype)
         d = (got.float() - one.float()).abs()
@@ -730,8 +713,5 @@ def test_hand_scheduled_kernels_are_deterministic(cuda):
     xi = (torch.randn(2, 40, 72, 512, generator=g)).to(cuda, dt)
     pcc = ops.pack_conv(torch.randn(256, 512, 3, 3, generator=g) / 68, None, dt, cuda)
     norm = (torch.ones(512, device=cuda), torch.zeros(512, device=cuda), 32, 1e-5, True)
-    ops.HALO_MIN_WGS = 0
-    try:
+    with ops.tuning(halo_min_wgs=0):
         repeat(lambda: ops.conv2d(xi, pcc, pad=1, norm=norm))
-    finally:
-        ops.HALO_MIN_WGS = 256

@@ -310,15 +310,11 @@ def test_attention_split_d512_fused(cuda, B, Nq, Nk):
     x = torch.randn(B, Nk, 512, generator=g) * 0.7
     want = _attn_ref(q, x, x, 1, 512 ** -0.5)
     qp, xp = ops.to_planes(q.to(cuda)), ops.to_planes(x.to(cuda))
-    old = ops.SPLIT_D512_FUSED_MIN
-    try:
-        with _all_split():
-            ops.SPLIT_D512_FUSED_MIN = 1
+    with _all_split():
+        with ops.tuning(split_d512_fused_min=1):
             got = ops.attention(qp, xp, xp, heads=1, scale=512 ** -0.5)
-            ops.SPLIT_D512_FUSED_MIN = 1 << 30
+        with ops.tuning(split_d512_fused_min=1 << 30):
             ref = ops.attention(qp, xp, xp, heads=1, scale=512 ** -0.5)
-    finally:
-        ops.SPLIT_D512_FUSED_MIN = old
     _cmp(got.f32(), want, REL, f"attention split d512 fused B{B} {Nq}x{Nk}")
     _cmp(got.f32(), ref.f32().cpu(), REL, "  fused vs GEMM form")
 

@@ -11,17 +11,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_two_rank_shard_and_gather():
-    import json
-    import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    _two_ranks(8)
-    _two_ranks(5)      # uneven: rank 0 holds 3 images, rank 1 holds 2 and pads
+    _ranks(8, 2)
+    _ranks(5, 2)      # uneven: rank 0 holds 3 images, rank 1 holds 2 and pads
 
 
-def _two_ranks(n):
+def test_eight_rank_shard_and_gather():
+    """BASELINE configs[4]'s partition: 64 images over 8 ranks (8 each), and 61 (ranks 0-4 hold 8, ranks 5-7 hold 7 and pad) --
+    the rank count the driver's scaling run uses, rehearsed on gloo."""
+    _ranks(64, 8)
+    _ranks(61, 8)
+
+
+def _ranks(n, world):
     import json
     import subprocess
     s = socket.socket()
@@ -30,18 +31,21 @@ def _two_ranks(n):
     s.close()
     worker = os.path.join(ROOT, "tests", "_dist_worker.py")
     procs = []
-    for r in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                   OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, worker, str(n)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     res = []
     for p in procs:
-        out, _ = p.communicate(timeout=180)
+        out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out
         res.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:]))
     res.sort(key=lambda d: d["rank"])
-    assert res[0]["idx"] == list(range(0, n, 2)) and res[1]["idx"] == list(range(1, n, 2))
     want = [int(round(((i / n * 2 - 1) + 1) * 0.5 * 255)) for i in range(n)]
-    assert res[0]["vals"] == want and res[1]["vals"] == want    # both ranks hold all images, in image order
+    for r in range(world):
+        assert res[r]["idx"] == list(range(r, n, world))
+        assert res[r]["vals"] == want                           # every rank holds all images, in image order
+    assert sorted(i for d in res for i in d["idx"]) == list(range(n))   # each image processed exactly once
 
 
 def test_shard_and_unshard_are_inverse():

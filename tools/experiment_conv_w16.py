@@ -17,7 +17,7 @@ on = [False]
 
 def patched(x, pc, **kw):
     tagged = kw.get("norm_group") in ("conv1", "conv2")
-    take = on[0] and pc.kh == 3 and ops._POLICY is not None and ops._POLICY.f16_inputs and (
+    take = on[0] and pc.kh == 3 and ops.context().policy is not None and ops.context().policy.f16_inputs and (
         which == "all" or (which == "res" and tagged) or (which == "other" and not tagged))
     if not take:
         return orig(x, pc, **kw)
