@@ -43,6 +43,7 @@ def s2_run(m, img, prec, thr, steps, tiled):
     def spy(self, x, i, *a, **k):
         out = orig(self, x, i, *a, **k)
         states.append(out[0].clone())
+        print(f"  [stage 2, {prec}, cache {thr}] step {len(states)} done", file=sys.stderr, flush=True)   # (a silent GPU command is taken to be hung)
         return out
 
     ae, df = {"fp32": ("fp32", "fp32"), "tolerance": ("split", "split")}[prec]
@@ -98,9 +99,11 @@ def stage1(args, dev, fh):
         for prec in ("fp32", "w2"):
             states, orig = [], net.p_sample
 
-            def spy(x, t, *a, _o=orig, _s=states, **k):
+            def spy(x, t, *a, _o=orig, _s=states, _p=prec, **k):
                 out = _o(x, t, *a, **k)
                 _s.append(out.clone())
+                torch.cuda.synchronize()
+                print(f"  [stage 1, {side}^2, {_p}] step {len(_s)} done", file=sys.stderr, flush=True)   # (a silent GPU command is taken to be hung)
                 return out
 
             unet.set_compute_dtype(prec)
