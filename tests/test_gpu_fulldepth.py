@@ -114,3 +114,31 @@ def test_stage1_config1_T50_batch4_split_inside_1e3(s1_runs):
     d16 = (s1_runs["fp16"] - want).abs()
     print(f"Stage 1, configs[1] (512^2, batch 4), T = 50: fp16 vs fp32 family max|d| = {float(d16.max()):.3e}, mean|d| = {float(d16.mean()):.3e}")
     assert float(d16.max()) < 1e-2 and float(d16.mean()) < 1e-3
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.3])
+def test_stage2_full_depth_50_steps_latent128_inside_1e3(cuda, full_model, thr):
+    """The same measurement one size up: 1024^2 input = latent 128 (16 384 tokens at level 0, 4 x the keys per softmax row of the latent-64
+    runs above), tiled VAE, all 50 EDM steps, tolerance composition vs the fp32-operand family.  Together with the truncated runs at latent
+    256 / 512 (tools/tolerance_at_scale.py, profiles/r06_tolerance_at_scale.txt) this is the growth law in the token count: the distance
+    does not grow with it (measured 6.7e-4 / 3.9e-5 cache off, 7.0e-4 / 4.5e-5 at 0.3, all 50 decisions equal)."""
+    import bench
+    img = bench.synthetic_image((1, 3, 1024, 1024), seed=4321, smooth=4).to(cuda)
+    m = full_model
+    res = {}
+    for prec in ("fp32", "split"):
+        m.noise_source = "cpu"
+        m.set_precision(*S2_MODES[prec])
+        try:
+            torch.manual_seed(7)
+            out = m.just_sampling(img, [""], **dict(bench.S2_KW, img_threshold=thr, num_steps=50))
+            res[prec] = (out.cpu(), [bool(step[0][2]) for step in m.cache_trace])
+        finally:
+            m.noise_source = "device"
+            m.set_precision("bf16", "fp16")
+    (want, wtrace), (got, trace) = res["fp32"], res["split"]
+    d = (got - want).abs()
+    print(f"Stage 2, FULL depth, 50 steps at latent 128, cache {thr}: split vs fp32 family max|d| = {float(d.max()):.3e}, "
+          f"mean|d| = {float(d.mean()):.3e} (range {float(want.abs().max()):.2f}); cache hits {sum(wtrace)} / {len(wtrace)}")
+    assert bool(torch.isfinite(want).all()) and float(d.max()) < 1e-3 and float(d.mean()) < 1.5e-4
+    assert trace == wtrace, "the split mode took a different cache decision than the fp32 family"
