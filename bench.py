@@ -293,7 +293,8 @@ def barrier(world):
 def kernel_table(summ):
     whole = all("ms_whole_image" in r for r in summ.values())
     # (tflops = algorithmic FLOPs of the product; mfma_tflops = what the matrix pipe executes: x 2 in the weight-pair form, x 3 in the split precision)
-    seg = lambda k: 2 if k.split(" [")[0].endswith("_w2") else (3 if "_split" in k.split(" [")[0] else 1)
+    # (_q8: two fp16 MFMAs + one e4m3 MFMA over twice the K per 32 channels and tap = 2 sixteen-bit equivalents at the e4m3 form's nominal 2x rate)
+    seg = lambda k: 2 if k.split(" [")[0].endswith(("_w2", "_q8")) else (3 if "_split" in k.split(" [")[0] else 1)
     return {k: dict({"ms": round(v["ms"], 2), "n": v["n"],
                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                      "mfma_tflops": round(seg(k) * v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
@@ -316,7 +317,9 @@ PMC_ALIAS = {"attention_d64": ("attn_d64c", "attn_d64"), "attention_d64_cross": 
              "gemm_256x256_w1": ("gemm256_w1", "gemm256"),
              "gemm_256x256_w2": ("gemm256_w2", "gemm256"), "conv_halo_128_w2": ("conv_halo_128_w2", "conv_halo_128"),
              "conv_halo_64_w2": ("conv_halo_64_w2", "conv_halo_64"), "conv_igemm_64x128_w2": ("conv_igemm_64x128",),
-             "conv_igemm_128x128_w2": ("conv_igemm_128x128",)}
+             "conv_igemm_128x128_w2": ("conv_igemm_128x128",),
+             # round 6: the e4m3 cross-term form of the ResBlock convolutions and its GroupNorm apply pass
+             "conv_halo_128_q8": ("conv_halo_128_q8", "conv_halo_128"), "groupnorm_apply_q8": ("gn_apply_split",)}
 
 
 def _pmc_row(kern, name):

@@ -41,6 +41,7 @@ extern "C" {
 #define RSVLD_F32 2   /* accepted ONLY by the *_f32 entry points at the end of this header */
 #define RSVLD_SPLIT 3 /* split-operand precision on the 16-bit tilings (rsvld_conv_desc.dtype; the *_split entry points below) */
 #define RSVLD_F16W2 4 /* fp16 activations x fp16 weight PAIRS [W_lo | W_hi] (rsvld_conv_desc.dtype; see below): two MFMAs per product */
+#define RSVLD_F16Q8 6 /* fp16 hi x hi + the two cross terms of the split product in e4m3 on the block-scaled matrix instruction (see below) */
 #define RSVLD_F16W1 5 /* fp16 activations x the SAME weights rounded to fp16, fp32 out (+ fp32 residual): one MFMA per product (see below) */
 
 /* epilogue activations for rsvld_conv2d_nhwc */
@@ -121,6 +122,20 @@ typedef struct rsvld_conv_desc {
  * of :250-285).  x : fp16; w : plain fp16 [Cout][Cin] (what RSVLD_F16 takes): ONE MFMA per product -- with the OUTPUT side of the
  * multi-segment family: out fp32 (out_f32 must be 1), residual fp32, out = alpha * (x W + b) + beta * residual in fp32.  The same layer with
  * a 16-bit output is plain RSVLD_F16. */
+/* dtype = RSVLD_F16Q8 (round 6; accepted by rsvld_conv3x3_halo_nhwc, Cout > 64, (Cin + Cin2) % 32 == 0, no fused norm): the 3x3 convolutions
+ * of the split-precision UNets with FEWER MATRIX CYCLES PER PRODUCT.  x w = x_hi w_hi + x_lo w_hi + x_hi w_lo; the two cross terms are 2^-11 of
+ * the product when the hi parts are fp16, so their operands run as e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4 (2.26 x the 16-bit FLOP rate
+ * measured, profiles/r06_mfma_f8f6f4.txt): per 32 channels and tap 2 fp16 MFMAs + 1 scaled MFMA instead of 6 bf16 MFMAs.
+ *     x, x2 : [B,H,W, 4 C bytes]  row = [ fp16(x) (C) | C / 32 blocks of 64 B { P0[0:16] | P1[0:16] | P0[16:32] | P1[16:32] } ],
+ *             P0 = e4m3((x - fp16 x) 2^14), P1 = e4m3(x 2^2) of the block's 32 channels  (rsvld_groupnorm_apply_split out_f32 = 3, rsvld_split_hq8)
+ *     w     : [Cout][9][ fp16(w) (Ctot) | Ctot / 32 blocks likewise ], P0 = e4m3(w 2^6), P1 = e4m3((w - fp16 w) 2^18)   (rsvld_pack_weight_hq8)
+ * (the 16-byte interleave lets the kernel read a block with the fragment addresses of its fp16 k-steps: lane half h gets all of P_h)
+ * out fp32 (out_f32 must be 1), residual fp32, epilogue statistics as for RSVLD_SPLIT.  Measured at full network depth over 50 steps the
+ * distance from the fp32 family is that of RSVLD_SPLIT (+3.5 % in the mean, profiles/r06_conv_lo8_emulation.txt). */
+#define RSVLD_HQ8_SX_LO 14
+#define RSVLD_HQ8_SX_HI 2
+#define RSVLD_HQ8_SW_HI 6
+#define RSVLD_HQ8_SW_LO 18
 int rsvld_conv2d_nhwc(const rsvld_conv_desc* d, void* stream);
 
 /* 3x3 / stride-1 / pad-1 convolution with an LDS-resident input halo patch (each activation byte crosses
@@ -403,6 +418,12 @@ int rsvld_split_pack_weights(const float* w, void* w3, int64_t Cout, int taps, i
 /* fp32 K-major weights [Cout][taps][Ctot] -> fp16 pairs [Cout][taps][W_lo(Ctot) | W_hi(Ctot)], W_hi = fp16(W), W_lo = fp16(W - W_hi): the
  * weights of dtype RSVLD_F16W2 (same nn.Conv2d / nn.Linear call sites as rsvld_conv2d_nhwc) */
 int rsvld_pack_weight_pairs(const float* w, void* w2, int64_t Cout, int taps, int Ctot, void* stream);
+/* fp32 K-major weights [Cout][taps][Ctot] (Ctot % 32 == 0) -> the rows of dtype RSVLD_F16Q8: [Cout][taps][ fp16(w) (Ctot) | Ctot / 32 blocks
+ * of P0 = e4m3(w 2^RSVLD_HQ8_SW_HI), P1 = e4m3((w - fp16 w) 2^RSVLD_HQ8_SW_LO) in 16-byte pieces ]: 4 Ctot bytes per tap (nn.Conv2d 3x3 call sites of
+ * sgm/modules/diffusionmodules/openaimodel.py:207-350) */
+int rsvld_pack_weight_hq8(const float* w, void* whq, int64_t Cout, int taps, int Ctot, void* stream);
+/* fp32 rows [rows][C] (C % 32 == 0) -> RSVLD_F16Q8 activation rows (4 C bytes each; saturating at the fp16 / e4m3 ranges, NaN kept in the fp16 part) */
+int rsvld_split_hq8(const float* x, void* out, int64_t rows, int C, void* stream);
 /* planes [rows][lo(C) | hi(C)] (row stride ld elements, ld >= 2C) -> the TRANSPOSED triple [C][V_hi^T(rows_p) | V_lo^T(rows_p) | V_hi^T(rows_p)]
  * (rows_p = rows padded with zeros to a multiple of 8): the "weights" of the P V product of an attention run as two split GEMMs */
 int rsvld_planes_transpose_triple(const void* planes, void* w3, int64_t rows, int64_t rows_p, int C, int64_t ld, void* stream);
@@ -422,7 +443,8 @@ int rsvld_groupnorm_stats_f32_fast(const float* x, const float* x2, float* mean_
 int rsvld_groupnorm_scale_shift_from_stats(const float* mean_var, const float* gamma, const float* beta, float* scale_shift,
                                            int B, int C, int groups, float eps, void* stream);
 /* y = act(scale * [x | x2] + shift) [* (1 + mod_scale1p) + mod_shift] from fp32 NHWC inputs; out: planes [B,HW, 2(C1+C2)]
- * (out_f32 = 0), fp32 [B,HW,C1+C2] (out_f32 = 1) or fp16 [B,HW,C1+C2] (out_f32 = 2: the input of an RSVLD_F16W2 layer).
+ * (out_f32 = 0), fp32 [B,HW,C1+C2] (out_f32 = 1), fp16 [B,HW,C1+C2] (out_f32 = 2: the input of an RSVLD_F16W2 layer) or RSVLD_F16Q8
+ * rows [B,HW, 4 (C1+C2) bytes] (out_f32 = 3; (C1+C2) % 32 == 0).
  * mod_* fp32 with row stride mod_stride (ZeroSFT, SR_modules.py:100-106). */
 int rsvld_groupnorm_apply_split(const float* x, const float* x2, void* out, const float* scale_shift,
                                 const float* mod_scale1p, const float* mod_shift, int mod_stride,

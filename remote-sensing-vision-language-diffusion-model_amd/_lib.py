@@ -14,6 +14,7 @@ F16, BF16, F32 = 0, 1, 2   # F32: the *_f32 entry points only (fp32-operand VAE 
 SPLIT = 3                   # rsvld_conv_desc.dtype: bf16 planes + weight triples (the split-operand product path)
 F16W2 = 4                   # rsvld_conv_desc.dtype: fp16 activations x fp16 weight pairs [W_lo | W_hi]
 F16W1 = 5                   # rsvld_conv_desc.dtype: fp16 activations x fp16 weights, fp32 out + fp32 residual (one MFMA per product)
+F16Q8 = 6                   # rsvld_conv_desc.dtype: fp16 hi x hi + the split product's two cross terms in e4m3 (rsvld_conv3x3_halo_nhwc)
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 # rsvld_conv_desc.tune (developer A/B overrides)
 TUNE_TILE = {"256x64": 1, "128x64": 2, "128x128": 3, "64x128": 4}
@@ -107,6 +108,8 @@ SIGNATURES = {
     "rsvld_f16_to_planes": (_i, [_vp, _i64, _vp, _i64, _i, _vp]),
     "rsvld_split_pack_weights": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "rsvld_pack_weight_pairs": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "rsvld_pack_weight_hq8": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "rsvld_split_hq8": (_i, [_vp, _vp, _i64, _i, _vp]),
     "rsvld_planes_transpose_triple": (_i, [_vp, _vp, _i64, _i64, _i, _i64, _vp]),
     "rsvld_planes_to_triple": (_i, [_vp, _vp, _i64, _i64, _i, _i64, _vp]),
     "rsvld_softmax_rows_split": (_i, [_vp, _vp, _i64, _i, _i, _i64, _f, _vp]),

@@ -45,6 +45,9 @@ struct HaloArgs {
     // dtype RSVLD_F16W2 (round 5): x / x2 fp16, the weights the per-tap pair [W_lo | W_hi]; Ctot = 2 Cseg logical channels whose second
     // segment re-reads the activation (and re-applies the fused GroupNorm: `ab` holds Cseg rows per image); residual and output fp32
     // (out_f32) or fp16
+    // dtype RSVLD_F16Q8 (round 6, seg = 5): x / x2 rows [fp16(x) (C) | C / 32 e4m3 blocks], weight rows per tap likewise; Ctot = 2 Cseg logical
+    // channels: a body = the fp16 chunk of 32 channels (two fp16 MFMAs per tap and tile) + their e4m3 block (ONE scaled MFMA over K = 64:
+    // lane half 0 x_lo w_hi, lane half 1 x_hi w_lo); fp32 out, fp32 residual
     int seg, Cseg;
 };
 
@@ -67,7 +70,7 @@ __device__ __forceinline__ int patch_off(int py, int px, int c) { return (py * P
 // pixel.  Split: segment 0 = lo planes, segments 1, 2 = hi planes; a pixel's row holds lo | hi.
 template <int SEG>
 __device__ __forceinline__ void halo_src_of(const HaloArgs& p, int ch0, int& which, int& Cs, int& coff) {
-    if (SEG != 3) {
+    if (SEG != 3 && SEG != 5) {   // (SEG 5: the fp16 part sits where the lo plane does, the e4m3 blocks where the hi plane does)
         if (SEG == 2 && ch0 >= p.Cseg) ch0 -= p.Cseg;   // the pair form reads the one activation twice
         if (ch0 < p.Cin) { which = 0; Cs = p.Cin; coff = ch0; } else { which = 1; Cs = p.Cin2; coff = ch0 - p.Cin; }
         return;
@@ -458,6 +461,8 @@ template <int N> __device__ __forceinline__ void halo_wait_barrier() {
 template <typename T, int BN, int NORM, int NW, int SEG = 1>
 __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     constexpr bool SPLIT = SEG == 3;
+    constexpr bool HQ = SEG == 5;            // RSVLD_F16Q8: chunk A of a body = fp16 channels, chunk B = their e4m3 cross-term block
+    constexpr bool TWO_PART = SPLIT || HQ;   // a pixel's row holds two parts of C 16-bit elements each
     constexpr int NT = 64 * NW;
     constexpr int WAVES_N = 2, WAVES_M = NW / 2;
     constexpr int TM = 4;                            // 32-pixel rows per wave
@@ -511,8 +516,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
         // dead target: the duplicate half of (scale, shift) buffer 0, never read
         pdst[i] = pp < PR ? p32_off(py, px, c4) : (int)(abuf - patch) + 512 + (tid & 31) * 16;
     }
-    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * (SPLIT ? 2 * p.Cin : p.Cin);
-    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * (SPLIT ? 2 * p.Cin2 : p.Cin2) : nullptr;
+    const T* __restrict__ X1 = (const T*)p.x + (int64_t)img * p.Hs * p.Ws * (TWO_PART ? 2 * p.Cin : p.Cin);
+    const T* __restrict__ X2 = p.x2 ? (const T*)p.x2 + (int64_t)img * p.Hs * p.Ws * (TWO_PART ? 2 * p.Cin2 : p.Cin2) : nullptr;
     const T* __restrict__ Wp = (const T*)p.w;
     const int64_t Kel = (int64_t)9 * p.Ctot;
 
@@ -577,14 +582,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
     // patch buffers alternating by body.  idx = the body's index within its kind.  xch = K' channel of a body's chunk (for halo_src_of),
     // wcol = its weight column.  PAIR_X0 / PAIR_W0: where the paired chunks start (the split form pairs its hi-plane segments 1 and 2).
     const int PAIR_X0 = SEG == 3 ? p.Cseg : 0;
-    auto xch = [&](auto kind_c, int idx, int which) { return decltype(kind_c)::value ? PAIR_X0 + idx * 32 : (2 * idx + which) * 32; };
+    auto xch = [&](auto kind_c, int idx, int which) {
+        return decltype(kind_c)::value ? PAIR_X0 + idx * 32 : HQ ? (which ? p.Cseg : 0) + idx * 32 : (2 * idx + which) * 32;
+    };
     auto dma_w = [&](auto kind_c, int idx, int st, int buf) {
         constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int g = 2 * st + j;
             const int tap = KIND ? st : (g >= 9 ? g - 9 : g);
-            const int col = KIND ? PAIR_X0 + j * p.Cseg + idx * 32 : (2 * idx + (g >= 9 ? 1 : 0)) * 32;
+            const int col = KIND ? PAIR_X0 + j * p.Cseg + idx * 32 : HQ ? (g >= 9 ? p.Cseg : 0) + idx * 32 : (2 * idx + (g >= 9 ? 1 : 0)) * 32;
             char* dst = wbuf + buf * W_BYTES + j * TAP_BYTES;
             const char* base = (const char*)(Wp + (int64_t)tap * p.Ctot + col);   // wave-uniform
 #pragma unroll
@@ -609,6 +616,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
+    // E8M0 scale bytes of the scaled MFMA, per lane half: (w 2^SW_HI)(x_lo 2^SX_LO) in half 0, (w_lo 2^SW_LO)(x 2^SX_HI) in half 1
+    const int q_scale_w = 127 - (lh ? RSVLD_HQ8_SW_LO : RSVLD_HQ8_SW_HI), q_scale_x = 127 - (lh ? RSVLD_HQ8_SX_HI : RSVLD_HQ8_SX_LO);
     int fb_off[3][2], fa_off[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -728,6 +737,38 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_halo32_kernel(HaloArgs p) {
                 const int ky = tap / 3, kx = tap - ky * 3;
                 const char* P = patch + par * PB;
                 const char* w_s = w_st + j * TAP_BYTES;
+                if (HQ && par) {   // the e4m3 block of the body's 32 channels: ONE scaled MFMA over K = 64 per tile (lane half 0: x_lo w_hi, 1: x_hi w_lo)
+                    typedef int i32x8 __attribute__((ext_vector_type(8)));
+                    __builtin_amdgcn_sched_barrier(0);
+                    i32x8 qa[TN];
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        const u32x4 a0 = *(const u32x4*)(w_s + fa_off[0] + ni * (32 * 64)), a1 = *(const u32x4*)(w_s + fa_off[1] + ni * (32 * 64));
+                        qa[ni] = (i32x8){(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+                    }
+                    // pixel fragments one tile row ahead of their MFMAs; the scheduler may not hoist further (it otherwise lifts every read of
+                    // the step to its top and spills 1.3 KiB of fragments: 128 accumulators + 24 prefetch registers leave ~70)
+                    auto ldq = [&](int mi) {
+                        const u32x4 b0 = *(const u32x4*)(P + fb_off[kx][0] + (mi + ky) * (PW * 64)), b1 = *(const u32x4*)(P + fb_off[kx][1] + (mi + ky) * (PW * 64));
+                        return (i32x8){(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+                    };
+                    i32x8 qb = ldq(0);
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        i32x8 qn = qb;
+                        if (mi + 1 < TM) qn = ldq(mi + 1);
+#pragma unroll
+                        for (int ni = 0; ni < TN; ++ni) {
+                            acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(qa[ni], qb, acc[ni][mi], 0, 0, 0, q_scale_w, 0, q_scale_x);
+                            // pins the product in front of the step's barrier: in the LAST body nothing else consumes the accumulators before the
+                            // epilogue, and hipcc sank all 72 scaled MFMAs behind the last barrier with their operands spilled (no instruction emitted)
+                            asm volatile("" : "+v"(acc[ni][mi]));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        qb = qn;
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     v8 fa[TN], fb[TM];
@@ -806,6 +847,7 @@ int launch_halo32(HaloArgs a, hipStream_t s) {
             if (norm == 1) return go(HALO_K(conv_halo32_kernel<T, BN, 1, NW, 2>));
             return go(HALO_K(conv_halo32_kernel<T, BN, 2, NW, 2>));
         }
+        if (a.seg == 5) return norm == 0 ? go(HALO_K(conv_halo32_kernel<T, BN, 0, NW, 5>)) : RSVLD_EUNSUPPORTED;   // RSVLD_F16Q8
     }
     if (a.seg != 1) return RSVLD_EUNSUPPORTED;
     if (norm == 0) return go(HALO_K(conv_halo32_kernel<T, BN, 0, NW, 1>));
@@ -857,7 +899,8 @@ extern "C" int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d) {
     if (d->Ho != up * d->H || d->Wo != up * d->W) return 0;
     if (d->Cin % 64 != 0 || d->Cin2 % 64 != 0) return 0;
     if (d->act == RSVLD_ACT_GEGLU) return 0;
-    if (d->out_f32 && d->Cout > 32 && d->dtype != RSVLD_SPLIT && d->dtype != RSVLD_F16W2) return 0;
+    if (d->out_f32 && d->Cout > 32 && d->dtype != RSVLD_SPLIT && d->dtype != RSVLD_F16W2 && d->dtype != RSVLD_F16Q8) return 0;
+    if (d->dtype == RSVLD_F16Q8 && (d->Cout <= 64 || !d->out_f32 || d->upsample)) return 0;   // the 128-wide kernels only; fp32 out
     if (d->Wo < 16 || d->Ho < 4) return 0;   // tiny maps: the 8x32 tile would be mostly padding
     return 1;
 }
@@ -868,11 +911,11 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     if (d->x == nullptr || d->w == nullptr || d->out == nullptr) return RSVLD_EINVAL;
     if (d->B <= 0 || d->Cout <= 0 || d->Cout % 8 != 0) return RSVLD_EINVAL;
     if ((d->Cin2 > 0) != (d->x2 != nullptr)) return RSVLD_EINVAL;
-    const bool split = d->dtype == RSVLD_SPLIT, w2 = d->dtype == RSVLD_F16W2;
-    const int seg = split ? 3 : w2 ? 2 : 1;
+    const bool split = d->dtype == RSVLD_SPLIT, w2 = d->dtype == RSVLD_F16W2, hq = d->dtype == RSVLD_F16Q8;
+    const int seg = split ? 3 : w2 ? 2 : hq ? 5 : 1;
     if (d->dtype != RSVLD_F16 && d->dtype != RSVLD_BF16 && seg == 1) return RSVLD_EINVAL;
     if (d->out_f32 < 0 || d->out_f32 > 1) return RSVLD_EINVAL;   // (an fp16 output of RSVLD_SPLIT exists for the Linear layers only)
-    if (split && norm_scale_shift != nullptr) return RSVLD_EUNSUPPORTED;   // the normalised tensor is split by its own kernel (rsvld_groupnorm_apply_split)
+    if ((split || hq) && norm_scale_shift != nullptr) return RSVLD_EUNSUPPORTED;   // the normalised tensor is split by its own kernel (rsvld_groupnorm_apply_split)
     if (split && !d->out_f32 && d->residual != nullptr) return RSVLD_EINVAL;
     if ((int64_t)d->Ho * d->Wo >= ((int64_t)1 << 31)) return RSVLD_EUNSUPPORTED;
     if (norm_scale_shift != nullptr && d->upsample) return RSVLD_EUNSUPPORTED;   // no GroupNorm sits before an Upsample conv
@@ -888,7 +931,7 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     a.Hs = d->H; a.Ws = d->W; a.ush = d->upsample ? 1 : 0;
     a.out_f32 = d->out_f32 ? 1 : 0; a.act = d->act; a.norm_silu = norm_silu ? 1 : 0;
     a.alpha = d->alpha; a.beta = d->beta;
-    a.Ctot = seg * (d->Cin + d->Cin2);
+    a.Ctot = (hq ? 2 : seg) * (d->Cin + d->Cin2);   // logical K' channels per tap (16-bit elements of a weight row)
     a.nchunks = a.Ctot / 64;
     a.tiles_x = (d->Wo + TW - 1) / TW;
     a.tiles_y = (d->Ho + TH - 1) / TH;
@@ -896,5 +939,5 @@ extern "C" int rsvld_conv3x3_halo_nhwc(const rsvld_conv_desc* d, const float* no
     a.rv_stride = d->rowvec_stride > 0 ? d->rowvec_stride : d->Cout;
     a.Cout_out = d->Cout;
     hipStream_t s = (hipStream_t)stream;
-    return (d->dtype == RSVLD_F16 || w2) ? dispatch_halo<f16>(a, s) : dispatch_halo<bf16>(a, s);   // RSVLD_SPLIT runs the bf16 kernels, RSVLD_F16W2 the fp16 ones
+    return (d->dtype == RSVLD_F16 || w2 || hq) ? dispatch_halo<f16>(a, s) : dispatch_halo<bf16>(a, s);   // RSVLD_SPLIT runs the bf16 kernels, RSVLD_F16W2 the fp16 ones
 }

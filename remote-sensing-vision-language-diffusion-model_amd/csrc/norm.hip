@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void gn_partial_f32_kernel(const float* __rest
     }
 }
 
-// y = act(a[b,c] * v + s[b,c]) [* (1 + mod_scale) + mod_shift]; fp32 in (one or two sources); OUT: 0 planes, 1 fp32, 2 fp16 out
+// y = act(a[b,c] * v + s[b,c]) [* (1 + mod_scale) + mod_shift]; fp32 in (one or two sources); OUT: 0 planes, 1 fp32, 2 fp16, 3 RSVLD_F16Q8 rows
 template <int OUT>
 __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __restrict__ x1, const float* __restrict__ x2, void* __restrict__ y,
                                                              const float* __restrict__ ab, const float* __restrict__ mod_scale,
@@ -513,6 +513,8 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __rest
                 *(f32x4*)(o + 4) = (f32x4){f[4], f[5], f[6], f[7]};
             } else if (OUT == 2) {
                 *(u32x4*)((f16*)y + pix * C + cc * 8) = pack8<f16>(f);
+            } else if (OUT == 3) {
+                st_hq8<true, RSVLD_HQ8_SX_LO, RSVLD_HQ8_SX_HI>((f16*)y + pix * (2 * (int64_t)C), C, cc * 8, f);
             } else {
                 st_planes8((bf16*)y + pix * (2 * C), C, cc * 8, f);
             }
@@ -849,8 +851,11 @@ extern "C" int rsvld_groupnorm_apply_split(const float* x, const float* x2, void
     if (rpb < 2 * rif) rpb = 2 * rif;
     const int nblk = (HW + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
-    if (out_f32 < 0 || out_f32 > 2) return RSVLD_EINVAL;
-    if (out_f32 == 1)
+    if (out_f32 < 0 || out_f32 > 3 || (out_f32 == 3 && (C1 + C2) % 32)) return RSVLD_EINVAL;
+    if (out_f32 == 3)
+        hipLaunchKernelGGL(gn_apply_split_kernel<3>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
+                           mod_shift, HW, C1, C2, silu, rpb, mod_stride > 0 ? mod_stride : C);
+    else if (out_f32 == 1)
         hipLaunchKernelGGL(gn_apply_split_kernel<1>, dim3((unsigned)nblk, B), dim3(256), 0, s, x, x2, out, scale_shift, mod_scale1p,
                            mod_shift, HW, C1, C2, silu, rpb, mod_stride > 0 ? mod_stride : C);
     else if (out_f32 == 2)

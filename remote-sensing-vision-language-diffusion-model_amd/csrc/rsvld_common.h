@@ -101,6 +101,39 @@ __device__ __forceinline__ f32x2_t gelu_erf2_f(f32x2_t x) {
     return r - ax * q;
 }
 
+// ---- RSVLD_F16Q8 rows (round 6): C values as  [ h16: C x fp16 | C / 32 blocks of 64 B ]  = 4 C bytes.  A block holds two e4m3 parts P0, P1 of
+// its 32 channels in 16-byte pieces  { P0[0:16] | P1[0:16] | P0[16:32] | P1[16:32] }: the halo kernel's lane half h reads 16-byte slots h and
+// 2 + h of a 64-byte row (the fragment addresses of its fp16 k-steps), i.e. all of P_h -- its 32 bytes of v_mfma_scale_f32_32x32x64_f8f6f4.
+// Activations: h16 = fp16(x), P0 = e4m3((x - h16) 2^SX_LO), P1 = e4m3(x 2^SX_HI); weights: h16 = fp16(w), P0 = e4m3(w 2^SW_HI),
+// P1 = e4m3((w - h16) 2^SW_LO): lane half 0 contracts x_lo w_hi, lane half 1 x_hi w_lo -- the two cross terms of the split product.
+// OCP e4m3 through v_cvt_pk_fp8_f32 (round to nearest even), saturating at +-448 by a clamp in fp32.
+__device__ __forceinline__ uint32_t cvt4_e4m3(float a, float b, float c, float d) {
+    int r = 0;
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (uint32_t)r;
+}
+__device__ __forceinline__ float sat_e4m3(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
+__device__ __forceinline__ float sat_f16_nan(float s) { return fabsf(s) > 65504.f ? copysignf(65504.f, s) : s; }   // (NaN stays NaN)
+// 8 consecutive channels c0 .. c0 + 7 (c0 % 8 == 0) of one row; FIRST_LO: the lo part is P0 (activations), else P1 (weights)
+template <bool FIRST_LO, int S_LO, int S_HI>
+__device__ __forceinline__ void st_hq8(f16* row, int C, int c0, const float (&f)[8]) {
+    f16x8 h;
+    float lo[8], hs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = (f16)sat_f16_nan(f[e]);
+        lo[e] = sat_e4m3((f[e] - (float)h[e]) * (float)(1 << S_LO));
+        hs[e] = sat_e4m3(f[e] * (float)(1 << S_HI));
+    }
+    *(u32x4*)(row + c0) = __builtin_bit_cast(u32x4, h);
+    char* q = (char*)(row + C) + (c0 >> 5) * 64 + ((c0 & 16) << 1) + (c0 & 15);
+    const u32x2 vlo = {cvt4_e4m3(lo[0], lo[1], lo[2], lo[3]), cvt4_e4m3(lo[4], lo[5], lo[6], lo[7])};
+    const u32x2 vhi = {cvt4_e4m3(hs[0], hs[1], hs[2], hs[3]), cvt4_e4m3(hs[4], hs[5], hs[6], hs[7])};
+    *(u32x2*)(q + (FIRST_LO ? 0 : 16)) = vlo;
+    *(u32x2*)(q + (FIRST_LO ? 16 : 0)) = vhi;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

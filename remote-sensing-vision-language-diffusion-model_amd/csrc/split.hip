@@ -1122,6 +1122,20 @@ __global__ __launch_bounds__(256) void pack_weight_pairs_kernel(const float* __r
     }
 }
 
+// fp32 rows -> RSVLD_F16Q8 rows (activations: lo part first) / weight rows (hi part first); 8 channels per thread
+template <bool ACT>
+__global__ __launch_bounds__(256) void to_hq8_kernel(const float* __restrict__ x, f16* __restrict__ o, int64_t items, int C8) {
+    const int C = C8 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / C8;
+        const int c = (int)(i - row * C8) * 8;
+        float f[8];
+        ld8f(x + row * C + c, f);
+        if (ACT) st_hq8<true, RSVLD_HQ8_SX_LO, RSVLD_HQ8_SX_HI>(o + row * (2 * (int64_t)C), C, c, f);
+        else st_hq8<false, RSVLD_HQ8_SW_LO, RSVLD_HQ8_SW_HI>(o + row * (2 * (int64_t)C), C, c, f);
+    }
+}
+
 static unsigned ew_blocks(int64_t items) {
     int64_t b = cdiv64(items, 256);
     return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -1169,6 +1183,20 @@ extern "C" int rsvld_pack_weight_pairs(const float* w, void* w2, int64_t Cout, i
     if (!w || !w2 || Cout < 1 || taps < 1 || Ctot < 8 || Ctot % 8) return RSVLD_EINVAL;
     const int64_t items = Cout * taps * (Ctot / 8);
     hipLaunchKernelGGL(pack_weight_pairs_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, w, (f16*)w2, items, Ctot / 8);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_pack_weight_hq8(const float* w, void* whq, int64_t Cout, int taps, int Ctot, void* stream) {
+    if (!w || !whq || Cout < 1 || taps < 1 || Ctot < 32 || Ctot % 32) return RSVLD_EINVAL;
+    const int64_t items = Cout * taps * (Ctot / 8);
+    hipLaunchKernelGGL(to_hq8_kernel<false>, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, w, (f16*)whq, items, Ctot / 8);
+    return rsvld_check_launch();
+}
+
+extern "C" int rsvld_split_hq8(const float* x, void* out, int64_t rows, int C, void* stream) {
+    if (!x || !out || rows < 1 || C < 32 || C % 32) return RSVLD_EINVAL;
+    const int64_t items = rows * (C / 8);
+    hipLaunchKernelGGL(to_hq8_kernel<true>, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, x, (f16*)out, items, C / 8);
     return rsvld_check_launch();
 }
 

@@ -164,13 +164,31 @@ class SplitPolicy:
                     cache decision equal (tools/tolerance_check.py, tools/fulldepth_check.py; the residual stream, the norms, proj_in / proj_out and
                     every convolution stay fp32 / three-MFMA).  16.7 -> 10.5 s of GEMM time per 4096^2 image.
                     The convolutions are different: their weights rounded to fp16 (emulated through the triples of fp16(W), round 5) end at
-                    1.8e-3 on the goldens and 2.6e-3 / 2.3e-3 at full depth -- no two-MFMA form of the 3x3 layers on fp16 planes x fp16 weights."""
+                    1.8e-3 on the goldens and 2.6e-3 / 2.3e-3 at full depth -- no two-MFMA form of the 3x3 layers on fp16 planes x fp16 weights.
+    ``q8_convs``    (round 6) the ResBlock convolutions ("conv1", "conv2": the two 3x3 layers behind a GroupNorm + SiLU) that keep BOTH operands
+                    at ~22 bits but spend fewer matrix cycles on them: x w = f16(x) f16(w) + x_lo w_hi + x_hi w_lo with the two cross terms
+                    (2^-11 of the product) contracted in e4m3 on the block-scaled matrix instruction (dtype RSVLD_F16Q8: per 32 channels and tap
+                    two fp16 MFMAs + one scaled MFMA instead of six bf16 MFMAs).  Emulated at full depth over 50 steps before the kernel was
+                    written: mean distance from the fp32 family +3.5 %, maxima 5.8e-4 / 5.1e-4, every cache decision unchanged
+                    (profiles/r06_conv_lo8_emulation.txt).  Default: both groups in the shipped composition, none elsewhere (the VAE: real
+                    SDXL-VAE activations leave the fp16 range)."""
 
-    __slots__ = ("impl", "f16_inputs", "f16_weights")
+    __slots__ = ("impl", "f16_inputs", "f16_weights", "q8_convs")
     GROUPS = ("attn", "attn_out", "ff", "qkv", "proj", "conv1", "conv2")
     WEIGHT_GROUPS = ("qkv", "geglu", "attn_out", "ff_out")
+    Q8_GROUPS = ("conv1", "conv2")
 
-    def __init__(self, impl="planes", f16_inputs=("attn", "attn_out", "ff", "qkv"), f16_weights=None):
+    def __init__(self, impl="planes", f16_inputs=("attn", "attn_out", "ff", "qkv"), f16_weights=None, q8_convs=None):
+        if q8_convs is None:        # the default: both ResBlock convolutions, in the shipped composition of the UNets only
+            q8_convs = self.Q8_GROUPS if (impl == "planes" and {"attn", "attn_out", "ff", "qkv"} <= set(f16_inputs)) else ()
+        bad = [g for g in q8_convs if g not in self.Q8_GROUPS]
+        if bad:
+            raise ValueError(f"SplitPolicy.q8_convs {bad}: one of {self.Q8_GROUPS}")
+        if set(q8_convs) & set(f16_inputs):
+            raise ValueError("SplitPolicy: a convolution's input is either rounded to fp16 (f16_inputs) or kept with e4m3 cross terms (q8_convs)")
+        if q8_convs and impl != "planes":
+            raise ValueError("SplitPolicy.q8_convs exists in the product path (impl \"planes\") only")
+        self.q8_convs = frozenset(q8_convs)
         if f16_weights is None:     # the default: every transformer GEMM whose input is fp16
             f16_weights = tuple(g for g, i in (("qkv", "qkv"), ("geglu", "ff"), ("attn_out", "attn_out"), ("ff_out", "ff")) if i in f16_inputs and impl == "planes")
         bad = [g for g in f16_weights if g not in self.WEIGHT_GROUPS]
@@ -193,10 +211,10 @@ class SplitPolicy:
             raise ValueError(f"SplitPolicy.f16_weights {bad}: a layer's weights are rounded to fp16 only where its input is (f16_inputs)")
 
     def key(self):
-        return (self.impl, tuple(sorted(self.f16_inputs)), tuple(sorted(self.f16_weights)))
+        return (self.impl, tuple(sorted(self.f16_inputs)), tuple(sorted(self.f16_weights)), tuple(sorted(self.q8_convs)))
 
     def describe(self):
-        return {"impl": self.impl, "f16_inputs": sorted(self.f16_inputs), "f16_weights": sorted(self.f16_weights)}
+        return {"impl": self.impl, "f16_inputs": sorted(self.f16_inputs), "f16_weights": sorted(self.f16_weights), "q8_convs": sorted(self.q8_convs)}
 
     def __eq__(self, o):
         return isinstance(o, SplitPolicy) and self.key() == o.key()
@@ -205,7 +223,8 @@ class SplitPolicy:
         return hash(self.key())
 
     def __repr__(self):
-        return f"SplitPolicy(impl={self.impl!r}, f16_inputs={sorted(self.f16_inputs)}, f16_weights={sorted(self.f16_weights)})"
+        return (f"SplitPolicy(impl={self.impl!r}, f16_inputs={sorted(self.f16_inputs)}, f16_weights={sorted(self.f16_weights)}, "
+                f"q8_convs={sorted(self.q8_convs)})")
 
 
 UNET_POLICY = SplitPolicy()                                   # the UNets / ControlNet of Stage 2
@@ -240,6 +259,28 @@ def f16_group(group):
         return False
     pol = _CTX.get().policy
     return pol is not None and pol.impl == "planes" and group in pol.f16_inputs
+
+
+def q8_group(group):
+    """Does the current policy run the 3x3 convolution behind norm group ``group`` with e4m3 cross terms (RSVLD_F16Q8)?"""
+    if group is None:
+        return False
+    pol = _CTX.get().policy
+    return pol is not None and pol.impl == "planes" and group in pol.q8_convs
+
+
+class Q8Rows:
+    """An activation in the RSVLD_F16Q8 row format: ``t`` is an fp16-typed tensor ``[B, H, W, 2, C]`` whose first plane is fp16(x) and whose
+    second plane holds, per 32 channels, 64 bytes of e4m3 cross-term operands (include/rsvld_hip.h); only the halo convolution reads it."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    @property
+    def shape(self):
+        s = self.t.shape
+        return tuple(s[:-2]) + (s[-1],)
 
 
 class Planes:
@@ -382,13 +423,14 @@ def _launch(name, flops, nbytes, fn):
 class PackedConv:
     """K-major 16-bit weights of a Conv2d / Linear: ``w[Cout_p, KH*KW*Cin_p]``, bias fp32."""
 
-    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu", "w3", "w2", "w1")
+    __slots__ = ("w", "bias", "cin", "cout", "cin_p", "cout_p", "kh", "kw", "geglu", "w3", "w2", "w1", "wq8")
 
     def __init__(self, w, bias, cin, cout, cin_p, cout_p, kh, kw, geglu=False):
         self.w, self.bias = w, bias
         self.w3 = None     # split product path: bf16 triples [Cout_p][KH*KW][W_hi | W_lo | W_hi], packed on first use from the fp32 ``w``
         self.w1 = None     # the fp32 ``w`` rounded to fp16 (SplitPolicy.f16_weights: fp16 activation x fp16 weight, one MFMA), likewise
         self.w2 = None     # fp16 pairs [Cout_p][KH*KW][W_lo | W_hi] (dtype RSVLD_F16W2: fp16 activations), likewise
+        self.wq8 = None    # RSVLD_F16Q8 rows [Cout_p][KH*KW][fp16(w) | e4m3 cross-term blocks], likewise
         self.cin, self.cout, self.cin_p, self.cout_p = cin, cout, cin_p, cout_p
         self.kh, self.kw, self.geglu = kh, kw, geglu
 
@@ -658,6 +700,78 @@ def _w2(pc):
     return pc.w2
 
 
+def _wq8(pc):
+    """RSVLD_F16Q8 weight rows of a PackedConv (fp32 K-major ``w``, input channels a multiple of 32), packed once on the device."""
+    if pc.wq8 is None:
+        if pc.w.dtype != torch.float32 or pc.cin_p % 32:
+            raise L.RsvldError("e4m3 cross-term weights: fp32-packed weights with a multiple of 32 input channels expected")
+        taps = pc.kh * pc.kw
+        wq = torch.empty((pc.cout_p, taps * 2 * pc.cin_p), device=pc.w.device, dtype=torch.float16)
+        L.check(L.load().rsvld_pack_weight_hq8(_ptr(pc.w), _ptr(wq), pc.cout_p, taps, pc.cin_p, _stream()), "rsvld_pack_weight_hq8")
+        pc.wq8 = wq
+    return pc.wq8
+
+
+def to_q8rows(x):
+    """fp32 ``[..., C]`` (C % 32 == 0, contiguous) -> Q8Rows (rsvld_split_hq8): the activation format of RSVLD_F16Q8."""
+    _need_gpu(x)
+    Cc = x.shape[-1]
+    if x.dtype != torch.float32 or not x.is_contiguous() or Cc % 32:
+        raise L.RsvldError("to_q8rows: contiguous fp32 with a multiple of 32 channels expected")
+    t = torch.empty(tuple(x.shape[:-1]) + (2, Cc), device=x.device, dtype=torch.float16)
+    _launch("split_q8", 0.0, 8.0 * x.numel(), lambda: L.check(L.load().rsvld_split_hq8(_ptr(x), _ptr(t), x.numel() // Cc, Cc, _stream()),
+                                                            "rsvld_split_hq8"))
+    return Q8Rows(t)
+
+
+def _q8_conv_eligible(B, H, W, Cc, pc, stride, pad, upsample, act, out_planes):
+    """Can rsvld_conv3x3_halo_nhwc run this layer as RSVLD_F16Q8 (and would the halo kernel be chosen for it in the split precision)?"""
+    if pc.kh != 3 or pc.kw != 3 or stride != 1 or upsample or out_planes or act != L.ACT_NONE or pad not in (None, 1, (1, 1, 1, 1)):
+        return False
+    if Cc % 64 or pc.cout_p <= 64 or pc.cout_p % 8 or W < 16 or H < 4 or pc.w.dtype != torch.float32:
+        return False
+    ctx = _CTX.get()
+    Bp = -(-B // ctx.plan_div)
+    return ctx.use_halo and Bp * ((H + 7) // 8) * ((W + 31) // 32) * ((pc.cout_p + 127) // 128) >= ctx.split_halo_min_wgs
+
+
+def _conv2d_q8(xq, pc, *, rowvec, residual, alpha, beta, stats):
+    """3x3 / stride 1 / pad 1 on Q8Rows: fp32 out (+ fp32 residual), epilogue statistics for the next GroupNorm."""
+    ctx = _CTX.get()
+    B, H, W, Cc = xq.shape
+    if Cc != pc.cin_p:
+        raise L.RsvldError(f"conv2d (q8): input channels {Cc} != packed {pc.cin_p}")
+    out = torch.empty((B, H, W, pc.cout_p), device=xq.t.device, dtype=torch.float32)
+    if residual is not None and (isinstance(residual, Planes) or residual.dtype != torch.float32 or tuple(residual.shape) != tuple(out.shape)
+                                 or not residual.is_contiguous()):
+        raise L.RsvldError("conv2d (q8): residual must be fp32 and match the output shape")
+    rv_stride = 0
+    if rowvec is not None:
+        if tuple(rowvec.shape) != (B, pc.cout_p) or rowvec.dtype != torch.float32 or rowvec.stride(1) != 1:
+            raise L.RsvldError("conv2d: rowvec must be fp32 [B, Cout] with unit inner stride")
+        rv_stride = rowvec.stride(0) if B > 1 else pc.cout_p
+    wq = _wq8(pc)
+    d = L.ConvDesc(
+        x=xq.t.data_ptr(), x2=None, w=wq.data_ptr(), bias=None if pc.bias is None else pc.bias.data_ptr(),
+        rowvec=None if rowvec is None else rowvec.data_ptr(), residual=None if residual is None else residual.data_ptr(), out=out.data_ptr(),
+        B=B, H=H, W=W, Cin=Cc, Cin2=0, Cout=pc.cout_p, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, Ho=H, Wo=W, upsample=0,
+        dtype=L.F16Q8, out_f32=1, act=L.ACT_NONE, alpha=alpha, beta=beta, rowvec_stride=rv_stride, plan_div=ctx.plan_div, tune=ctx.tune)
+    lib = L.load()
+    if not lib.rsvld_conv3x3_halo_supported(C.byref(d)):
+        raise L.RsvldError("conv2d (q8): shape not supported by the halo kernel (checked by _q8_conv_eligible)")
+    part_out, ntiles = None, ((H + 7) // 8) * ((W + 31) // 32)
+    if stats:
+        part_out = torch.empty((B, ntiles, pc.cout_p, 2), device=out.device, dtype=torch.float32)
+    flops = 2.0 * B * H * W * pc.cout * pc.cin * 9
+    nbytes = 4.0 * (B * H * W * Cc + out.numel() + (0 if residual is None else residual.numel())) + 4.0 * pc.w.numel()
+    _launch("conv_halo_128_q8" + _detail(B, H, W, Cc, 0, pc, 1, False), flops, nbytes, lambda: L.check(
+        lib.rsvld_conv3x3_halo_nhwc(C.byref(d), None, 0, _ptr(part_out), _stream()), "rsvld_conv3x3_halo_nhwc"))
+    if part_out is not None:
+        out._gn_part = (part_out, ntiles)
+    out._nhwc = True
+    return out
+
+
 def _gn_scale_shift_f32(x, x2, gamma, nbeta, groups, eps):
     """(scale, shift) fp32 ``[B, C1+C2, 2]`` of a GroupNorm over fp32 NHWC ``[x | x2]``: from the producers' epilogue partials when
     every source carries them (no pass over the tensors), else one statistics pass."""
@@ -681,7 +795,7 @@ def _gn_scale_shift_f32(x, x2, gamma, nbeta, groups, eps):
     return ab
 
 
-def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None, f16=False):
+def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None, f16=False, q8=False):
     B, H, W, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[-1]
     Cc = C1 + C2
@@ -692,6 +806,12 @@ def _gn_apply_split(x, x2, ab, silu, planes, mod_scale1p=None, mod_shift=None, f
                 or mod_scale1p.dtype != torch.float32 or mod_shift.dtype != torch.float32):
             raise L.RsvldError("group_norm: modulation tensors must be fp32, share a row stride and be channel-contiguous")
     f16 = f16 and planes          # the fp16 hand-over replaces a planes output only
+    if q8:                        # RSVLD_F16Q8 rows (the input of a convolution with e4m3 cross terms)
+        out = torch.empty((B, H, W, 2, Cc), device=x.device, dtype=torch.float16)
+        _launch("groupnorm_apply_q8", 0.0, 8.0 * B * H * W * Cc, lambda: L.check(L.load().rsvld_groupnorm_apply_split(
+            _ptr(x), _ptr(x2), _ptr(out), _ptr(ab), _ptr(mod_scale1p), _ptr(mod_shift), mod_stride, B, H * W, C1, C2, int(silu), 3, _stream()),
+            "rsvld_groupnorm_apply_split"))
+        return Q8Rows(out)
     if f16:
         out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float16)
     elif planes:
@@ -730,6 +850,11 @@ def _conv2d_split(x, pc, *, x2, stride, pad, upsample, rowvec, residual, act, al
             x16 = _gn_apply_split(x, x2, ab, silu, planes=True, f16=True)
             return conv2d(x16, pc, stride=stride, pad=pad, upsample=upsample, rowvec=rowvec, residual=residual, act=act, alpha=alpha,
                           beta=beta, stats=stats, out_planes=out_planes, out_group=out_group, group=group)
+        if q8_group(norm_group) and _q8_conv_eligible(x.shape[0], x.shape[1], x.shape[2], x.shape[3] + (0 if x2 is None else x2.shape[3]), pc,
+                                                      stride, pad, upsample, act, out_planes):
+            # both operands keep ~22 bits, the two cross terms of the product run in e4m3 (RSVLD_F16Q8; SplitPolicy.q8_convs)
+            return _conv2d_q8(_gn_apply_split(x, x2, ab, silu, planes=True, q8=True), pc, rowvec=rowvec, residual=residual, alpha=alpha,
+                              beta=beta, stats=stats)
         x, x2 = _gn_apply_split(x, x2, ab, silu, planes=True), None
     ctx = _CTX.get()
     x = to_planes(x)

@@ -633,3 +633,106 @@ def test_transformer_block_policy_composition(cuda):
     e_pol = float((outs["unet"] - outs["fp32"]).abs().max()) / rng
     print(f"transformer block vs the fp32 family: all-split {e_all:.2e}, UNet policy {e_pol:.2e} of the range {rng:.2f}")
     assert e_all < 1e-4 and e_pol < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: RSVLD_F16Q8 -- the ResBlock convolutions of a split-precision network with the two cross terms of the product in e4m3 on the
+# block-scaled matrix instruction (SplitPolicy.q8_convs).  Two references: (a) the ARITHMETIC the kernel promises, restated on the host in
+# fp64 from the same fp32 normalised tensor (torch's own e4m3 casts): must agree to fp32 accumulation noise -- this pins the row format,
+# the 16-byte interleave, the lane-half pairing and the E8M0 scale bytes; (b) plain fp64 of the layer: must sit where the split precision
+# sits (~2^-15 per product), an order of magnitude inside what an fp16-operand form would give.
+def _q8_parts(v, s_hi, s_lo):
+    """host restatement of st_hq8: (fp16 part, e4m3(v 2^s_hi) / 2^s_hi, e4m3((v - fp16 v) 2^s_lo) / 2^s_lo), all fp64"""
+    h = v.half().float()
+    q = lambda t, s: (t * 2.0 ** s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).double() / 2.0 ** s
+    return h.double(), q(v, s_hi), q(v - h, s_lo)
+
+
+Q8_CASES = [
+    # B, H, W, C1, C2, Cout, rowvec, residual        which halo instantiation
+    (2, 24, 40, 128, 0, 256, True, True),          # 4-wave tiles, one source, every epilogue input
+    (1, 19, 37, 64, 64, 128, False, True),         # two sources (a decoder ResBlock's skip concat), ragged tile rows and columns
+    (4, 128, 128, 192, 0, 256, True, False),       # 8-wave (16 x 32 pixel) tiles: >= 192 of them and K >= 192
+    (2, 16, 32, 320, 0, 320, False, False),        # Cout = 2.5 column tiles, 10 bodies
+]
+
+
+@pytest.mark.parametrize("case", Q8_CASES)
+def test_conv3x3_q8_cross_terms(cuda, case):
+    from rsvld_amd import ops
+    B, H, W, C1, C2, Co, use_rv, use_res = case
+    C = C1 + C2
+    g = torch.Generator().manual_seed(B * H + C + Co)
+    x1 = torch.randn(B, C1, H, W, generator=g) * 1.7 + 0.3
+    x2 = torch.randn(B, C2, H, W, generator=g) * 0.6 - 0.2 if C2 else None
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    b = torch.randn(Co, generator=g) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    rv = torch.randn(B, Co, generator=g) if use_rv else None
+    res = torch.randn(B, Co, H, W, generator=g) if use_res else None
+    pc = ops.pack_conv(w, b, torch.float32, cuda, cin_split=(C1, C2) if C2 else None)
+    xd, x2d = _nhwc(x1, cuda), None if x2 is None else _nhwc(x2, cuda)
+    norm = (gamma.to(cuda), beta.to(cuda), 32, 1e-5, True)
+    kw = dict(x2=x2d, pad=1, rowvec=None if rv is None else rv.to(cuda), residual=None if res is None else _nhwc(res, cuda), norm=norm,
+              stats=True, alpha=0.5 if use_res else 1.0)
+    with ops.f32_split(ops.UNET_POLICY), ops.tuning(split_halo_min_wgs=0, profiler=(prof := ops.LaunchProfiler())):
+        got = ops.conv2d(xd, pc, norm_group="conv1", **kw)
+        ab = ops._gn_scale_shift_f32(xd, x2d, norm[0], norm[1], 32, 1e-5)
+        xn = ops._gn_apply_split(xd, x2d, ab, True, planes=False).cpu()          # the fp32 tensor the q8 apply kernel quantises
+    names = set(prof.summary())
+    assert "conv_halo_128_q8" in names and "groupnorm_apply_q8" in names, names   # the route under test ran
+    with ops.f32_split(ops.SplitPolicy(q8_convs=())), ops.tuning(split_halo_min_wgs=0):
+        split = ops.conv2d(xd, pc, norm_group="conv1", **kw)                      # the same layer as three bf16 MFMAs per product
+    assert got.dtype == torch.float32 and got.shape == (B, H, W, Co) and hasattr(got, "_gn_part")
+    # (a) the promised arithmetic, in fp64 on the host
+    from rsvld_amd import _lib as L
+    wp = pc.w.cpu().view(Co, 3, 3, C).permute(0, 3, 1, 2)                         # the packed K order is [tap][x | x2] = the concat order
+    xh, xq, xlq = _q8_parts(xn.permute(0, 3, 1, 2), 2, 14)
+    wh, wq, wlq = _q8_parts(wp, 6, 18)
+    conv = lambda a, ww: F.conv2d(a, ww, None, padding=1)
+    y = conv(xh, wh) + conv(xlq, wq) + conv(xq, wlq) + b.double().view(1, -1, 1, 1)
+    if rv is not None:
+        y = y + rv.double()[:, :, None, None]
+    y = y * kw["alpha"]
+    if res is not None:
+        y = y + res.double()
+    _cmp(got.permute(0, 3, 1, 2), y, 5e-6, f"q8 convolution {case} vs its arithmetic restated in fp64")
+    # (b) the layer itself
+    xe = F.silu(F.group_norm(x1.double() if x2 is None else torch.cat([x1, x2], 1).double(), 32, gamma.double(), beta.double(), 1e-5))
+    ye = F.conv2d(xe, w.double(), b.double(), padding=1)
+    if rv is not None:
+        ye = ye + rv.double()[:, :, None, None]
+    ye = ye * kw["alpha"] + (0 if res is None else res.double())
+    e_q8 = _cmp(got.permute(0, 3, 1, 2), ye, 4e-5, f"q8 convolution {case} vs fp64")
+    e_sp = _cmp(split.permute(0, 3, 1, 2), ye, 4e-5, "   the same layer, three bf16 MFMAs per product")
+    print(f"   q8 / split distance from fp64: {e_q8 / max(e_sp, 1e-30):.2f}")
+    # epilogue statistics = sums over the stored tensor
+    part, ntiles = got._gn_part
+    s = part.double().sum(1).cpu()
+    gd = got.double().cpu()
+    _cmp(s[..., 0], gd.sum((1, 2)), 1e-5, "   epilogue sum")
+    _cmp(s[..., 1], (gd * gd).sum((1, 2)), 1e-5, "   epilogue sum of squares")
+
+
+def test_q8_rows_format_and_saturation(cuda):
+    """rsvld_split_hq8 / rsvld_pack_weight_hq8: the row format bit for bit against torch's casts; saturation at the fp16 / e4m3 ranges; NaN kept."""
+    from rsvld_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(5, 7, 64, generator=g) * torch.logspace(-5, 2, 64)
+    x[0, 0, :4] = torch.tensor([1e6, -70000.0, 300.0, float("nan")])
+    q = ops.to_q8rows(x.to(cuda))
+    assert q.shape == (5, 7, 64) and q.t.shape == (5, 7, 2, 64)
+    t = q.t.cpu()
+    h = t[..., 0, :].float()
+    want_h = x.clone()
+    want_h[0, 0, 0], want_h[0, 0, 1] = 65504.0, -65504.0
+    assert torch.equal(h[0, 0, 4:], x.half().float()[0, 0, 4:]) and bool(torch.isnan(h[0, 0, 3])) and h[0, 0, :2].tolist() == [65504.0, -65504.0]
+    blocks = t[..., 1, :].contiguous().view(torch.uint8).view(5, 7, 2, 4, 16)          # [block][16-byte piece][byte]; pieces P0a P1a P0b P1b
+    p0 = torch.cat([blocks[..., 0, :], blocks[..., 2, :]], -1).reshape(5, 7, 64).view(torch.float8_e4m3fn).float()
+    p1 = torch.cat([blocks[..., 1, :], blocks[..., 3, :]], -1).reshape(5, 7, 64).view(torch.float8_e4m3fn).float()
+    hh = x.half().float()
+    want0 = ((x - hh) * 2.0 ** 14).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    want1 = (x * 4.0).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    ok = torch.isfinite(x) & (x.abs() < 60000)
+    assert torch.equal(p0[ok], want0[ok]) and torch.equal(p1[ok], want1[ok])
+    assert p1[0, 0, 0] == 448.0 and p1[0, 0, 1] == -448.0 and p1[0, 0, 2] == 448.0      # 300 * 4 saturates

@@ -46,3 +46,34 @@ for (B, H, W, C1, C2, Co) in SPLIT:
         ms, names = timed(lambda: ops.conv2d(x, pc, x2=x2, stats=True))
     fl = 3.0 * 2.0 * B * H * W * Co * (C1 + C2) * 9
     print(f"split B{B} {H}x{W} Cin{C1}+{C2} Cout{Co}: {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} MFMA-TF/s  {names}", flush=True)
+
+# round 6: the same Stage-2 layers as a ResBlock runs them (GroupNorm + SiLU in front): planes + three bf16 MFMAs vs RSVLD_F16Q8 rows + e4m3 cross terms
+def timed_all(fn):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    prof = ops.LaunchProfiler()
+    with ops.tuning(profiler=prof):
+        for _ in range(reps):
+            fn()
+    return {k: r["ms"] / reps for k, r in prof.summary().items()}
+
+
+for (B, H, W, C1, C2, Co) in SPLIT:
+    x = torch.randn(B, H, W, C1, device=dev)
+    x2 = torch.randn(B, H, W, C2, device=dev) if C2 else None
+    w = torch.randn(Co, C1 + C2, 3, 3) / (3 * (C1 + C2) ** 0.5)
+    pc = ops.pack_conv(w, torch.zeros(Co), torch.float32, dev, cin_split=(C1, C2) if C2 else None)
+    gamma, beta = torch.ones(C1 + C2, device=dev), torch.zeros(C1 + C2, device=dev)
+    rv = torch.randn(B, Co, device=dev)
+    res = {}
+    for name, pol in (("split", ops.SplitPolicy(q8_convs=())), ("q8", ops.UNET_POLICY)):
+        with ops.f32_split(pol):
+            res[name] = timed_all(lambda: ops.conv2d(x, pc, x2=x2, norm=(gamma, beta, 32, 1e-5, True), norm_group="conv1", stats=True, rowvec=rv))
+    tot = {k: sum(v.values()) for k, v in res.items()}
+    conv = {k: sum(t for n, t in v.items() if n.startswith("conv_")) for k, v in res.items()}
+    fl = 2.0 * B * H * W * Co * (C1 + C2) * 9
+    print(f"resblock conv B{B} {H}x{W} Cin{C1}+{C2} Cout{Co}: split {tot['split']*1e3:7.0f} us (conv {conv['split']*1e3:7.0f}) | q8 {tot['q8']*1e3:7.0f} us "
+          f"(conv {conv['q8']*1e3:7.0f} = {fl/conv['q8']/1e9:6.0f} algorithmic TF/s) | conv x{conv['split']/conv['q8']:.2f}, layer x{tot['split']/tot['q8']:.2f}  "
+          f"{sorted(res['q8'])}", flush=True)
+    del x, x2
