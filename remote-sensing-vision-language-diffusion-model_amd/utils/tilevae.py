@@ -68,7 +68,11 @@ def merge_stats(stats, pixels):
     st = torch.stack(stats, 0) if isinstance(stats, (list, tuple)) else stats   # [T,B,32,2]
     p = torch.tensor(pixels, dtype=torch.float32, device=st.device) / max(pixels)
     p = (p / p.sum()).view(-1, 1, 1, 1)
-    return (st * p).sum(0).contiguous()
+    w = st * p
+    # one reduction PER IMAGE over a contiguous [T,32,2] block: the order of a torch reduction depends on the shape it is given, and with
+    # T = 64 tiles (4096^2) a [T,B,32,2] sum gave image 0 other last bits at B = 2 than at B = 1 (found by tests/test_gpu_batch16.py at
+    # configs[3]'s size; the 4-tile images of the 1024^2 test happened to agree) -- batch members must equal their batch-of-1 runs
+    return torch.stack([w[:, b].contiguous().sum(0) for b in range(w.shape[1])], 0)
 
 
 # ---- per-tile programs (generators yielding (tensor, norm_layer) at every GroupNorm) -----------------

@@ -95,6 +95,7 @@ if __name__ == "__main__":
              "split_w1_all": ("w2", "split", "split", P(f16_weights=("qkv", "geglu", "attn_out", "ff_out")), None),   # + to_out and ff.net.2 (RSVLD_F16W1)
              "split_w1_ao": ("w2", "split", "split", P(f16_weights=("qkv", "geglu", "attn_out")), None),
              "split_w1_fo": ("w2", "split", "split", P(f16_weights=("qkv", "geglu", "ff_out")), None),
+             "split_noq8": ("w2", "split", "split", P(q8_convs=()), None),   # round 5's composition: the ResBlock convolutions as three bf16 MFMAs
              "split_full": ("split", "split", "split", ops.ALL_SPLIT, ops.ALL_SPLIT)}
     if "--only" in sys.argv:
         modes = {k: v for k, v in modes.items() if k in sys.argv[sys.argv.index("--only") + 1].split(",")}
