@@ -48,6 +48,7 @@ def test_constants_match_header():
     for name, expr in re.findall(r"^#define\s+(RSVLD_[A-Z0-9_]+)\s+(\(?-?[0-9]+(?:\s*<<\s*[0-9]+)?\)?)", src, flags=re.M):
         defs[name] = eval(expr)                      # integer literals and shifts only (the regular expression admits nothing else)
     want = {"RSVLD_F16": _lib.F16, "RSVLD_BF16": _lib.BF16, "RSVLD_F32": _lib.F32, "RSVLD_SPLIT": _lib.SPLIT,
+            "RSVLD_F16W2": _lib.F16W2, "RSVLD_F16W1": _lib.F16W1, "RSVLD_F16Q8": _lib.F16Q8,
             "RSVLD_ACT_NONE": _lib.ACT_NONE, "RSVLD_ACT_SILU": _lib.ACT_SILU, "RSVLD_ACT_GEGLU": _lib.ACT_GEGLU,
             "RSVLD_TUNE_STAGES_SHIFT": _lib.TUNE_STAGES_SHIFT, "RSVLD_TUNE_NO_KSPLIT": _lib.TUNE_NO_KSPLIT,
             "RSVLD_TUNE_REG_STAGING": _lib.TUNE_REG_STAGING, "RSVLD_TUNE_HALO_NW4": _lib.TUNE_HALO_NW4,

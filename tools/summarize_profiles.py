@@ -16,7 +16,7 @@ import os
 import re
 
 
-SEG_SFX = {"1": "", "2": "_w2", "3": "_split", "4": "_w1"}   # round 5: the K-segment template parameter of the matrix kernels (pairs / triples)
+SEG_SFX = {"1": "", "2": "_w2", "3": "_split", "4": "_w1", "5": "_q8"}   # the K-segment template parameter of the matrix kernels (pairs / triples / round 6: fp16 + e4m3 cross terms)
 
 
 def short_name(n):
