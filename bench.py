@@ -1007,6 +1007,8 @@ def main():
                                                            "instead of ops.UNET_POLICY's")
     ap.add_argument("--unet-f16-weights", default=None, help="experiment: the ops.SplitPolicy.f16_weights of the Stage-2 UNets (comma list; an empty "
                                                             "string = every weight of the fp16-input GEMMs as a pair) instead of ops.UNET_POLICY's")
+    ap.add_argument("--unet-q8-convs", default=None, help="experiment: the ops.SplitPolicy.q8_convs of the Stage-2 UNets (comma list; an empty string = the ResBlock "
+                                                         "convolutions as three bf16 MFMAs per product, round 5's composition) instead of ops.UNET_POLICY's")
     ap.add_argument("--profile-detail", action="store_true", help="append every matrix layer's shape to its group in roofline.by_kernel")
     ap.add_argument("--dev-env", action="store_true", help="apply the developer A/B switches of the environment (rsvld_amd.devtools.apply_env)")
     ap.add_argument("--pmc-pass", action="store_true", help="c4: one iteration of each stage + the fixed part and nothing "
@@ -1038,11 +1040,12 @@ def main():
         devtools.apply_env()
     if args.profile_detail:
         ops.set_defaults(profile_detail=True)
-    if args.unet_f16_groups is not None or args.unet_f16_weights is not None:     # an explicit policy ARGUMENT of set_precision (apply_precision)
+    if args.unet_f16_groups is not None or args.unet_f16_weights is not None or args.unet_q8_convs is not None:     # an explicit policy ARGUMENT of set_precision (apply_precision)
         global UNET_POLICY
         gi = ops.UNET_POLICY.f16_inputs if args.unet_f16_groups is None else tuple(g for g in args.unet_f16_groups.split(",") if g)
         gw = None if args.unet_f16_weights is None else tuple(g for g in args.unet_f16_weights.split(",") if g)
-        UNET_POLICY = ops.SplitPolicy(f16_inputs=tuple(gi), f16_weights=gw)
+        gq = None if args.unet_q8_convs is None else tuple(g for g in args.unet_q8_convs.split(",") if g)
+        UNET_POLICY = ops.SplitPolicy(f16_inputs=tuple(gi), f16_weights=gw, q8_convs=gq)
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

@@ -122,7 +122,7 @@ def stage1(args, dev, fh):
         (want, wx, t32), (got, gx, tw2) = runs["fp32"], runs["w2"]
         per_step = [(float((a - b).abs().max()), float((a - b).abs().mean())) for a, b in zip(gx, wx)]
         d = (got - want).abs()
-        emit(fh, {"stage": 1, "side": side, "tokens_level3": (side // 8) ** 2 * 4 if side >= 8 else None, "steps": steps,
+        emit(fh, {"stage": 1, "side": side, "attention_tokens": (side // 8) ** 2, "steps": steps,
                   "pixel_max": float(d.max()), "pixel_mean": float(d.mean()), "pixel_range": float(want.abs().max()),
                   "inside_1e-3": bool(float(d.max()) < 1e-3),
                   "per_step_max": [round(a, 7) for a, _ in per_step], "per_step_mean": [round(b, 8) for _, b in per_step],
