@@ -279,9 +279,9 @@ def dist_gather_rows(vals, dev, world):
         return [[float(v) for v in vals]]
     on_host = torch.distributed.get_backend() == "gloo"
     t = torch.tensor(vals, device="cpu" if on_host else dev, dtype=torch.float64)
-    out = torch.empty((world, len(vals)), device=t.device, dtype=torch.float64)
+    out = torch.empty(world * len(vals), device=t.device, dtype=torch.float64)    # (the flat, concatenated form: the one every backend takes)
     torch.distributed.all_gather_into_tensor(out, t)
-    return [[float(v) for v in row] for row in out.tolist()]
+    return [[float(v) for v in row] for row in out.view(world, len(vals)).tolist()]
 
 
 def barrier(world):

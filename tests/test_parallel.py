@@ -45,6 +45,8 @@ def _ranks(n, world):
     for r in range(world):
         assert res[r]["idx"] == list(range(r, n, world))
         assert res[r]["vals"] == want                           # every rank holds all images, in image order
+        assert res[r]["rows"] == [[q + 0.5, 10.0 * q] for q in range(world)]      # bench.dist_gather_rows: every rank's figures on every rank
+        assert res[r]["max"] == [float(world - 1), 7.0]                            # bench.dist_max
     assert sorted(i for d in res for i in d["idx"]) == list(range(n))   # each image processed exactly once
 
 
