@@ -3,7 +3,12 @@ RSVLD_LIB=<another build of librsvld_hip.so> selects a different library for A/B
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from rsvld_amd import ops
+from rsvld_amd import _lib, ops
+
+if os.environ.get("RSVLD_LIB"):      # an OLDER build may lack entry points added since: bind only what it exports (this tool calls rsvld_attention only)
+    import ctypes
+    _old = ctypes.CDLL(os.environ["RSVLD_LIB"])
+    _lib.SIGNATURES = {k: v for k, v in _lib.SIGNATURES.items() if hasattr(_old, k)}
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
