@@ -121,7 +121,8 @@ def test_stage2_full_depth_50_steps_latent128_inside_1e3(cuda, full_model, thr):
     """The same measurement one size up: 1024^2 input = latent 128 (16 384 tokens at level 0, 4 x the keys per softmax row of the latent-64
     runs above), tiled VAE, all 50 EDM steps, tolerance composition vs the fp32-operand family.  Together with the truncated runs at latent
     256 / 512 (tools/tolerance_at_scale.py, profiles/r06_tolerance_at_scale.txt) this is the growth law in the token count: the distance
-    does not grow with it (measured 6.7e-4 / 3.9e-5 cache off, 7.0e-4 / 4.5e-5 at 0.3, all 50 decisions equal)."""
+    does not grow with it (tools/tolerance_at_scale.py on the final composition, untiled VAE: 8.2e-4 / 3.9e-5 cache off, 5.8e-4 / 4.6e-5 at 0.3, all 50
+    decisions equal; the maximum over 3 M pixels scatters between runs of different summation order, the mean is the stable figure)."""
     import bench
     img = bench.synthetic_image((1, 3, 1024, 1024), seed=4321, smooth=4).to(cuda)
     m = full_model
