@@ -122,11 +122,11 @@ typedef struct rsvld_conv_desc {
  * of :250-285).  x : fp16; w : plain fp16 [Cout][Cin] (what RSVLD_F16 takes): ONE MFMA per product -- with the OUTPUT side of the
  * multi-segment family: out fp32 (out_f32 must be 1), residual fp32, out = alpha * (x W + b) + beta * residual in fp32.  The same layer with
  * a 16-bit output is plain RSVLD_F16. */
-/* dtype = RSVLD_F16Q8 (round 6; accepted by rsvld_conv3x3_halo_nhwc, Cout > 64, (Cin + Cin2) % 32 == 0, no fused norm): the 3x3 convolutions
+/* dtype = RSVLD_F16Q8 (round 6; accepted by rsvld_conv3x3_halo_nhwc: Cout > 64, ONE source (Cin2 = 0), Cin % 64 == 0, no fused norm, no up-sampling): the 3x3 convolutions
  * of the split-precision UNets with FEWER MATRIX CYCLES PER PRODUCT.  x w = x_hi w_hi + x_lo w_hi + x_hi w_lo; the two cross terms are 2^-11 of
  * the product when the hi parts are fp16, so their operands run as e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4 (2.26 x the 16-bit FLOP rate
  * measured, profiles/r06_mfma_f8f6f4.txt): per 32 channels and tap 2 fp16 MFMAs + 1 scaled MFMA instead of 6 bf16 MFMAs.
- *     x, x2 : [B,H,W, 4 C bytes]  row = [ fp16(x) (C) | C / 32 blocks of 64 B { P0[0:16] | P1[0:16] | P0[16:32] | P1[16:32] } ],
+ *     x     : [B,H,W, 4 C bytes]  row = [ fp16(x) (C) | C / 32 blocks of 64 B { P0[0:16] | P1[0:16] | P0[16:32] | P1[16:32] } ],
  *             P0 = e4m3((x - fp16 x) 2^14), P1 = e4m3(x 2^2) of the block's 32 channels  (rsvld_groupnorm_apply_split out_f32 = 3, rsvld_split_hq8)
  *     w     : [Cout][9][ fp16(w) (Ctot) | Ctot / 32 blocks likewise ], P0 = e4m3(w 2^6), P1 = e4m3((w - fp16 w) 2^18)   (rsvld_pack_weight_hq8)
  * (the 16-byte interleave lets the kernel read a block with the fragment addresses of its fp16 k-steps: lane half h gets all of P_h)

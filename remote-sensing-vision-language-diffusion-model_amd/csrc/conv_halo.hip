@@ -900,7 +900,8 @@ extern "C" int rsvld_conv3x3_halo_supported(const rsvld_conv_desc* d) {
     if (d->Cin % 64 != 0 || d->Cin2 % 64 != 0) return 0;
     if (d->act == RSVLD_ACT_GEGLU) return 0;
     if (d->out_f32 && d->Cout > 32 && d->dtype != RSVLD_SPLIT && d->dtype != RSVLD_F16W2 && d->dtype != RSVLD_F16Q8) return 0;
-    if (d->dtype == RSVLD_F16Q8 && (d->Cout <= 64 || !d->out_f32 || d->upsample)) return 0;   // the 128-wide kernels only; fp32 out
+    if (d->dtype == RSVLD_F16Q8 && (d->Cout <= 64 || !d->out_f32 || d->upsample || d->Cin2 != 0)) return 0;   // the 128-wide kernels only; fp32 out; ONE source
+                                                                                                              // (the GroupNorm apply pass that writes q8 rows has already concatenated)
     if (d->Wo < 16 || d->Ho < 4) return 0;   // tiny maps: the 8x32 tile would be mostly padding
     return 1;
 }
